@@ -1,0 +1,169 @@
+"""Preprocess + decode restatements in numpy (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+Preprocess
+----------
+Reference: OnnxRuntimeBackend::preprocess (VisionPilot/middleware_recipes/common/backends/
+onnx_runtime_backend.cpp:41-60: cv::resize INTER_LINEAR to 640x320, convertTo 1/255, subtract/divide
+with BGR-ordered ImageNet constants, split -> planes B,G,R); EgoLanesOnnxEngine::preprocessEgoLanes
+(VisionPilot/production_release/src/inference/onnxruntime_engine.cpp:72-102: resize, BGR->RGB, /255,
+(x-MEAN[c])/STD[c] -> planes R,G,B); Python ToTensor+Normalize (Models/inference/scene_seg_infer.py:15-20).
+
+cv::resize is OpenCV (third-party, not under /root/reference, not installed here): PARITY UNPINNED.
+Our definition -- which the engine must reproduce BIT-EXACTLY -- is an integer bilinear modelled on
+OpenCV's published u8 INTER_LINEAR scheme: half-pixel centres, edge clamp, 11-bit fixed-point taps
+(2048 = 1.0), horizontal pass in int32, vertical pass
+    dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+At scale 1 it is the identity.  Float part: t = q / 255 ; y = (t - mean) / std in IEEE fp32 (exactly
+what torchvision's ToTensor/Normalize do).
+
+Decode
+------
+argmax (first max wins): scene_seg_infer.py:52-55 torch.max(dim=2); C++ strict '>' from -1e9,
+ROS2/models/src/run_model_node.cpp:144-163 (class 1 -> 255 else 0); binary '>0 -> 255' :164-171 and
+domain_seg_infer.py:54-58 (0/1 floats); lane priority mask {other 2 > right 1 > left 0 > none 255}
+common/visualizers/cuda_visualization_kernels.cu:45-75; LaneSegmentation 0/1 float planes
+onnxruntime_engine.cpp:151-192; cv::resize INTER_NEAREST run_model_node.cpp:176-177;
+depth cv::resize INTER_LINEAR (float) run_model_node.cpp:100-104.
+"""
+import numpy as np
+
+NET_H, NET_W = 320, 640
+MEAN_RGB = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+STD_RGB = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+COEF_BITS = 11
+COEF_ONE = 1 << COEF_BITS
+
+
+def linear_taps_u8(src, dst):
+    """Per-destination (index0, index1, tap0, tap1) with 11-bit fixed-point taps; index1 is clamped and
+    gets tap 0 at the borders, so callers never read out of range."""
+    scale = np.float64(src) / np.float64(dst)
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    f[lo] = 0.0
+    s[lo] = 0
+    hi = s >= src - 1
+    f[hi] = 0.0
+    s[hi] = src - 1
+    a1 = np.rint(f * np.float32(COEF_ONE)).astype(np.int32)
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(COEF_ONE)).astype(np.int32)
+    s1 = np.minimum(s + 1, src - 1).astype(np.int32)
+    return s, s1, a0, a1
+
+
+def resize_bilinear_u8(img, out_h=NET_H, out_w=NET_W):
+    """img: HxWxC uint8 -> out_h x out_w x C uint8 (our integer bilinear)."""
+    img = np.ascontiguousarray(img)
+    h, w, _ = img.shape
+    x0, x1, a0, a1 = linear_taps_u8(w, out_w)
+    y0, y1, b0, b1 = linear_taps_u8(h, out_h)
+    s = img.astype(np.int32)
+    hp = s[:, x0, :] * a0[None, :, None] + s[:, x1, :] * a1[None, :, None]     # H x out_w x C, int32
+    r0 = hp[y0] >> 4
+    r1 = hp[y1] >> 4
+    v = (((b0[:, None, None] * r0) >> 16) + ((b1[:, None, None] * r1) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def normalize_planes(img_u8, input_is_bgr, planes_rgb):
+    """uint8 HxWx3 -> fp32 3xHxW.  ``planes_rgb`` False gives B,G,R plane order (middleware 'common'
+    backends), True gives R,G,B (EgoLanes engine, Python).  Constants always follow the plane's colour."""
+    x = img_u8.astype(np.float32) / np.float32(255.0)
+    rgb = x[..., ::-1] if input_is_bgr else x
+    rgb = (rgb - MEAN_RGB) / STD_RGB
+    out = rgb if planes_rgb else rgb[..., ::-1]
+    return np.ascontiguousarray(out.transpose(2, 0, 1)).astype(np.float32)
+
+
+def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False):
+    """Any-size u8 frame -> 1x3x320x640 fp32 network input."""
+    return normalize_planes(resize_bilinear_u8(frame_u8), input_is_bgr, planes_rgb)[None]
+
+
+# ------------------------------------------------------------------------------------------ decode
+def argmax_classes(logits):
+    """CxHxW fp32 -> HxW int64, lowest index wins ties (strict '>' scan == torch.max)."""
+    best = np.zeros(logits.shape[1:], dtype=np.int64)
+    score = np.full(logits.shape[1:], np.float32(-1e9), dtype=np.float32)
+    for c in range(logits.shape[0]):
+        m = logits[c] > score
+        score = np.where(m, logits[c], score)
+        best = np.where(m, c, best)
+    return best
+
+
+def seg_mask_u8(logits):
+    """run_model_node.cpp:144-171: C>1 -> 255 where argmax==1 ; C==1 -> 255 where >0."""
+    if logits.shape[0] > 1:
+        return np.where(argmax_classes(logits) == 1, 255, 0).astype(np.uint8)
+    return np.where(logits[0] > 0.0, 255, 0).astype(np.uint8)
+
+
+def binary_float(logits):
+    """domain_seg_infer.py:54-58: HxWx1 float 0/1."""
+    return (logits > 0).astype(np.float32).transpose(1, 2, 0)
+
+
+def egolanes_priority_mask(logits):
+    """cuda_visualization_kernels.cu:45-75."""
+    b0, b1, b2 = (logits[i] > 0.0 for i in range(3))
+    return np.where(b2, 2, np.where(b1, 1, np.where(b0, 0, 255))).astype(np.uint8)
+
+
+def egolanes_planes(logits, threshold=0.0):
+    """onnxruntime_engine.cpp:151-192: three fp32 0/1 planes."""
+    return (logits > np.float32(threshold)).astype(np.float32)
+
+
+def nearest_index(src, dst):
+    """OpenCV resizeNN index table: min(floor(x * (1/(dst/src))), src-1), computed in double."""
+    inv = np.float64(dst) / np.float64(src)
+    ifx = np.float64(1.0) / inv
+    return np.minimum(np.floor(np.arange(dst, dtype=np.float64) * ifx).astype(np.int64), src - 1)
+
+
+def resize_nearest_u8(mask, out_h, out_w):
+    return mask[nearest_index(mask.shape[0], out_h)][:, nearest_index(mask.shape[1], out_w)]
+
+
+def linear_taps_f32(src, dst):
+    scale = np.float64(src) / np.float64(dst)
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    f[lo] = 0.0
+    s[lo] = 0
+    hi = s >= src - 1
+    f[hi] = 0.0
+    s[hi] = src - 1
+    return s, np.minimum(s + 1, src - 1).astype(np.int32), (np.float32(1.0) - f).astype(np.float32), f
+
+
+def resize_bilinear_f32(plane, out_h, out_w):
+    """Float bilinear, half-pixel centres, edge clamp, horizontal then vertical, fp32 (no FMA contraction)."""
+    x0, x1, a0, a1 = linear_taps_f32(plane.shape[1], out_w)
+    y0, y1, b0, b1 = linear_taps_f32(plane.shape[0], out_h)
+    p = plane.astype(np.float32)
+    hp = (p[:, x0] * a0[None, :]).astype(np.float32) + (p[:, x1] * a1[None, :]).astype(np.float32)
+    return ((hp[y0] * b0[:, None]).astype(np.float32) + (hp[y1] * b1[:, None]).astype(np.float32)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------ synthetic data
+def synthetic_frame(h, w, seed, smooth=True):
+    """Seeded u8 HxWx3 frame.  ``smooth`` mixes low-frequency sinusoids with noise so argmax regions are
+    non-trivial."""
+    rng = np.random.default_rng(seed)
+    if not smooth:
+        return rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.empty((h, w, 3), dtype=np.float32)
+    for c in range(3):
+        fy, fx, ph = rng.uniform(1.0, 6.0), rng.uniform(1.0, 6.0), rng.uniform(0, 6.28)
+        img[..., c] = 127.5 + 90.0 * np.sin(2 * np.pi * (fy * yy / h + fx * xx / w) + ph)
+    img += rng.normal(0.0, 12.0, size=img.shape).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
