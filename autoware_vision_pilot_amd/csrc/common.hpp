@@ -1,0 +1,62 @@
+// Shared device/host definitions for libvp_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vp {
+
+typedef _Float16 half_t;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// Activation tensor in HBM: NHWC, channels padded to a multiple of 32 (pad channels are always 0).
+// Precision modes:
+//   fp16   : value = hi
+//   fp16x3 : value = hi + lo  (lo = fp16(x - fp16(x))): ~22 mantissa bits carried on the fp16 MFMA pipe;
+//            a product a*b is evaluated as ahi*bhi + ahi*blo + alo*bhi with fp32 accumulation.
+struct ActView {
+  half_t* hi;
+  half_t* lo;  // nullptr in fp16 mode
+  int H, W, C;  // C = padded channel count
+};
+
+enum ActFn { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3 };
+enum ResMode { RES_NONE = 0, RES_ADD = 1, RES_MULADD = 2 };  // MULADD: out = v*res + res  (scene_context.py:56)
+enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_NCHW_F32 = 2 };
+
+// Implicit-GEMM convolution launch parameters (see kernels_conv.hip).
+struct ConvGemmParams {
+  const half_t* in_hi;
+  const half_t* in_lo;
+  int H, W, Cin;       // input spatial size, padded input channels (multiple of BK)
+  const half_t* w_hi;  // [taps][CoutW][Cin]
+  const half_t* w_lo;
+  const float* bias;   // [CoutW]
+  int ks;              // 1 or 3 (stride 1, pad ks/2)
+  int Ncols;           // GEMM columns to store (multiple of 32): Cout_pad, or 4*Cout_pad for STORE_SHUFFLE2
+  int CoutW;           // weight rows allocated (multiple of the CO tile)
+  int act, res_mode, store_mode;
+  const half_t* res_hi;
+  const half_t* res_lo;
+  half_t* out_hi;
+  half_t* out_lo;
+  int Cstore;          // channel stride of the output tensor (padded C); for SHUFFLE2 Ncols == 4*Cstore
+  float* out_f32;      // STORE_NCHW_F32: [Creal][H*W]
+  int Creal;
+  int nsplit;          // split-K factor (grid.z); >1 -> partial sums go to `partial`
+  float* partial;      // [nsplit][M][CoutW] fp32 scratch
+};
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_GELU) return gelu_exact(v);
+  if (act == ACT_SILU) return silu_f(v);
+  if (act == ACT_SIGMOID) return sigmoid_f(v);
+  return v;
+}
+
+}  // namespace vp

@@ -1,0 +1,952 @@
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vp {
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ================================================================================================ WeightBlob
+void WeightBlob::parse(const void* blob, size_t bytes) {
+  const uint8_t* p = static_cast<const uint8_t*>(blob);
+  const uint8_t* end = p + bytes;
+  auto need = [&](size_t n) {
+    if ((size_t)(end - p) < n) throw std::runtime_error("weight blob truncated");
+  };
+  need(8);
+  if (std::memcmp(p, "VPW1", 4) != 0) throw std::runtime_error("weight blob: bad magic (expected VPW1)");
+  uint32_t count;
+  std::memcpy(&count, p + 4, 4);
+  p += 8;
+  for (uint32_t i = 0; i < count; ++i) {
+    need(2);
+    uint16_t nl;
+    std::memcpy(&nl, p, 2);
+    p += 2;
+    need(nl + 1);
+    std::string name(reinterpret_cast<const char*>(p), nl);
+    p += nl;
+    const int nd = *p++;
+    need(4 * (size_t)nd);
+    HostTensor t;
+    size_t n = 1;
+    for (int d = 0; d < nd; ++d) {
+      uint32_t v;
+      std::memcpy(&v, p, 4);
+      p += 4;
+      t.shape.push_back((int)v);
+      n *= v;
+    }
+    need(4 * n);
+    t.data.resize(n);
+    std::memcpy(t.data.data(), p, 4 * n);
+    p += 4 * n;
+    t_.emplace(std::move(name), std::move(t));
+  }
+}
+const HostTensor& WeightBlob::get(const std::string& key) const {
+  auto it = t_.find(key);
+  if (it == t_.end()) throw std::runtime_error("weight blob: missing tensor '" + key + "'");
+  return it->second;
+}
+
+// ======================================================================================== folding + packing
+namespace {
+
+constexpr float kBnEps = 1e-5f;  // torchvision efficientnet_b0 BatchNorm2d default
+
+struct Folded {
+  std::vector<float> w, b;
+  int cout = 0, cin = 0, k = 0;  // cin = per-group input channels
+};
+
+// conv(no bias) + BatchNorm(eval) -> conv with bias:  w' = w * g/sqrt(v+eps),  b' = beta - mean * g/sqrt(v+eps)
+Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) {
+  const HostTensor& w = blob.get(p + ".0.weight");
+  const HostTensor& g = blob.get(p + ".1.weight");
+  const HostTensor& beta = blob.get(p + ".1.bias");
+  const HostTensor& mean = blob.get(p + ".1.running_mean");
+  const HostTensor& var = blob.get(p + ".1.running_var");
+  if (w.shape.size() != 4) throw std::runtime_error("conv weight rank != 4: " + p);
+  Folded f;
+  f.cout = w.shape[0];
+  f.cin = w.shape[1];
+  f.k = w.shape[2];
+  const size_t per = (size_t)f.cin * f.k * f.k;
+  f.w.resize(w.data.size());
+  f.b.resize(f.cout);
+  for (int co = 0; co < f.cout; ++co) {
+    const float s = g.data[co] / std::sqrt(var.data[co] + kBnEps);
+    for (size_t i = 0; i < per; ++i) f.w[co * per + i] = w.data[co * per + i] * s;
+    f.b[co] = beta.data[co] - mean.data[co] * s;
+  }
+  return f;
+}
+
+void split_half(float v, half_t* hi, half_t* lo) {
+  const half_t h = (half_t)v;
+  *hi = h;
+  *lo = (half_t)(v - (float)h);
+}
+
+}  // namespace
+
+// ==================================================================================================== Engine
+Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id) : kind_(kind), precision_(precision), gpu_(gpu_id) {
+  if (precision != 0 && precision != 1) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw std::runtime_error("libvp_hip: no HIP device visible (this library has no CPU fallback)");
+  if (gpu_id < 0 || gpu_id >= ndev) throw std::invalid_argument("gpu_id out of range");
+  VP_HIP_CHECK(hipSetDevice(gpu_id));
+  VP_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  VP_HIP_CHECK(hipEventCreate(&ev0_));
+  VP_HIP_CHECK(hipEventCreate(&ev1_));
+  if (kind >= 0) {
+    if (!blob) throw std::invalid_argument("weights required");
+    build_model(*blob);
+    finish_plan();
+  }
+}
+
+Engine::~Engine() {
+  hipSetDevice(gpu_);
+  if (stream_) hipStreamSynchronize(stream_);
+  if (graph_exec_) hipGraphExecDestroy(graph_exec_);
+  if (graph_) hipGraphDestroy(graph_);
+  for (void* p : allocs_) hipFree(p);
+  if (h_logits_) hipHostFree(h_logits_);
+  if (h_mask_) hipHostFree(h_mask_);
+  if (ev0_) hipEventDestroy(ev0_);
+  if (ev1_) hipEventDestroy(ev1_);
+  if (stream_) hipStreamDestroy(stream_);
+}
+
+void* Engine::dalloc(size_t bytes, bool zero) {
+  void* p = nullptr;
+  VP_HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+  allocs_.push_back(p);
+  if (zero) VP_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
+  return p;
+}
+template <class T>
+T* Engine::dupload(const std::vector<T>& v) {
+  T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
+  VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+Act* Engine::new_act(const std::string& name, int creal, int h, int w) {
+  auto a = std::make_unique<Act>();
+  a->name = name;
+  a->Creal = creal;
+  a->C = round_up(creal, 32);
+  a->H = h;
+  a->W = w;
+  a->hi = static_cast<half_t*>(dalloc(a->elems() * sizeof(half_t)));
+  if (split()) a->lo = static_cast<half_t*>(dalloc(a->elems() * sizeof(half_t)));
+  acts_.push_back(std::move(a));
+  return acts_.back().get();
+}
+
+void Engine::upload_act(Act* a, const float* chw) {
+  float* d = static_cast<float*>(dalloc((size_t)a->Creal * a->H * a->W * sizeof(float), false));
+  VP_HIP_CHECK(hipMemcpy(d, chw, (size_t)a->Creal * a->H * a->W * sizeof(float), hipMemcpyHostToDevice));
+  VP_HIP_CHECK(launch_nchw_to_act(d, a->Creal, a->view(), stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------------------------------- conv planning
+void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc) {
+  auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
+  int tile;
+  if (o.tile >= 0) {
+    tile = o.tile;
+  } else if (ncols <= 32) {
+    tile = 3;
+  } else if (ncols % 128 == 0 && cdiv(M, 128) * (ncols / 128) >= 192) {
+    tile = 0;
+  } else if (cdiv(M, 128) * cdiv(ncols, 64) >= 128 || M >= 2048) {
+    tile = 1;
+  } else {
+    tile = 2;
+  }
+  pc->tile = tile;
+  pc->bk = o.bk > 0 ? o.bk : 32;
+  if (cin_pad % pc->bk != 0) pc->bk = 32;
+  pc->CoutW = round_up(ncols, conv_tile_co(tile));
+  const long long blocks = cdiv(M, conv_tile_px(tile)) * (pc->CoutW / conv_tile_co(tile));
+  const int S = ks * ks * (cin_pad / pc->bk);
+  int ns = 1;
+  if (o.nsplit > 0) {
+    ns = o.nsplit;
+  } else if (blocks < 256) {
+    ns = (int)std::min<long long>(cdiv(512, blocks), std::max(1, S / 4));
+    ns = std::max(1, std::min(ns, 32));
+  }
+  pc->nsplit = std::min(ns, std::max(1, S));
+}
+
+void Engine::push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
+                          int store_mode, int cout_real) {
+  ConvGemmParams p{};
+  p.in_hi = in->hi;
+  p.in_lo = in->lo;
+  p.H = in->H;
+  p.W = in->W;
+  p.Cin = in->C;
+  p.w_hi = pc.w_hi;
+  p.w_lo = pc.w_lo;
+  p.bias = pc.bias;
+  p.ks = ks;
+  p.Ncols = ncols;
+  p.CoutW = pc.CoutW;
+  p.act = o.act;
+  p.res_mode = o.res_mode;
+  p.res_hi = o.res ? o.res->hi : nullptr;
+  p.res_lo = o.res ? o.res->lo : nullptr;
+  p.store_mode = store_mode;
+  p.out_hi = out ? out->hi : nullptr;
+  p.out_lo = out ? out->lo : nullptr;
+  p.Cstore = out ? out->C : 0;
+  p.out_f32 = o.logits_out;
+  p.Creal = cout_real;
+  p.nsplit = pc.nsplit;
+  const int M = in->H * in->W;
+  p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
+  const int tile = pc.tile, bk = pc.bk;
+  const bool sp = split();
+  Op op;
+  op.name = name;
+  op.flops = 2.0 * M * (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks;
+  const double esz = sp ? 4.0 : 2.0;
+  op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
+                    (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
+  op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
+  ops_.push_back(std::move(op));
+}
+
+// w: [cout][cin][ks][ks] fp32 (already BN-folded where applicable), b: [cout]
+Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout, int ks,
+                      const ConvOpts& o, Act* out_override) {
+  const int cin = in->Creal, cin_pad = in->C;
+  if (w.size() != (size_t)cout * cin * ks * ks) throw std::runtime_error("conv weight size mismatch: " + name);
+  const int M = in->H * in->W;
+  const int ncols = round_up(cout, 32);
+  PackedConv pc;
+  choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
+  const int taps = ks * ks;
+  std::vector<half_t> hi((size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < taps; ++t) {
+        const float v = w[((size_t)co * cin + ci) * taps + t];
+        const size_t d = ((size_t)t * pc.CoutW + co) * cin_pad + ci;
+        half_t h, l;
+        split_half(v, &h, &l);
+        hi[d] = h;
+        if (split()) lo[d] = l;
+      }
+  std::vector<float> bias(pc.CoutW, 0.0f);
+  for (int co = 0; co < cout; ++co) bias[co] = b[co];
+  pc.w_hi = dupload(hi);
+  pc.w_lo = split() ? dupload(lo) : nullptr;
+  pc.bias = dupload(bias);
+  Act* out = nullptr;
+  int store = STORE_NHWC;
+  if (o.logits_out) {
+    store = STORE_NCHW_F32;
+  } else {
+    out = out_override ? out_override : new_act(name, cout, in->H, in->W);
+  }
+  push_conv_op(name, in, pc, ks, ncols, o, out, store, cout);
+  return out;
+}
+
+// ConvTranspose2d(k2,s2): w [cin][cout][2][2] -> GEMM rows n = (dy*2+dx)*Cout_pad + co over input pixels.
+Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
+                       const ConvOpts& o) {
+  const int cin = in->Creal, cin_pad = in->C;
+  if (w.size() != (size_t)cin * cout * 4) throw std::runtime_error("convT weight size mismatch: " + name);
+  Act* out = new_act(name, cout, in->H * 2, in->W * 2);
+  const int cpad = out->C;
+  const int ncols = 4 * cpad;
+  PackedConv pc;
+  choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, o, &pc);
+  std::vector<half_t> hi((size_t)pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
+  std::vector<float> bias(pc.CoutW, 0.0f);
+  for (int q = 0; q < 4; ++q)
+    for (int co = 0; co < cout; ++co) {
+      const int n = q * cpad + co;
+      bias[n] = b[co];
+      for (int ci = 0; ci < cin; ++ci) {
+        const float v = w[((size_t)ci * cout + co) * 4 + q];  // [ci][co][dy][dx], q = dy*2+dx
+        half_t h, l;
+        split_half(v, &h, &l);
+        hi[(size_t)n * cin_pad + ci] = h;
+        if (split()) lo[(size_t)n * cin_pad + ci] = l;
+      }
+    }
+  pc.w_hi = dupload(hi);
+  pc.w_lo = split() ? dupload(lo) : nullptr;
+  pc.bias = dupload(bias);
+  push_conv_op(name, in, pc, 1, ncols, o, out, STORE_SHUFFLE2, cout);
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------ backbone
+// torchvision efficientnet_b0().features as used by Models/model_components/backbone.py:9-22.
+std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::string& P) {
+  struct Stage { int e, k, s, cin, cout, n; };
+  static const Stage stages[7] = {{1, 3, 1, 32, 16, 1}, {6, 3, 2, 16, 24, 2}, {6, 5, 2, 24, 40, 2}, {6, 3, 2, 40, 80, 3},
+                                  {6, 5, 1, 80, 112, 3}, {6, 5, 2, 112, 192, 4}, {6, 3, 1, 192, 320, 1}};
+  std::vector<Act*> stage_out;
+  // ---- features[0]: stem
+  Act* x;
+  {
+    Folded f = fold_conv_bn(blob, P + "0");
+    std::vector<float> wk(27 * 32);
+    for (int co = 0; co < 32; ++co)
+      for (int k = 0; k < 27; ++k) wk[k * 32 + co] = f.w[co * 27 + k];
+    StemParams sp{};
+    sp.in = d_input_;
+    sp.H = net_h();
+    sp.W = net_w();
+    sp.w = dupload(wk);
+    sp.b = dupload(f.b);
+    x = new_act(P + "0", 32, net_h() / 2, net_w() / 2);
+    sp.out = x->view();
+    Op op;
+    op.name = P + "0";
+    op.flops = 2.0 * 27 * 32 * x->H * x->W;
+    op.bytes = 4.0 * 3 * net_h() * net_w() + 2.0 * x->elems();
+    op.run = [sp](hipStream_t st) { return launch_stem(sp, st); };
+    ops_.push_back(std::move(op));
+  }
+  stage_out.push_back(x);
+  for (int si = 0; si < 7; ++si) {
+    const Stage& S = stages[si];
+    for (int bi = 0; bi < S.n; ++bi) {
+      const std::string bp = P + std::to_string(si + 1) + "." + std::to_string(bi) + ".block.";
+      const int cin = bi == 0 ? S.cin : S.cout, stride = bi == 0 ? S.s : 1, cexp = cin * S.e;
+      int j = 0;
+      const Act* y = x;
+      if (S.e != 1) {
+        Folded f = fold_conv_bn(blob, bp + std::to_string(j));
+        ConvOpts o;
+        o.act = ACT_SILU;
+        y = add_conv(bp + std::to_string(j), x, f.w, f.b, cexp, 1, o);
+        ++j;
+      }
+      // depthwise
+      Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
+      {
+        Folded f = fold_conv_bn(blob, bp + std::to_string(j));
+        const int kk = S.k * S.k;
+        std::vector<float> wk((size_t)kk * z->C, 0.0f), bk(z->C, 0.0f);
+        for (int c = 0; c < cexp; ++c) {
+          for (int t = 0; t < kk; ++t) wk[(size_t)t * z->C + c] = f.w[(size_t)c * kk + t];
+          bk[c] = f.b[c];
+        }
+        DwParams dp{};
+        dp.in = y->view();
+        dp.out = z->view();
+        dp.w = dupload(wk);
+        dp.b = dupload(bk);
+        dp.k = S.k;
+        dp.stride = stride;
+        Op op;
+        op.name = bp + std::to_string(j);
+        op.flops = 2.0 * kk * cexp * z->H * z->W;
+        op.bytes = (split() ? 4.0 : 2.0) * (y->elems() + z->elems());
+        op.run = [dp](hipStream_t st) { return launch_dwconv(dp, st); };
+        ops_.push_back(std::move(op));
+        ++j;
+      }
+      // squeeze-excite -> per-frame scaled projection weights
+      const int sq = std::max(1, cin / 4);
+      const int HWz = z->H * z->W;
+      const int nslab = std::max(1, std::min(256, HWz / 64));
+      float* partial = static_cast<float*>(dalloc((size_t)nslab * z->C * sizeof(float)));
+      float* scale = static_cast<float*>(dalloc(z->C * sizeof(float)));
+      {
+        PoolParams pp{z->view(), partial, nslab};
+        Op op;
+        op.name = bp + std::to_string(j) + ".avgpool";
+        op.bytes = (split() ? 4.0 : 2.0) * z->elems();
+        op.run = [pp](hipStream_t st) { return launch_pool_partial(pp, st); };
+        ops_.push_back(std::move(op));
+        const std::string sp = bp + std::to_string(j);
+        const HostTensor& w1 = blob.get(sp + ".fc1.weight");
+        const HostTensor& b1 = blob.get(sp + ".fc1.bias");
+        const HostTensor& w2 = blob.get(sp + ".fc2.weight");
+        const HostTensor& b2 = blob.get(sp + ".fc2.bias");
+        if (w1.shape[0] != sq || w1.shape[1] != cexp) throw std::runtime_error("SE fc1 shape mismatch: " + sp);
+        std::vector<float> w1p((size_t)sq * z->C, 0.0f), w2p((size_t)z->C * sq, 0.0f), b2p(z->C, 0.0f);
+        for (int q = 0; q < sq; ++q)
+          for (int c = 0; c < cexp; ++c) w1p[(size_t)q * z->C + c] = w1.data[(size_t)q * cexp + c];
+        for (int c = 0; c < cexp; ++c) {
+          for (int q = 0; q < sq; ++q) w2p[(size_t)c * sq + q] = w2.data[(size_t)c * sq + q];
+          b2p[c] = b2.data[c];
+        }
+        SeParams se{};
+        se.partial = partial;
+        se.nslab = nslab;
+        se.C = z->C;
+        se.Creal = cexp;
+        se.sq = sq;
+        se.inv_hw = 1.0f / (float)HWz;
+        se.w1 = dupload(w1p);
+        se.b1 = dupload(b1.data);
+        se.w2 = dupload(w2p);
+        se.b2 = dupload(b2p);
+        se.scale = scale;
+        Op op2;
+        op2.name = sp + ".fc";
+        op2.flops = 4.0 * sq * cexp;
+        op2.run = [se](hipStream_t st) { return launch_se_fc(se, st); };
+        ops_.push_back(std::move(op2));
+        ++j;
+      }
+      // project 1x1 (+BN folded) with SE scale folded into K, optional residual
+      {
+        Folded f = fold_conv_bn(blob, bp + std::to_string(j));
+        const int ncols = round_up(S.cout, 32);
+        ConvOpts o;
+        const bool residual = (stride == 1 && cin == S.cout);
+        if (residual) {
+          o.res_mode = RES_ADD;
+          o.res = x;
+        }
+        PackedConv pc;
+        choose_conv_cfg(HWz, ncols, z->C, 1, o, &pc);
+        std::vector<float> wf((size_t)pc.CoutW * z->C, 0.0f), bias(pc.CoutW, 0.0f);
+        for (int co = 0; co < S.cout; ++co) {
+          for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c];
+          bias[co] = f.b[co];
+        }
+        ScaleWParams sw{};
+        sw.w = dupload(wf);
+        sw.scale = scale;
+        sw.rows = pc.CoutW;
+        sw.C = z->C;
+        sw.out_hi = static_cast<half_t*>(dalloc(wf.size() * sizeof(half_t)));
+        sw.out_lo = split() ? static_cast<half_t*>(dalloc(wf.size() * sizeof(half_t))) : nullptr;
+        Op op;
+        op.name = bp + std::to_string(j) + ".se_scale_w";
+        op.bytes = 6.0 * wf.size();
+        op.run = [sw](hipStream_t st) { return launch_scale_weights(sw, st); };
+        ops_.push_back(std::move(op));
+        pc.w_hi = sw.out_hi;
+        pc.w_lo = sw.out_lo;
+        pc.bias = dupload(bias);
+        Act* out = new_act(bp + std::to_string(j), S.cout, z->H, z->W);
+        push_conv_op(bp + std::to_string(j), z, pc, 1, ncols, o, out, STORE_NHWC, S.cout);
+        x = out;
+      }
+    }
+    stage_out.push_back(x);
+  }
+  {
+    Folded f = fold_conv_bn(blob, P + "8");
+    ConvOpts o;
+    o.act = ACT_SILU;
+    stage_out.push_back(add_conv(P + "8", x, f.w, f.b, 1280, 1, o));
+  }
+  // taps l0, l2, l3, l4, l8 (backbone.py:22)
+  return {stage_out[0], stage_out[2], stage_out[3], stage_out[4], stage_out[8]};
+}
+
+// ------------------------------------------------------------------------------------------------- context
+// scene_context.py:25-57 (== depth_context.py, auto_steer_context.py with 1456 channels)
+Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const Act* deep, int cctx) {
+  const int HW = deep->H * deep->W;
+  const int nslab = 8;
+  float* partial = static_cast<float*>(dalloc((size_t)nslab * deep->C * sizeof(float)));
+  {
+    PoolParams pp{deep->view(), partial, nslab};
+    Op op;
+    op.name = p + "avgpool";
+    op.run = [pp](hipStream_t st) { return launch_pool_partial(pp, st); };
+    ops_.push_back(std::move(op));
+  }
+  const float* x = nullptr;
+  int K = cctx;
+  const int widths[3] = {800, 800, 200};
+  for (int i = 0; i < 3; ++i) {
+    const std::string lp = p + "context_layer_" + std::to_string(i);
+    const HostTensor& w = blob.get(lp + ".weight");
+    const HostTensor& b = blob.get(lp + ".bias");
+    if (w.shape[0] != widths[i] || w.shape[1] != K) throw std::runtime_error("context MLP shape mismatch: " + lp);
+    FcParams fp{};
+    fp.x = x;
+    fp.w = dupload(w.data);
+    fp.b = dupload(b.data);
+    fp.N = widths[i];
+    fp.K = K;
+    fp.act = i < 2 ? ACT_GELU : ACT_SIGMOID;
+    fp.out = static_cast<float*>(dalloc(widths[i] * sizeof(float)));
+    if (i == 0) {
+      fp.partial = partial;
+      fp.nslab = nslab;
+      fp.Kstride = deep->C;
+      fp.inv_hw = 1.0f / (float)HW;
+    }
+    Op op;
+    op.name = lp;
+    op.flops = 2.0 * widths[i] * K;
+    op.bytes = 4.0 * widths[i] * K;
+    op.run = [fp](hipStream_t st) { return launch_fc(fp, st); };
+    ops_.push_back(std::move(op));
+    x = fp.out;
+    K = widths[i];
+  }
+  Act* c = new_act(p + "context_layer_3", 128, deep->H, deep->W);
+  {
+    const HostTensor& w = blob.get(p + "context_layer_3.weight");  // [128][1][3][3]
+    const HostTensor& b = blob.get(p + "context_layer_3.bias");
+    std::vector<float> wk(9 * c->C, 0.0f), bk(c->C, 0.0f);
+    for (int co = 0; co < 128; ++co) {
+      for (int t = 0; t < 9; ++t) wk[t * c->C + co] = w.data[co * 9 + t];
+      bk[co] = b.data[co];
+    }
+    CtxConv1Params cp{};
+    cp.map = x;
+    cp.H = deep->H;
+    cp.W = deep->W;
+    cp.w = dupload(wk);
+    cp.b = dupload(bk);
+    cp.out = c->view();
+    Op op;
+    op.name = p + "context_layer_3";
+    op.flops = 2.0 * 9 * 128 * HW;
+    op.run = [cp](hipStream_t st) { return launch_ctx_conv1(cp, st); };
+    ops_.push_back(std::move(op));
+  }
+  const int couts[3] = {256, 512, cctx};
+  for (int i = 0; i < 3; ++i) {
+    const std::string lp = p + "context_layer_" + std::to_string(4 + i);
+    ConvOpts o;
+    o.act = ACT_GELU;
+    if (i == 2) {  // context = gelu(c7) * features + features  (scene_context.py:53-56)
+      o.res_mode = RES_MULADD;
+      o.res = deep;
+    }
+    c = add_conv(lp, c, blob.get(lp + ".weight").data, blob.get(lp + ".bias").data, couts[i], 3, o);
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------- neck
+// scene_neck.py:26-60 (== scene_3d_neck.py, ego_path_neck.py)
+Act* Engine::build_neck(const WeightBlob& blob, const std::string& p, const Act* ctx, const std::vector<Act*>& feats, int cctx) {
+  const int up_c[3] = {cctx, 768, 512};
+  const int d_c[6] = {768, 768, 512, 512, 512, 256};
+  const Act* x = ctx;
+  for (int blk = 0; blk < 3; ++blk) {
+    const std::string up = p + "upsample_layer_" + std::to_string(blk), sk = p + "skip_link_layer_" + std::to_string(blk);
+    Act* u = add_convT(up, x, blob.get(up + ".weight").data, blob.get(up + ".bias").data, up_c[blk], ConvOpts{});
+    ConvOpts so;  // d = upsample(x) + skip(feature): second GEMM accumulates in place on the pixel-shuffled tensor
+    so.res_mode = RES_ADD;
+    so.res = u;
+    add_conv(sk, feats[3 - blk], blob.get(sk + ".weight").data, blob.get(sk + ".bias").data, up_c[blk], 1, so, u);
+    x = u;
+    for (int k = 0; k < 2; ++k) {
+      const std::string dl = p + "decode_layer_" + std::to_string(2 * blk + k);
+      ConvOpts o;
+      o.act = ACT_GELU;
+      x = add_conv(dl, x, blob.get(dl + ".weight").data, blob.get(dl + ".bias").data, d_c[2 * blk + k], 3, o);
+    }
+  }
+  return const_cast<Act*>(x);
+}
+
+// ---------------------------------------------------------------------------------------------------- heads
+void Engine::build_head(const WeightBlob& blob, const std::string& p, const Act* neck, const std::vector<Act*>& feats) {
+  auto W = [&](const std::string& k) -> const std::vector<float>& { return blob.get(p + k + ".weight").data; };
+  auto B = [&](const std::string& k) -> const std::vector<float>& { return blob.get(p + k + ".bias").data; };
+  ConvOpts gelu;
+  gelu.act = ACT_GELU;
+  const Act* x = neck;
+  std::string last;
+  int c_last = 0;
+  if (kind_ == 3) {  // ego_lanes_head.py:18-26 (80x160)
+    x = add_conv(p + "decode_layer_6", x, W("decode_layer_6"), B("decode_layer_6"), 256, 3, gelu);
+    x = add_conv(p + "decode_layer_7", x, W("decode_layer_7"), B("decode_layer_7"), 128, 3, gelu);
+    last = "decode_layer_8";
+    c_last = 3;
+  } else {  // scene_seg_head.py:21-44, scene_3d_head.py:23-47, domain_seg_head.py:21-44
+    const int c9 = kind_ == 1 ? 128 : 64;
+    Act* u = add_convT(p + "upsample_layer_3", x, W("upsample_layer_3"), B("upsample_layer_3"), 256, ConvOpts{});
+    ConvOpts so;
+    so.res_mode = RES_ADD;
+    so.res = u;
+    add_conv(p + "skip_link_layer_3", feats[0], W("skip_link_layer_3"), B("skip_link_layer_3"), 256, 1, so, u);
+    x = add_conv(p + "decode_layer_6", u, W("decode_layer_6"), B("decode_layer_6"), 256, 3, gelu);
+    x = add_conv(p + "decode_layer_7", x, W("decode_layer_7"), B("decode_layer_7"), 128, 3, gelu);
+    x = add_convT(p + "upsample_layer_4", x, W("upsample_layer_4"), B("upsample_layer_4"), 128, ConvOpts{});
+    x = add_conv(p + "decode_layer_8", x, W("decode_layer_8"), B("decode_layer_8"), 128, 3, gelu);
+    x = add_conv(p + "decode_layer_9", x, W("decode_layer_9"), B("decode_layer_9"), c9, 3, gelu);
+    last = "decode_layer_10";
+    c_last = kind_ == 0 ? 3 : 1;
+  }
+  out_c_ = c_last;
+  out_h_ = x->H;
+  out_w_ = x->W;
+  d_logits_ = static_cast<float*>(dalloc((size_t)out_c_ * out_h_ * out_w_ * sizeof(float)));
+  d_mask_ = static_cast<uint8_t*>(dalloc((size_t)out_h_ * out_w_));
+  ConvOpts fo;
+  fo.logits_out = d_logits_;
+  add_conv(p + last, x, W(last), B(last), c_last, 3, fo);
+}
+
+void Engine::build_model(const WeightBlob& blob) {
+  struct Prefix { const char *bb, *ctx, *neck, *head; };
+  static const Prefix P[4] = {
+      {"Backbone.encoder.", "SceneContext.", "SceneNeck.", "SceneSegHead."},
+      {"PreTrainedBackbone.pretrainedBackBone.encoder.", "DepthContext.", "DepthNeck.", "SuperDepthHead."},
+      {"DomainSegUpstream.pretrainedBackBone.encoder.", "DomainSegUpstream.pretrainedContext.", "DomainSegUpstream.pretrainedNeck.",
+       "DomainSegHead."},
+      {"BEVBackbone.encoder.", "AutoSteerContext.", "EgopathNeck.", "EgoLanesHead."}};
+  if (kind_ < 0 || kind_ > 3) throw std::invalid_argument("unknown model kind");
+  d_input_ = static_cast<float*>(dalloc((size_t)3 * net_h() * net_w() * sizeof(float)));
+  // op 0: preprocess (parameters are patched per frame geometry in ensure_tables)
+  {
+    Op op;
+    op.name = "preprocess";
+    op.run = [this](hipStream_t st) {
+      PreprocessParams pp{};
+      pp.frame = d_frame_;
+      pp.stride = frame_stride_;
+      pp.xtab = d_xtab_;
+      pp.ytab = d_ytab_;
+      pp.out_h = net_h();
+      pp.out_w = net_w();
+      // plane colour order: RGB planes or BGR planes; source byte index depends on the frame's pixel format
+      static const float mean_rgb[3] = {0.485f, 0.456f, 0.406f}, std_rgb[3] = {0.229f, 0.224f, 0.225f};
+      for (int c = 0; c < 3; ++c) {
+        const int colour = plane_order_ == 1 ? c : 2 - c;       // 0=R 1=G 2=B
+        pp.src_c[c] = pixel_format_ == 1 ? colour : 2 - colour;  // RGB8: R at byte 0 ; BGR8: R at byte 2
+        pp.mean[c] = mean_rgb[colour];
+        pp.stdv[c] = std_rgb[colour];
+      }
+      pp.out = d_input_;
+      return launch_preprocess(pp, st);
+    };
+    ops_.push_back(std::move(op));
+    first_net_op_ = 1;
+  }
+  const Prefix& pf = P[kind_];
+  std::vector<Act*> feats = build_backbone(blob, pf.bb);
+  const int cctx = kind_ == 3 ? 1456 : 1280;
+  const Act* deep = feats[4];
+  if (kind_ == 3) {  // backbone_feature_fusion.py:13-38
+    Act* fused = new_act("BackboneFeatureFusion", 1456, feats[4]->H, feats[4]->W);
+    FusionParams fp{};
+    const int shifts[5] = {4, 3, 2, 1, 0};
+    for (int i = 0; i < 5; ++i) {
+      fp.f[i] = feats[i]->view();
+      fp.creal[i] = feats[i]->Creal;
+      fp.shift[i] = shifts[i];
+    }
+    fp.out = fused->view();
+    fp.Creal_out = 1456;
+    Op op;
+    op.name = "BackboneFeatureFusion";
+    op.run = [fp](hipStream_t st) { return launch_fusion(fp, st); };
+    ops_.push_back(std::move(op));
+    deep = fused;
+  }
+  Act* ctx = build_context(blob, pf.ctx, deep, cctx);
+  Act* neck = build_neck(blob, pf.neck, ctx, feats, cctx);
+  build_head(blob, pf.head, neck, feats);
+  decode_mode_ = kind_ == 3 ? 1 : 0;
+}
+
+void Engine::finish_plan() {
+  if (d_logits_ && !h_logits_) {
+    VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_logits_), (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipHostMallocDefault));
+    VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_mask_), (size_t)out_h_ * out_w_, hipHostMallocDefault));
+    Op op;
+    op.name = "decode";
+    op.bytes = 4.0 * out_c_ * out_h_ * out_w_ + out_h_ * out_w_;
+    op.run = [this](hipStream_t st) { return launch_decode_mask(d_logits_, out_c_, out_h_ * out_w_, decode_mode_, d_mask_, st); };
+    ops_.push_back(std::move(op));
+  }
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  VP_HIP_CHECK(hipDeviceSynchronize());
+}
+
+// ------------------------------------------------------------------------------------------ frame handling
+void Engine::set_input_format(int pixel_format, int plane_order) {
+  if (pixel_format < 0 || pixel_format > 1 || plane_order < 0 || plane_order > 1) throw std::invalid_argument("bad input format");
+  if (pixel_format != pixel_format_ || plane_order != plane_order_) graph_valid_ = false;
+  pixel_format_ = pixel_format;
+  plane_order_ = plane_order;
+}
+void Engine::set_decode_mode(int mode) {
+  if (mode < 0 || mode > 2) throw std::invalid_argument("bad decode mode");
+  if (mode != decode_mode_) graph_valid_ = false;
+  decode_mode_ = mode;
+}
+
+// 11-bit fixed-point bilinear taps -- must stay bit-identical to oracle/pre_post.py linear_taps_u8.
+static void linear_taps_u8(int src, int dst, std::vector<int>* tab) {
+  tab->resize((size_t)dst * 4);
+  const double scale = (double)src / (double)dst;
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)std::floor(f);
+    f -= (float)s;
+    if (s < 0) {
+      f = 0.0f;
+      s = 0;
+    }
+    if (s >= src - 1) {
+      f = 0.0f;
+      s = src - 1;
+    }
+    (*tab)[4 * d + 0] = s;
+    (*tab)[4 * d + 1] = std::min(s + 1, src - 1);
+    (*tab)[4 * d + 2] = (int)std::nearbyint((1.0f - f) * 2048.0f);
+    (*tab)[4 * d + 3] = (int)std::nearbyint(f * 2048.0f);
+  }
+}
+
+void Engine::ensure_tables(int h, int w) {
+  if (h == tab_h_ && w == tab_w_) return;
+  std::vector<int> xt, yt;
+  linear_taps_u8(w, net_w(), &xt);
+  linear_taps_u8(h, net_h(), &yt);
+  if (!d_xtab_) {
+    d_xtab_ = static_cast<int*>(dalloc(net_w() * 4 * sizeof(int)));
+    d_ytab_ = static_cast<int*>(dalloc(net_h() * 4 * sizeof(int)));
+  }
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  VP_HIP_CHECK(hipMemcpy(d_xtab_, xt.data(), xt.size() * sizeof(int), hipMemcpyHostToDevice));
+  VP_HIP_CHECK(hipMemcpy(d_ytab_, yt.data(), yt.size() * sizeof(int), hipMemcpyHostToDevice));
+  tab_h_ = h;
+  tab_w_ = w;
+}
+
+void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride) {
+  if (!frame || h < 2 || w < 2 || stride < 3 * w) throw std::invalid_argument("bad frame geometry");
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  const size_t need = (size_t)h * stride;
+  if (need > frame_cap_) {
+    VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    d_frame_ = static_cast<uint8_t*>(dalloc(need, false));
+    frame_cap_ = need;
+    graph_valid_ = false;
+  }
+  if (h != frame_h_ || w != frame_w_ || stride != frame_stride_) graph_valid_ = false;
+  ensure_tables(h, w);
+  frame_h_ = h;
+  frame_w_ = w;
+  frame_stride_ = stride;
+  VP_HIP_CHECK(hipMemcpyAsync(d_frame_, frame, need, hipMemcpyHostToDevice, stream_));
+  if (input_is_tensor_) graph_valid_ = false;
+  input_is_tensor_ = false;
+}
+
+void Engine::upload_tensor(const float* nchw) {
+  if (!nchw) throw std::invalid_argument("null tensor");
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  VP_HIP_CHECK(hipMemcpyAsync(d_input_, nchw, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  if (!input_is_tensor_) graph_valid_ = false;
+  input_is_tensor_ = true;
+}
+
+void Engine::run_eager() {
+  for (size_t i = input_is_tensor_ ? first_net_op_ : 0; i < ops_.size(); ++i) {
+    hipError_t e = ops_[i].run(stream_);
+    if (e != hipSuccess) throw std::runtime_error("launch failed in layer '" + ops_[i].name + "': " + hipGetErrorString(e));
+  }
+}
+
+void Engine::capture_graph() {
+  if (graph_exec_) {
+    hipGraphExecDestroy(graph_exec_);
+    graph_exec_ = nullptr;
+  }
+  if (graph_) {
+    hipGraphDestroy(graph_);
+    graph_ = nullptr;
+  }
+  VP_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+  try {
+    run_eager();
+  } catch (...) {
+    hipGraph_t g = nullptr;
+    hipStreamEndCapture(stream_, &g);
+    if (g) hipGraphDestroy(g);
+    throw;
+  }
+  VP_HIP_CHECK(hipStreamEndCapture(stream_, &graph_));
+  VP_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+  graph_valid_ = true;
+}
+
+void Engine::enqueue() {
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
+  if (!warmed_) {  // first pass is eager: sets kernel attributes and surfaces launch errors with layer names
+    run_eager();
+    VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    warmed_ = true;
+    have_outputs_ = true;
+    if (!use_graph_) return;
+  }
+  if (use_graph_) {
+    if (!graph_valid_) capture_graph();
+    VP_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
+  } else {
+    run_eager();
+  }
+  have_outputs_ = true;
+}
+
+void Engine::sync() { VP_HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+void Engine::fetch_outputs() {
+  VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::read_input_tensor(float* dst) {
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  VP_HIP_CHECK(hipMemcpy(dst, d_input_, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyDeviceToHost));
+}
+
+// OpenCV resizeNN index table (oracle/pre_post.py nearest_index)
+static void nearest_tab(int src, int dst, int* tab) {
+  const double inv = (double)dst / (double)src;
+  const double ifx = 1.0 / inv;
+  for (int d = 0; d < dst; ++d) tab[d] = std::min((int)std::floor(d * ifx), src - 1);
+}
+static void linear_taps_f32(int src, int dst, int* idx, float* wgt) {
+  const double scale = (double)src / (double)dst;
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)std::floor(f);
+    f -= (float)s;
+    if (s < 0) {
+      f = 0.0f;
+      s = 0;
+    }
+    if (s >= src - 1) {
+      f = 0.0f;
+      s = src - 1;
+    }
+    idx[2 * d] = s;
+    idx[2 * d + 1] = std::min(s + 1, src - 1);
+    wgt[2 * d] = 1.0f - f;
+    wgt[2 * d + 1] = f;
+  }
+}
+
+void Engine::mask_resized(uint8_t* dst, int h, int w) {
+  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
+  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
+  const size_t need = (size_t)h * w, tabn = (size_t)(h + w);
+  if (need > resize_cap_) {
+    d_resize_out_ = dalloc(std::max(need, (size_t)4 * h * w), false);
+    resize_cap_ = std::max(need, (size_t)4 * h * w);
+  }
+  if (tabn * 4 > rs_tab_cap_) {
+    d_rs_tab_ = static_cast<int*>(dalloc(tabn * 4 * sizeof(int), false));
+    rs_tab_cap_ = tabn * 4;
+  }
+  std::vector<int> tab(h + w);
+  nearest_tab(out_h_, h, tab.data());
+  nearest_tab(out_w_, w, tab.data() + h);
+  VP_HIP_CHECK(hipMemcpyAsync(d_rs_tab_, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+  VP_HIP_CHECK(launch_resize_nearest(d_mask_, out_w_, d_rs_tab_, d_rs_tab_ + h, h, w, static_cast<uint8_t*>(d_resize_out_), stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, need, hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::depth_resized(float* dst, int h, int w) {
+  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
+  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
+  const size_t need = (size_t)4 * h * w, tabn = (size_t)4 * (h + w);
+  if (need > resize_cap_) {
+    d_resize_out_ = dalloc(need, false);
+    resize_cap_ = need;
+  }
+  if (tabn > rs_tab_cap_) {
+    d_rs_tab_ = static_cast<int*>(dalloc(tabn * sizeof(int), false));
+    rs_tab_cap_ = tabn;
+  }
+  std::vector<int> idx(2 * (h + w));
+  std::vector<float> wgt(2 * (h + w));
+  linear_taps_f32(out_h_, h, idx.data(), wgt.data());
+  linear_taps_f32(out_w_, w, idx.data() + 2 * h, wgt.data() + 2 * h);
+  int* d_idx = d_rs_tab_;
+  float* d_wgt = reinterpret_cast<float*>(d_rs_tab_ + 2 * (h + w));
+  VP_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(d_wgt, wgt.data(), wgt.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  VP_HIP_CHECK(launch_resize_bilinear_f32(d_logits_, out_w_, d_idx, d_wgt, d_idx + 2 * h, d_wgt + 2 * h, h, w,
+                                          static_cast<float*>(d_resize_out_), stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, need, hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// -------------------------------------------------------------------------------------------------- timing
+void Engine::timer_begin() { VP_HIP_CHECK(hipEventRecord(ev0_, stream_)); }
+float Engine::timer_end() {
+  VP_HIP_CHECK(hipEventRecord(ev1_, stream_));
+  VP_HIP_CHECK(hipEventSynchronize(ev1_));
+  float ms = 0.f;
+  VP_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+  return ms;
+}
+
+int Engine::profile_layers(int iters, float* ms, int cap) {
+  const size_t first = input_is_tensor_ ? first_net_op_ : 0;
+  const int n = (int)ops_.size();
+  if (cap < n) throw std::invalid_argument("profile buffer too small");
+  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident");
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) VP_HIP_CHECK(hipEventCreate(&e));
+  std::vector<double> acc(n, 0.0);
+  for (int it = 0; it < iters + 1; ++it) {  // iteration 0 is a warm-up
+    for (int i = (int)first; i < n; ++i) {
+      VP_HIP_CHECK(hipEventRecord(ev[i], stream_));
+      hipError_t e = ops_[i].run(stream_);
+      if (e != hipSuccess) throw std::runtime_error("launch failed in layer '" + ops_[i].name + "'");
+    }
+    VP_HIP_CHECK(hipEventRecord(ev[n], stream_));
+    VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    if (it == 0) continue;
+    for (int i = (int)first; i < n; ++i) {
+      float t = 0.f;
+      VP_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      acc[i] += t;
+    }
+  }
+  for (int i = 0; i < n; ++i) ms[i] = (float)(acc[i] / std::max(1, iters));
+  for (auto& e : ev) hipEventDestroy(e);
+  warmed_ = true;
+  have_outputs_ = true;
+  return n;
+}
+
+void Engine::read_act(int i, float* dst) {
+  if (i < 0 || i >= (int)acts_.size()) throw std::invalid_argument("tensor index out of range");
+  const Act& a = *acts_[i];
+  const size_t n = (size_t)a.Creal * a.H * a.W;
+  float* d = nullptr;
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  VP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
+  hipError_t e = launch_act_to_nchw(a.view(), a.Creal, d, stream_);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+  if (e == hipSuccess) e = hipMemcpy(dst, d, n * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(d);
+  VP_HIP_CHECK(e);
+}
+
+}  // namespace vp

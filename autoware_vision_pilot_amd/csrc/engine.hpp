@@ -1,0 +1,187 @@
+// Host-side engine of libvp_hip: weight blob -> folded/packed device weights -> static per-model launch plan
+// (one HIP stream, replayed as a hipGraph) behind the C ABI of include/vp_hip.h.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace vp {
+
+struct HostTensor {
+  std::vector<int> shape;
+  std::vector<float> data;
+  size_t numel() const { return data.size(); }
+};
+
+// "VPW1" container: u32 count, then per tensor {u16 name_len, name, u8 ndim, u32 dims[ndim], fp32 data}.
+// Written by autoware_vision_pilot_amd/weights.py from a reference state_dict (keys kept verbatim).
+class WeightBlob {
+ public:
+  void parse(const void* blob, size_t bytes);
+  const HostTensor& get(const std::string& key) const;
+  bool has(const std::string& key) const { return t_.count(key) != 0; }
+  size_t size() const { return t_.size(); }
+
+ private:
+  std::map<std::string, HostTensor> t_;
+};
+
+struct Act {
+  std::string name;
+  int Creal = 0, C = 0, H = 0, W = 0;
+  half_t* hi = nullptr;
+  half_t* lo = nullptr;
+  ActView view() const { return ActView{hi, lo, H, W, C}; }
+  size_t elems() const { return (size_t)H * W * C; }
+};
+
+struct Op {
+  std::string name;
+  double flops = 0, bytes = 0;
+  std::function<hipError_t(hipStream_t)> run;
+};
+
+struct ConvOpts {
+  int act = ACT_NONE;
+  int res_mode = RES_NONE;
+  const Act* res = nullptr;
+  int tile = -1, bk = -1, nsplit = -1;
+  float* logits_out = nullptr;  // STORE_NCHW_F32 target
+};
+
+class Engine {
+ public:
+  Engine(int kind, const WeightBlob* blob, int precision, int gpu_id);
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  // configuration
+  void set_input_format(int pixel_format, int plane_order);
+  void set_decode_mode(int mode);
+  int net_h() const { return 320; }
+  int net_w() const { return 640; }
+
+  // frame path
+  void upload_frame(const uint8_t* frame, int h, int w, int stride);
+  void upload_tensor(const float* nchw);
+  void enqueue();
+  void sync();
+  void fetch_outputs();
+  void mask_resized(uint8_t* dst, int h, int w);
+  void depth_resized(float* dst, int h, int w);
+  void read_input_tensor(float* dst);
+
+  const float* host_logits() const { return h_logits_; }
+  const uint8_t* host_mask() const { return h_mask_; }
+  void* dev_logits() const { return d_logits_; }
+  void* dev_mask() const { return d_mask_; }
+  int out_c() const { return out_c_; }
+  int out_h() const { return out_h_; }
+  int out_w() const { return out_w_; }
+  bool have_outputs() const { return have_outputs_; }
+  void use_graph(bool on) { use_graph_ = on; }
+
+  void timer_begin();
+  float timer_end();
+  int profile_layers(int iters, float* ms, int cap);
+
+  const std::vector<Op>& ops() const { return ops_; }
+  const std::vector<std::unique_ptr<Act>>& acts() const { return acts_; }
+  void read_act(int i, float* dst);
+
+  // plan-building blocks (public for the single-op test entry)
+  Act* new_act(const std::string& name, int creal, int h, int w);
+  Act* add_conv(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout, int ks,
+                const ConvOpts& o, Act* out_override = nullptr);
+  Act* add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
+                 const ConvOpts& o);
+  void run_eager();
+  void upload_act(Act* a, const float* chw);
+  hipStream_t stream() const { return stream_; }
+  bool split() const { return precision_ == 1; }
+
+  std::string last_error;
+
+ private:
+  struct PackedConv {
+    half_t* w_hi = nullptr;
+    half_t* w_lo = nullptr;
+    float* bias = nullptr;
+    int CoutW = 0, tile = 0, bk = 32, nsplit = 1;
+  };
+  void* dalloc(size_t bytes, bool zero = true);
+  template <class T>
+  T* dupload(const std::vector<T>& v);
+  void choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc);
+  void push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
+                    int store_mode, int cout_real);
+
+  void build_model(const WeightBlob& blob);
+  std::vector<Act*> build_backbone(const WeightBlob& blob, const std::string& prefix);
+  Act* build_context(const WeightBlob& blob, const std::string& p, const Act* deep, int cctx);
+  Act* build_neck(const WeightBlob& blob, const std::string& p, const Act* ctx, const std::vector<Act*>& feats, int cctx);
+  void build_head(const WeightBlob& blob, const std::string& p, const Act* neck, const std::vector<Act*>& feats);
+  void finish_plan();
+  void ensure_tables(int h, int w);
+  void capture_graph();
+
+  int kind_, precision_, gpu_;
+  hipStream_t stream_ = nullptr;
+  std::vector<void*> allocs_;
+  std::vector<std::unique_ptr<Act>> acts_;
+  std::vector<Op> ops_;
+  size_t first_net_op_ = 0;  // ops_[0] is the preprocess op (skipped for vp_infer_tensor)
+
+  // input
+  int pixel_format_ = 0, plane_order_ = 0, decode_mode_ = 0;
+  uint8_t* d_frame_ = nullptr;
+  size_t frame_cap_ = 0;
+  int frame_h_ = 0, frame_w_ = 0, frame_stride_ = 0;
+  int* d_xtab_ = nullptr;
+  int* d_ytab_ = nullptr;
+  int tab_h_ = 0, tab_w_ = 0;
+  float* d_input_ = nullptr;  // [3][320][640]
+  bool input_is_tensor_ = false;
+
+  // outputs
+  int out_c_ = 0, out_h_ = 0, out_w_ = 0;
+  float* d_logits_ = nullptr;
+  uint8_t* d_mask_ = nullptr;
+  float* h_logits_ = nullptr;
+  uint8_t* h_mask_ = nullptr;
+  bool have_outputs_ = false;
+
+  // split-K scratch
+  float* d_partial_ = nullptr;
+  size_t partial_need_ = 0;
+  std::vector<float**> partial_slots_;
+
+  // resize scratch
+  void* d_resize_out_ = nullptr;
+  size_t resize_cap_ = 0;
+  int* d_rs_tab_ = nullptr;
+  size_t rs_tab_cap_ = 0;
+
+  // graph
+  bool use_graph_ = true;
+  hipGraph_t graph_ = nullptr;
+  hipGraphExec_t graph_exec_ = nullptr;
+  bool graph_valid_ = false, graph_for_tensor_ = false;
+  bool warmed_ = false;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+};
+
+#define VP_HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess)                                                                                    \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);           \
+  } while (0)
+
+}  // namespace vp

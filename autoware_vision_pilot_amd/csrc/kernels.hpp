@@ -1,0 +1,107 @@
+// Kernel parameter blocks + host launchers of libvp_hip (definitions in kernels_conv.hip / kernels_misc.hip).
+#pragma once
+#include "common.hpp"
+
+namespace vp {
+
+struct PreprocessParams {
+  const uint8_t* frame;  // device, HxWx3
+  int stride;            // bytes per row
+  const int* xtab;       // [out_w][4] = x0, x1, a0, a1
+  const int* ytab;       // [out_h][4] = y0, y1, b0, b1
+  int out_h, out_w;
+  int src_c[3];          // source byte index feeding output plane 0,1,2
+  float mean[3], stdv[3];
+  float* out;            // [3][out_h][out_w]
+};
+
+struct StemParams {
+  const float* in;  // [3][H][W]
+  int H, W;         // input size (output is H/2 x W/2)
+  const float* w;   // [27][32]  (k = (ci*3+ky)*3+kx, co fastest), BN scale folded
+  const float* b;   // [32]
+  ActView out;      // C = 32
+};
+
+struct DwParams {
+  ActView in, out;
+  const float* w;  // [k*k][C]
+  const float* b;  // [C]
+  int k, stride;
+};
+
+struct PoolParams {
+  ActView in;
+  float* partial;  // [nslab][C]
+  int nslab;
+};
+
+struct SeParams {
+  const float* partial;  // [nslab][C]
+  int nslab, C, Creal, sq;
+  float inv_hw;
+  const float* w1;  // [sq][C]   (zero in pad columns)
+  const float* b1;  // [sq]
+  const float* w2;  // [C][sq]
+  const float* b2;  // [C]
+  float* scale;     // [C]
+};
+
+struct ScaleWParams {
+  const float* w;  // [rows][C] fp32 (BN folded)
+  const float* scale;
+  half_t* out_hi;
+  half_t* out_lo;  // may be null
+  int rows, C;
+};
+
+struct FcParams {
+  const float* x;
+  const float* w;  // [N][K]
+  const float* b;
+  float* out;
+  int N, K, act;
+  const float* partial;  // optional: x = mean over nslab partial sums (avg-pool input, scene_context.py:27)
+  int nslab, Kstride;
+  float inv_hw;
+};
+
+struct CtxConv1Params {
+  const float* map;  // [H][W] fp32
+  int H, W;
+  const float* w;    // [9][C]
+  const float* b;    // [C]
+  ActView out;
+};
+
+struct FusionParams {
+  ActView f[5];
+  int creal[5];   // 32,24,40,80,1280
+  int shift[5];   // 4,3,2,1,0
+  ActView out;    // 10x20 x 1472 (1456 real)
+  int Creal_out;
+};
+
+// tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px ; bk = 32 | 64
+hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st);
+int conv_tile_co(int tile);
+int conv_tile_px(int tile);
+
+hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
+hipError_t launch_stem(const StemParams& p, hipStream_t st);
+hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
+hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
+hipError_t launch_se_fc(const SeParams& p, hipStream_t st);
+hipError_t launch_scale_weights(const ScaleWParams& p, hipStream_t st);
+hipError_t launch_fc(const FcParams& p, hipStream_t st);
+hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st);
+hipError_t launch_fusion(const FusionParams& p, hipStream_t st);
+hipError_t launch_decode_mask(const float* logits, int C, int HW, int mode, uint8_t* out, hipStream_t st);
+hipError_t launch_resize_nearest(const uint8_t* src, int sw, const int* ytab, const int* xtab, int oh, int ow, uint8_t* dst,
+                                 hipStream_t st);
+hipError_t launch_resize_bilinear_f32(const float* src, int sw, const int* yi, const float* yf, const int* xi, const float* xf,
+                                      int oh, int ow, float* dst, hipStream_t st);
+hipError_t launch_nchw_to_act(const float* src, int Creal, const ActView& a, hipStream_t st);
+hipError_t launch_act_to_nchw(const ActView& a, int Creal, float* dst, hipStream_t st);
+
+}  // namespace vp

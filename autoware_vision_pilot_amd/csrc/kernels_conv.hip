@@ -1,0 +1,285 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_f16), im2col-free.
+//
+// Covers every dense conv of the hot path:
+//   * 3x3 / stride 1 / pad 1 convs of context, neck and heads (scene_context.py:19-22, scene_neck.py:13-24,
+//     scene_seg_head.py:13-19, ...),
+//   * 1x1 convs (skip links scene_neck.py:12,17,22; EfficientNet-B0 expand / project / head convs),
+//   * ConvTranspose2d(k2,s2) as a GEMM over input pixels with N = 4*Cout and a pixel-shuffle store
+//     (scene_neck.py:11,16,21; scene_seg_head.py:11,16).
+//
+// GEMM view (swapped so that the MFMA result registers hold consecutive output channels of ONE pixel, which
+// is the contiguous direction of NHWC):   D[co][px] = sum_k  Wt[co][k] * X[px][k],   k = (tap, cin).
+//   MFMA A operand  = weight tile  [CO_TILE][BK]   (rows  -> output channels, result register index)
+//   MFMA B operand  = pixel  tile  [PX_TILE][BK]   (cols  -> pixels, lane & 31)
+// Pixels are the linear index m = y*W + x, so a tile is any PX_TILE consecutive pixels (ragged edges and
+// images narrower than the tile are handled by predication, zero padding by predicated loads).
+//
+// Pipeline: register-staged global->LDS double buffer, one barrier per K step; LDS rows padded by 16 B
+// (80 B / 144 B row pitch: conflict-free for ds_read_b128's 16-lane groups).
+// fp16x3 mode (SPLIT): both operands carry a hi and a lo fp16 plane; three MFMAs per tile pair.
+#include "kernels.hpp"
+
+namespace vp {
+
+__device__ __forceinline__ void epilogue_store4(const ConvGemmParams& p, int M, int m, int co, float v[4]) {
+  const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + co);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r] + b[r], p.act);
+
+  if (p.store_mode == STORE_NCHW_F32) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (co + r < p.Creal) p.out_f32[(size_t)(co + r) * M + m] = v[r];
+    return;
+  }
+  size_t o;
+  if (p.store_mode == STORE_SHUFFLE2) {
+    const int q = co / p.Cstore, c = co - q * p.Cstore;
+    const int y = m / p.W, x = m - y * p.W;
+    o = ((size_t)(2 * y + (q >> 1)) * (2 * p.W) + (2 * x + (q & 1))) * p.Cstore + c;
+  } else {
+    o = (size_t)m * p.Cstore + co;
+  }
+  if (p.res_mode != RES_NONE) {
+    const h4_t rh = *reinterpret_cast<const h4_t*>(p.res_hi + o);
+    float r4[4] = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+    if (p.res_lo) {
+      const h4_t rl = *reinterpret_cast<const h4_t*>(p.res_lo + o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) r4[r] += (float)rl[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == RES_ADD) ? (v[r] + r4[r]) : (v[r] * r4[r] + r4[r]);
+  }
+  h4_t hi;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) hi[r] = (half_t)v[r];
+  *reinterpret_cast<h4_t*>(p.out_hi + o) = hi;
+  if (p.out_lo) {
+    h4_t lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lo[r] = (half_t)(v[r] - (float)hi[r]);
+    *reinterpret_cast<h4_t*>(p.out_lo + o) = lo;
+  }
+}
+
+template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+  static_assert(WCO * WPX == 4, "4 waves per workgroup");
+  constexpr int ROWB = BK * 2 + 16;   // LDS row pitch in bytes
+  constexpr int CH = BK / 8;          // 16-byte chunks per row
+  constexpr int A_CHUNKS = CO_TILE * CH, B_CHUNKS = PX_TILE * CH;
+  constexpr int A_ITERS = (A_CHUNKS + 255) / 256, B_ITERS = (B_CHUNKS + 255) / 256;
+  constexpr int MT = CO_TILE / WCO / 32, NT = PX_TILE / WPX / 32;
+  static_assert(MT >= 1 && NT >= 1, "wave tile must be at least 32x32");
+  constexpr int A_BYTES = CO_TILE * ROWB, B_BYTES = PX_TILE * ROWB;
+  constexpr int STAGE = (A_BYTES + B_BYTES) * (SPLIT ? 2 : 1);
+  constexpr int OFF_AHI = 0, OFF_BHI = A_BYTES, OFF_ALO = A_BYTES + B_BYTES, OFF_BLO = 2 * A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave / WPX, wpx = wave % WPX;
+  const int M = p.H * p.W;
+  const int m0 = blockIdx.x * PX_TILE, co0 = blockIdx.y * CO_TILE;
+  const int KC = p.Cin / BK;
+  const int S = p.ks * p.ks * KC;
+  const int s_begin = (int)(((long long)S * blockIdx.z) / p.nsplit);
+  const int s_end = (int)(((long long)S * (blockIdx.z + 1)) / p.nsplit);
+  const int half_k = p.ks >> 1;
+
+  // ---- per-thread staging assignment
+  size_t a_off[A_ITERS];
+  int a_lds[A_ITERS];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int idx = tid + 256 * i, row = idx / CH, ch = idx % CH;
+    a_off[i] = (size_t)(co0 + row) * p.Cin + ch * 8;
+    a_lds[i] = row * ROWB + ch * 16;
+  }
+  int b_y[B_ITERS], b_x[B_ITERS], b_lds[B_ITERS], b_ch[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    const int idx = tid + 256 * i, row = idx / CH, ch = idx % CH;
+    const int m = m0 + row;
+    const bool ok = (idx < B_CHUNKS) && (m < M);
+    const int y = m / p.W;
+    b_y[i] = ok ? y : -(1 << 20);
+    b_x[i] = m - y * p.W;
+    b_ch[i] = ch * 8;
+    b_lds[i] = row * ROWB + ch * 16;
+  }
+
+  uint4 ra_hi[A_ITERS], rb_hi[B_ITERS], ra_lo[SPLIT ? A_ITERS : 1], rb_lo[SPLIT ? B_ITERS : 1];
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+  auto load_regs = [&](int s) {
+    const int tap = s / KC;
+    const int c0 = (s - tap * KC) * BK;
+    const int ky = tap / p.ks;
+    const int dy = ky - half_k, dx = (tap - ky * p.ks) - half_k;
+    const size_t wbase = (size_t)tap * p.CoutW * p.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) {
+        ra_hi[i] = *reinterpret_cast<const uint4*>(p.w_hi + wbase + a_off[i]);
+        if constexpr (SPLIT) ra_lo[i] = *reinterpret_cast<const uint4*>(p.w_lo + wbase + a_off[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int yy = b_y[i] + dy, xx = b_x[i] + dx;
+      const bool ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+      const size_t g = ((size_t)yy * p.W + xx) * p.Cin + c0 + b_ch[i];
+      rb_hi[i] = ok ? *reinterpret_cast<const uint4*>(p.in_hi + g) : zero4;
+      if constexpr (SPLIT) rb_lo[i] = ok ? *reinterpret_cast<const uint4*>(p.in_lo + g) : zero4;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) {
+        *reinterpret_cast<uint4*>(st + OFF_AHI + a_lds[i]) = ra_hi[i];
+        if constexpr (SPLIT) *reinterpret_cast<uint4*>(st + OFF_ALO + a_lds[i]) = ra_lo[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      if (B_CHUNKS % 256 == 0 || tid + 256 * i < B_CHUNKS) {
+        *reinterpret_cast<uint4*>(st + OFF_BHI + b_lds[i]) = rb_hi[i];
+        if constexpr (SPLIT) *reinterpret_cast<uint4*>(st + OFF_BLO + b_lds[i]) = rb_lo[i];
+      }
+    }
+  };
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
+  const int a_frag = OFF_AHI + (wco * MT * 32) * ROWB + frag_off;
+  const int b_frag = OFF_BHI + (wpx * NT * 32) * ROWB + frag_off;
+
+  if (s_begin < s_end) {
+    load_regs(s_begin);
+    store_lds(0);
+  }
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    if (s + 1 < s_end) load_regs(s + 1);
+    const char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      h8_t a[MT], b[NT], alo[SPLIT ? MT : 1], blo[SPLIT ? NT : 1];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        a[i] = *reinterpret_cast<const h8_t*>(st + a_frag + i * 32 * ROWB + kk * 32);
+        if constexpr (SPLIT) alo[i] = *reinterpret_cast<const h8_t*>(st + (OFF_ALO - OFF_AHI) + a_frag + i * 32 * ROWB + kk * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        b[j] = *reinterpret_cast<const h8_t*>(st + b_frag + j * 32 * ROWB + kk * 32);
+        if constexpr (SPLIT) blo[j] = *reinterpret_cast<const h8_t*>(st + (OFF_BLO - OFF_BHI) + b_frag + j * 32 * ROWB + kk * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if constexpr (SPLIT) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], blo[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (s + 1 < s_end) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds pixel (lane&31), registers hold 4 groups of 4 consecutive output channels
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int m = m0 + (wpx * NT + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + (wco * MT + i) * 32 + 8 * g + 4 * (lane >> 5);
+        if (m < M && co < p.Ncols) {
+          float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          if (p.nsplit > 1) {
+            f32x4_t o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4_t*>(p.partial + ((size_t)blockIdx.z * M + m) * p.CoutW + co) = o;
+          } else {
+            epilogue_store4(p, M, m, co, v);
+          }
+        }
+      }
+    }
+}
+
+// Sums the split-K partial slabs in a fixed order (deterministic) and runs the shared epilogue.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams p) {
+  const int M = p.H * p.W;
+  const int groups = p.Ncols >> 2;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)M * groups) return;
+  const int m = (int)(t / groups), co = (int)(t % groups) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.nsplit; ++z) {
+    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.partial + ((size_t)z * M + m) * p.CoutW + co);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += q[r];
+  }
+  epilogue_store4(p, M, m, co, v);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+template <int BK, int CO, int PX, int WCO, int WPX, bool SPLIT>
+static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int ROWB = BK * 2 + 16;
+  constexpr int lds = 2 * (CO + PX) * ROWB * (SPLIT ? 2 : 1);
+  auto k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int M = p.H * p.W;
+  dim3 grid((M + PX - 1) / PX, p.CoutW / CO, p.nsplit);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (p.nsplit > 1) {
+    const long long n = (long long)M * (p.Ncols >> 2);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px
+hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st) {
+#define VP_CASE(T, CO, PX, WCO, WPX)                                                          \
+  if (tile == T) {                                                                            \
+    if (bk == 64) return split ? launch_cfg<64, CO, PX, WCO, WPX, true>(p, st) : launch_cfg<64, CO, PX, WCO, WPX, false>(p, st); \
+    return split ? launch_cfg<32, CO, PX, WCO, WPX, true>(p, st) : launch_cfg<32, CO, PX, WCO, WPX, false>(p, st);   \
+  }
+  VP_CASE(0, 128, 128, 2, 2)
+  VP_CASE(1, 64, 128, 2, 2)
+  VP_CASE(2, 64, 64, 2, 2)
+  VP_CASE(3, 32, 128, 1, 4)
+#undef VP_CASE
+  return hipErrorInvalidValue;
+}
+
+int conv_tile_co(int tile) { return tile == 0 ? 128 : (tile == 3 ? 32 : 64); }
+int conv_tile_px(int tile) { return tile == 2 ? 64 : 128; }
+
+}  // namespace vp

@@ -1,0 +1,269 @@
+// C ABI of libvp_hip.so (declarations + reference citations: include/vp_hip.h).  No exception crosses it.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "../../include/vp_hip.h"
+#include "engine.hpp"
+
+struct vp_engine {
+  std::unique_ptr<vp::Engine> impl;
+  std::string err;
+};
+
+namespace {
+
+void set_err(char* err, size_t n, const std::string& msg) {
+  if (err && n) {
+    std::snprintf(err, n, "%s", msg.c_str());
+  }
+}
+
+template <class F>
+int guarded(vp_engine* e, F&& f) {
+  if (!e || !e->impl) return VP_ERR_ARG;
+  try {
+    f(*e->impl);
+    return VP_OK;
+  } catch (const std::invalid_argument& ex) {
+    e->err = ex.what();
+    return VP_ERR_ARG;
+  } catch (const std::exception& ex) {
+    e->err = ex.what();
+    return std::strncmp(ex.what(), "HIP error", 9) == 0 ? VP_ERR_HIP : VP_ERR_STATE;
+  }
+}
+
+int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int precision, int gpu_id, char* err, size_t err_len) {
+  if (!out) return VP_ERR_ARG;
+  *out = nullptr;
+  try {
+    vp::WeightBlob wb;
+    try {
+      wb.parse(blob, bytes);
+    } catch (const std::exception& ex) {
+      set_err(err, err_len, ex.what());
+      return VP_ERR_WEIGHTS;
+    }
+    auto h = std::make_unique<vp_engine>();
+    try {
+      h->impl = std::make_unique<vp::Engine>(kind, &wb, precision, gpu_id);
+    } catch (const std::invalid_argument& ex) {
+      set_err(err, err_len, ex.what());
+      return VP_ERR_ARG;
+    } catch (const std::exception& ex) {
+      set_err(err, err_len, ex.what());
+      return std::strstr(ex.what(), "weight") ? VP_ERR_WEIGHTS : VP_ERR_HIP;
+    }
+    *out = h.release();
+    return VP_OK;
+  } catch (...) {
+    set_err(err, err_len, "unknown failure");
+    return VP_ERR_STATE;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vp_version(void) { return "libvp_hip 0.1 (gfx950)"; }
+
+int vp_create_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id, char* err,
+                          size_t err_len) {
+  if (!blob) {
+    set_err(err, err_len, "null weight blob");
+    return VP_ERR_ARG;
+  }
+  return create_impl(out, model_kind, blob, blob_bytes, precision, gpu_id, err, err_len);
+}
+
+int vp_create(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, char* err, size_t err_len) {
+  if (!weights_path || !*weights_path) {
+    set_err(err, err_len, "No path to weight file provided");  // scene_seg_infer.py:33
+    return VP_ERR_ARG;
+  }
+  std::ifstream f(weights_path, std::ios::binary | std::ios::ate);
+  if (!f) {
+    set_err(err, err_len, std::string("cannot open weight file: ") + weights_path);
+    return VP_ERR_WEIGHTS;
+  }
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  std::vector<char> buf((size_t)n);
+  if (!f.read(buf.data(), n)) {
+    set_err(err, err_len, "short read on weight file");
+    return VP_ERR_WEIGHTS;
+  }
+  return create_impl(out, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
+}
+
+void vp_destroy(vp_engine* e) { delete e; }
+
+const char* vp_last_error(const vp_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order) {
+  return guarded(e, [&](vp::Engine& g) { g.set_input_format(pixel_format, plane_order); });
+}
+int vp_set_decode_mode(vp_engine* e, int mode) {
+  return guarded(e, [&](vp::Engine& g) { g.set_decode_mode(mode); });
+}
+int vp_input_hw(const vp_engine* e, int* h, int* w) {
+  if (!e || !e->impl || !h || !w) return VP_ERR_ARG;
+  *h = e->impl->net_h();
+  *w = e->impl->net_w();
+  return VP_OK;
+}
+
+int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes) {
+  return guarded(e, [&](vp::Engine& g) {
+    g.upload_frame(frame, h, w, stride_bytes);
+    g.enqueue();
+    g.fetch_outputs();
+  });
+}
+int vp_infer_tensor(vp_engine* e, const float* nchw) {
+  return guarded(e, [&](vp::Engine& g) {
+    g.upload_tensor(nchw);
+    g.enqueue();
+    g.fetch_outputs();
+  });
+}
+int vp_logits(const vp_engine* e, const float** data, int64_t shape[4]) {
+  if (!e || !e->impl || !data || !shape) return VP_ERR_ARG;
+  if (!e->impl->have_outputs()) {
+    const_cast<vp_engine*>(e)->err = "Inference has not been run yet. Call vp_infer() first.";  // onnx_runtime_backend.cpp:86-88
+    return VP_ERR_STATE;
+  }
+  *data = e->impl->host_logits();
+  shape[0] = 1;
+  shape[1] = e->impl->out_c();
+  shape[2] = e->impl->out_h();
+  shape[3] = e->impl->out_w();
+  return VP_OK;
+}
+int vp_mask_u8(const vp_engine* e, const uint8_t** data, int* h, int* w) {
+  if (!e || !e->impl || !data || !h || !w) return VP_ERR_ARG;
+  if (!e->impl->have_outputs()) {
+    const_cast<vp_engine*>(e)->err = "Inference has not been run yet. Call vp_infer() first.";
+    return VP_ERR_STATE;
+  }
+  *data = e->impl->host_mask();
+  *h = e->impl->out_h();
+  *w = e->impl->out_w();
+  return VP_OK;
+}
+int vp_mask_resized_u8(vp_engine* e, uint8_t* dst, int h, int w) {
+  return guarded(e, [&](vp::Engine& g) { g.mask_resized(dst, h, w); });
+}
+int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w) {
+  return guarded(e, [&](vp::Engine& g) { g.depth_resized(dst, h, w); });
+}
+int vp_input_tensor(vp_engine* e, float* dst) {
+  return guarded(e, [&](vp::Engine& g) { g.read_input_tensor(dst); });
+}
+
+int vp_upload_frame(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes) {
+  return guarded(e, [&](vp::Engine& g) { g.upload_frame(frame, h, w, stride_bytes); });
+}
+int vp_enqueue(vp_engine* e) {
+  return guarded(e, [&](vp::Engine& g) { g.enqueue(); });
+}
+int vp_sync(vp_engine* e) {
+  return guarded(e, [&](vp::Engine& g) { g.sync(); });
+}
+int vp_fetch_outputs(vp_engine* e) {
+  return guarded(e, [&](vp::Engine& g) { g.fetch_outputs(); });
+}
+int vp_device_outputs(const vp_engine* e, void** logits, void** mask) {
+  if (!e || !e->impl) return VP_ERR_ARG;
+  if (logits) *logits = e->impl->dev_logits();
+  if (mask) *mask = e->impl->dev_mask();
+  return VP_OK;
+}
+int vp_use_graph(vp_engine* e, int enable) {
+  return guarded(e, [&](vp::Engine& g) { g.use_graph(enable != 0); });
+}
+int vp_timer_begin(vp_engine* e) {
+  return guarded(e, [&](vp::Engine& g) { g.timer_begin(); });
+}
+int vp_timer_end(vp_engine* e, float* ms) {
+  return guarded(e, [&](vp::Engine& g) {
+    const float t = g.timer_end();
+    if (ms) *ms = t;
+  });
+}
+
+int vp_layer_count(const vp_engine* e) { return (e && e->impl) ? (int)e->impl->ops().size() : VP_ERR_ARG; }
+int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, double* bytes) {
+  if (!e || !e->impl || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
+  const vp::Op& op = e->impl->ops()[i];
+  if (name) *name = op.name.c_str();
+  if (flops) *flops = op.flops;
+  if (bytes) *bytes = op.bytes;
+  return VP_OK;
+}
+int vp_profile_layers(vp_engine* e, int iters, float* ms, int capacity) {
+  int n = 0;
+  const int rc = guarded(e, [&](vp::Engine& g) { n = g.profile_layers(iters, ms, capacity); });
+  return rc == VP_OK ? n : rc;
+}
+int vp_tensor_count(const vp_engine* e) { return (e && e->impl) ? (int)e->impl->acts().size() : VP_ERR_ARG; }
+int vp_tensor_info(const vp_engine* e, int i, const char** name, int* c, int* h, int* w) {
+  if (!e || !e->impl || i < 0 || i >= (int)e->impl->acts().size()) return VP_ERR_ARG;
+  const vp::Act& a = *e->impl->acts()[i];
+  if (name) *name = a.name.c_str();
+  if (c) *c = a.Creal;
+  if (h) *h = a.H;
+  if (w) *w = a.W;
+  return VP_OK;
+}
+int vp_tensor_read(vp_engine* e, int i, float* dst) {
+  return guarded(e, [&](vp::Engine& g) { g.read_act(i, dst); });
+}
+
+int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
+                 int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out, char* err,
+                 size_t err_len) {
+  if (!in || !weight || !bias || !out || cin < 1 || cout < 1 || h < 1 || w < 1) {
+    set_err(err, err_len, "bad argument");
+    return VP_ERR_ARG;
+  }
+  try {
+    vp::Engine g(-1, nullptr, precision, gpu_id);
+    vp::Act* a = g.new_act("in", cin, h, w);
+    g.upload_act(a, in);
+    const int oh = mode == 1 ? 2 * h : h, ow = mode == 1 ? 2 * w : w;
+    vp::ConvOpts o;
+    o.act = act;
+    o.tile = tile;
+    o.bk = bk;
+    o.nsplit = nsplit;
+    vp::Act* r = nullptr;
+    if (res_mode != 0) {
+      if (!res) throw std::invalid_argument("res_mode set but res is null");
+      r = g.new_act("res", cout, oh, ow);
+      g.upload_act(r, res);
+      o.res_mode = res_mode;
+      o.res = r;
+    }
+    const size_t wn = (size_t)cin * cout * (mode == 1 ? 4 : ks * ks);
+    std::vector<float> wv(weight, weight + wn), bv(bias, bias + cout);
+    vp::Act* y = mode == 1 ? g.add_convT("op", a, wv, bv, cout, o) : g.add_conv("op", a, wv, bv, cout, ks, o);
+    g.run_eager();
+    g.sync();
+    int idx = -1;
+    for (size_t i = 0; i < g.acts().size(); ++i)
+      if (g.acts()[i].get() == y) idx = (int)i;
+    g.read_act(idx, out);
+    return VP_OK;
+  } catch (const std::invalid_argument& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_ARG;
+  } catch (const std::exception& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_HIP;
+  }
+}
+
+}  // extern "C"

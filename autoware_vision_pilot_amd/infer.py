@@ -1,0 +1,80 @@
+"""Python operator API: same class names, call signatures, return types and errors as the reference's
+``Models/inference/*_infer.py`` wrappers, executed by libvp_hip on an MI355X (no torch, no CPU fallback).
+
+    SceneSegNetworkInfer(checkpoint_path).inference(PIL 640x320 RGB) -> int64  [320,640]   scene_seg_infer.py:11-57
+    Scene3DNetworkInfer(checkpoint_path).inference(image)            -> fp32   [320,640,1] scene_3d_infer.py:12-58
+    DomainSegNetworkInfer(checkpoint_path).inference(image)          -> fp32   [320,640,1] (0/1) domain_seg_infer.py:12-60
+    EgoLanesNetworkInfer(checkpoint_path).inference(image)           -> fp32   [3,80,160]  ego_lanes_infer.py:8-62
+
+``checkpoint_path`` is a VPW1 blob (``weights.export_checkpoint`` converts the reference ``.pth``), or blob bytes.
+``image`` is anything with ``.size == (640, 320)`` convertible by ``numpy.asarray`` to HxWx3 uint8 RGB (a PIL image),
+exactly what the reference's callers pass after ``PIL.Image.resize((640, 320))``.
+"""
+import numpy as np
+
+from . import lib as _lib
+
+_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+
+
+def image_loader(image):
+    """ToTensor + Normalize (scene_seg_infer.py:15-20): HxWx3 uint8 RGB -> 1x3xHxW fp32."""
+    a = np.asarray(image)
+    if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+        raise ValueError("image must be HxWx3 uint8 RGB")
+    x = (a.astype(np.float32) / np.float32(255.0) - _MEAN) / _STD
+    return np.ascontiguousarray(x.transpose(2, 0, 1))[None]
+
+
+class _NetworkInfer:
+    _kind = None
+
+    def __init__(self, checkpoint_path="", precision="fp16", gpu_id=0):
+        if checkpoint_path is None or len(checkpoint_path) == 0:
+            raise ValueError("No path to checkpiont file provided in class initialization")
+        self.device = f"hip:{gpu_id}"
+        self.model = _lib.Engine(self._kind, checkpoint_path, precision=precision, gpu_id=gpu_id)
+        self.model.set_input_format(_lib.VP_RGB8, _lib.VP_PLANES_RGB)
+
+    def _forward(self, image, check_size=True):
+        if check_size:
+            width, height = image.size
+            if width != 640 or height != 320:
+                raise ValueError("Incorrect input size - input image must have height of 320px and width of 640px")
+        self.model.infer_tensor(image_loader(image))
+        return self.model.logits()  # CxHxW fp32
+
+
+class SceneSegNetworkInfer(_NetworkInfer):
+    _kind = "sceneseg"
+
+    def __init__(self, checkpoint_path="", precision="fp16", gpu_id=0):
+        super().__init__(checkpoint_path, precision, gpu_id)
+        self.model.set_decode_mode(_lib.VP_DECODE_CLASS_INDEX)
+
+    def inference(self, image):
+        self._forward(image)
+        return self.model.mask().astype(np.int64)  # argmax index map, first max wins (scene_seg_infer.py:52-55)
+
+
+class Scene3DNetworkInfer(_NetworkInfer):
+    _kind = "scene3d"
+
+    def inference(self, image):
+        return np.ascontiguousarray(self._forward(image).transpose(1, 2, 0))
+
+
+class DomainSegNetworkInfer(_NetworkInfer):
+    _kind = "domainseg"
+
+    def inference(self, image):
+        self._forward(image)
+        return (self.model.mask() > 0).astype(np.float32)[..., None]  # 0/1 floats (domain_seg_infer.py:54-58)
+
+
+class EgoLanesNetworkInfer(_NetworkInfer):
+    _kind = "egolanes"
+
+    def inference(self, image):
+        return self._forward(image, check_size=False)  # ego_lanes_infer.py:50-62 has no size check

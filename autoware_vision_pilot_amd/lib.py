@@ -1,0 +1,254 @@
+"""ctypes binding of libvp_hip.so (C ABI: include/vp_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is visible every entry point
+raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C autoware_vision_pilot_amd/csrc``.
+
+Note for mixed processes (tests, bench): PyTorch-ROCm bundles its own ``libamdhip64.so``; import ``torch``
+BEFORE this module in any process that uses both, so that a single HIP runtime is loaded.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvp_hip.so")
+
+VP_SCENESEG, VP_SCENE3D, VP_DOMAINSEG, VP_EGOLANES = 0, 1, 2, 3
+VP_FP16, VP_FP16X3 = 0, 1
+VP_BGR8, VP_RGB8 = 0, 1
+VP_PLANES_BGR, VP_PLANES_RGB = 0, 1
+VP_DECODE_SEG_MASK, VP_DECODE_LANE_LABEL, VP_DECODE_CLASS_INDEX = 0, 1, 2
+KINDS = {"sceneseg": VP_SCENESEG, "scene3d": VP_SCENE3D, "domainseg": VP_DOMAINSEG, "egolanes": VP_EGOLANES}
+PRECISIONS = {"fp16": VP_FP16, "fp16x3": VP_FP16X3, "fp32": VP_FP16X3}
+
+# every symbol include/vp_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_SIGS = {
+    "vp_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_from_memory": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_destroy": (None, [_P]),
+    "vp_last_error": (C.c_char_p, [_P]),
+    "vp_set_input_format": (C.c_int, [_P, C.c_int, C.c_int]),
+    "vp_set_decode_mode": (C.c_int, [_P, C.c_int]),
+    "vp_input_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    "vp_infer_tensor": (C.c_int, [_P, _P]),
+    "vp_logits": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]),
+    "vp_mask_u8": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_mask_resized_u8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "vp_depth_resized_f32": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "vp_input_tensor": (C.c_int, [_P, _P]),
+    "vp_upload_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    "vp_enqueue": (C.c_int, [_P]),
+    "vp_sync": (C.c_int, [_P]),
+    "vp_fetch_outputs": (C.c_int, [_P]),
+    "vp_device_outputs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "vp_use_graph": (C.c_int, [_P, C.c_int]),
+    "vp_timer_begin": (C.c_int, [_P]),
+    "vp_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "vp_layer_count": (C.c_int, [_P]),
+    "vp_layer_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vp_profile_layers": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "vp_tensor_count": (C.c_int, [_P]),
+    "vp_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_tensor_read": (C.c_int, [_P, C.c_int, _P]),
+    "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
+                               C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
+    "vp_version": (C.c_char_p, []),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+class VpError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libvp_hip.so and bind every symbol; raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VpError(f"{LIB_PATH} not built -- run __graft_entry__.build(); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """Thin RAII wrapper over a vp_engine handle."""
+
+    def __init__(self, kind, weights, precision="fp16", gpu_id=0):
+        lib = load()
+        self._lib = lib
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        k = KINDS[kind] if isinstance(kind, str) else int(kind)
+        pr = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        if isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)):
+            buf = np.frombuffer(weights, dtype=np.uint8) if not isinstance(weights, np.ndarray) else weights
+            rc = lib.vp_create_from_memory(C.byref(self._h), k, _ptr(buf), buf.nbytes, pr, gpu_id, err, len(err))
+        else:
+            rc = lib.vp_create(C.byref(self._h), k, os.fsencode(weights) if weights else b"", pr, gpu_id, err, len(err))
+        if rc != 0:
+            self._h = C.c_void_p()
+            msg = err.value.decode(errors="replace")
+            raise (ValueError if rc == -1 else VpError)(f"vp_create failed ({rc}): {msg}")
+        self.kind = kind
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.vp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc < 0:
+            msg = self._lib.vp_last_error(self._h).decode(errors="replace")
+            raise (ValueError if rc == -1 else VpError)(f"libvp_hip error {rc}: {msg}")
+        return rc
+
+    # ---- configuration
+    def set_input_format(self, pixel_format, plane_order):
+        self._ck(self._lib.vp_set_input_format(self._h, pixel_format, plane_order))
+
+    def set_decode_mode(self, mode):
+        self._ck(self._lib.vp_set_decode_mode(self._h, mode))
+
+    def input_hw(self):
+        h, w = C.c_int(), C.c_int()
+        self._ck(self._lib.vp_input_hw(self._h, C.byref(h), C.byref(w)))
+        return h.value, w.value
+
+    # ---- synchronous path
+    def infer(self, frame_u8):
+        f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
+        if f.ndim != 3 or f.shape[2] != 3:
+            raise ValueError("frame must be HxWx3 uint8")
+        self._ck(self._lib.vp_infer(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
+
+    def infer_tensor(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.size != 3 * 320 * 640:
+            raise ValueError("tensor must be 1x3x320x640")
+        self._ck(self._lib.vp_infer_tensor(self._h, _ptr(x)))
+
+    def logits(self):
+        p = C.POINTER(C.c_float)()
+        shape = (C.c_int64 * 4)()
+        self._ck(self._lib.vp_logits(self._h, C.byref(p), shape))
+        n = int(shape[1] * shape[2] * shape[3])
+        return np.ctypeslib.as_array(p, shape=(n,)).reshape(tuple(shape)[1:]).copy()
+
+    def mask(self):
+        p = C.POINTER(C.c_uint8)()
+        h, w = C.c_int(), C.c_int()
+        self._ck(self._lib.vp_mask_u8(self._h, C.byref(p), C.byref(h), C.byref(w)))
+        return np.ctypeslib.as_array(p, shape=(h.value * w.value,)).reshape(h.value, w.value).copy()
+
+    def mask_resized(self, h, w):
+        out = np.empty((h, w), dtype=np.uint8)
+        self._ck(self._lib.vp_mask_resized_u8(self._h, _ptr(out), h, w))
+        return out
+
+    def depth_resized(self, h, w):
+        out = np.empty((h, w), dtype=np.float32)
+        self._ck(self._lib.vp_depth_resized_f32(self._h, _ptr(out), h, w))
+        return out
+
+    def input_tensor(self):
+        out = np.empty((1, 3, 320, 640), dtype=np.float32)
+        self._ck(self._lib.vp_input_tensor(self._h, _ptr(out)))
+        return out
+
+    # ---- device-resident path
+    def upload_frame(self, frame_u8):
+        f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
+        self._keep = f
+        self._ck(self._lib.vp_upload_frame(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
+
+    def enqueue(self):
+        self._ck(self._lib.vp_enqueue(self._h))
+
+    def sync(self):
+        self._ck(self._lib.vp_sync(self._h))
+
+    def fetch_outputs(self):
+        self._ck(self._lib.vp_fetch_outputs(self._h))
+
+    def device_outputs(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._ck(self._lib.vp_device_outputs(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def use_graph(self, on):
+        self._ck(self._lib.vp_use_graph(self._h, int(bool(on))))
+
+    def timer_begin(self):
+        self._ck(self._lib.vp_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._ck(self._lib.vp_timer_end(self._h, C.byref(ms)))
+        return ms.value
+
+    # ---- introspection
+    def layers(self):
+        out = []
+        for i in range(self._ck(self._lib.vp_layer_count(self._h))):
+            name, fl, by = C.c_char_p(), C.c_double(), C.c_double()
+            self._ck(self._lib.vp_layer_info(self._h, i, C.byref(name), C.byref(fl), C.byref(by)))
+            out.append((name.value.decode(), fl.value, by.value))
+        return out
+
+    def profile_layers(self, iters=10):
+        n = self._ck(self._lib.vp_layer_count(self._h))
+        ms = np.zeros(n, dtype=np.float32)
+        self._ck(self._lib.vp_profile_layers(self._h, iters, _ptr(ms), n))
+        return ms
+
+    def tensors(self):
+        out = []
+        for i in range(self._ck(self._lib.vp_tensor_count(self._h))):
+            name, c, h, w = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
+            self._ck(self._lib.vp_tensor_info(self._h, i, C.byref(name), C.byref(c), C.byref(h), C.byref(w)))
+            out.append((name.value.decode(), c.value, h.value, w.value))
+        return out
+
+    def tensor_read(self, i):
+        _, c, h, w = self.tensors()[i]
+        out = np.empty((c, h, w), dtype=np.float32)
+        self._ck(self._lib.vp_tensor_read(self._h, i, _ptr(out)))
+        return out
+
+
+def op_conv2d(x, weight, bias, ks=3, mode=0, act=0, res=None, res_mode=0, precision=VP_FP16, tile=-1, bk=-1, nsplit=-1, gpu_id=0):
+    """Single-operator entry for unit parity tests (vp_op_conv2d)."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    cin, h, w = x.shape
+    cout = weight.shape[1] if mode == 1 else weight.shape[0]
+    oh, ow = (2 * h, 2 * w) if mode == 1 else (h, w)
+    out = np.empty((cout, oh, ow), dtype=np.float32)
+    r = np.ascontiguousarray(res, dtype=np.float32) if res is not None else None
+    err = C.create_string_buffer(512)
+    rc = lib.vp_op_conv2d(gpu_id, precision, mode, _ptr(x), cin, h, w, _ptr(weight), _ptr(bias), cout, ks, act, res_mode,
+                          _ptr(r) if r is not None else None, tile, bk, nsplit, _ptr(out), err, len(err))
+    if rc != 0:
+        raise VpError(f"vp_op_conv2d failed ({rc}): {err.value.decode(errors='replace')}")
+    return out

@@ -1,0 +1,120 @@
+/*
+ * vp_hip.h -- C ABI of libvp_hip.so: MI355X-native (gfx950) engine for the VisionPilot per-frame hot path
+ *             preprocess -> SceneSeg / Scene3D / DomainSeg / EgoLanes forward -> argmax / threshold decode.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no exceptions cross it.
+ * Reference interfaces each entry point replaces (paths relative to the reference repo):
+ *
+ *   vp_create / vp_create_from_memory
+ *       OnnxRuntimeBackend::OnnxRuntimeBackend(model_path, precision, gpu_id)
+ *         VisionPilot/middleware_recipes/common/backends/onnx_runtime_backend.cpp:9-39
+ *       TensorRTBackend ctor            .../common/backends/tensorrt_backend.cpp:35-60
+ *       EgoLanesOnnxEngine ctor         VisionPilot/production_release/src/inference/onnxruntime_engine.cpp:13-66
+ *       SceneSegNetworkInfer.__init__   Models/inference/scene_seg_infer.py:12-36
+ *   vp_infer
+ *       InferenceBackend::doInference(const cv::Mat&)  .../common/include/inference_backend_base.hpp:19,
+ *         onnx_runtime_backend.cpp:41-82 (preprocess + Run)
+ *       EgoLanesOnnxEngine::doInference onnxruntime_engine.cpp:104-135 (+ preprocessEgoLanes :72-102)
+ *   vp_infer_tensor
+ *       XInfer.inference() after ToTensor/Normalize   Models/inference/scene_seg_infer.py:44-49
+ *   vp_logits
+ *       InferenceBackend::getRawTensorData / getTensorShape   inference_backend_base.hpp:22-23
+ *   vp_input_hw
+ *       getModelInputHeight / getModelInputWidth              inference_backend_base.hpp:25-26
+ *   vp_mask_u8 (VP_DECODE_*)
+ *       RunModelNode::onImage argmax / threshold loops  ROS2/models/src/run_model_node.cpp:144-171
+ *       MasksVisualizationKernels::createMaskFromTensor{CUDA,HIP}, createEgoLanesMaskFromTensorCUDA
+ *         common/visualizers/cuda_visualization_kernels.cu:13-75, masks_viz.hip.cpp:11-97
+ *       torch.max(dim=2)                                 Models/inference/scene_seg_infer.py:52-55
+ *   vp_mask_resized_u8 / vp_depth_resized_f32
+ *       cv::resize(mask, INTER_NEAREST) / cv::resize(depth, INTER_LINEAR)  run_model_node.cpp:104,177
+ *
+ * Threading: one engine per caller thread; an engine owns its HIP stream and every buffer it uses, there is
+ * no process-global state, so several engines may live in one process.
+ * All functions return 0 on success and a negative vp_status on failure; vp_last_error() gives the text.
+ */
+#ifndef VP_HIP_H_
+#define VP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vp_engine vp_engine;
+
+enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_WEIGHTS = -2, VP_ERR_HIP = -3, VP_ERR_STATE = -4 };
+
+enum vp_model_kind { VP_SCENESEG = 0, VP_SCENE3D = 1, VP_DOMAINSEG = 2, VP_EGOLANES = 3 };
+
+/* VP_FP16  : fp16 tensors, fp16 MFMA, fp32 accumulate (the reference's "fp16" configuration).
+ * VP_FP16X3: fp32-class accuracy on the fp16 matrix pipe: every tensor is a (hi, lo) fp16 pair and every
+ *            product is three MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate -- the parity mode (1e-3). */
+enum vp_precision { VP_FP16 = 0, VP_FP16X3 = 1 };
+
+enum vp_pixel_format { VP_BGR8 = 0, VP_RGB8 = 1 };
+/* Plane order of the network input: BGR planes = middleware "common" backends (onnx_runtime_backend.cpp:47-57),
+ * RGB planes = EgoLanes engines and the Python wrappers.  Normalisation constants follow the plane's colour. */
+enum vp_plane_order { VP_PLANES_BGR = 0, VP_PLANES_RGB = 1 };
+
+enum vp_decode_mode {
+  VP_DECODE_SEG_MASK = 0,   /* C>1: 255 where argmax==1 else 0 ; C==1: 255 where logit>0 */
+  VP_DECODE_LANE_LABEL = 1, /* {2,1,0,255} priority label */
+  VP_DECODE_CLASS_INDEX = 2 /* raw argmax index (first maximum wins) */
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+int vp_create(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, char* err, size_t err_len);
+int vp_create_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id,
+                          char* err, size_t err_len);
+void vp_destroy(vp_engine* e);
+const char* vp_last_error(const vp_engine* e);
+
+/* ---- configuration ------------------------------------------------------------------------------------- */
+int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order);
+int vp_set_decode_mode(vp_engine* e, int decode_mode);
+int vp_input_hw(const vp_engine* e, int* h, int* w);
+
+/* ---- synchronous per-frame path (host buffers in, host buffers out) -------------------------------------- */
+int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes);
+int vp_infer_tensor(vp_engine* e, const float* nchw_1x3x320x640);
+int vp_logits(const vp_engine* e, const float** data, int64_t shape[4]);       /* host pointer, valid until next infer */
+int vp_mask_u8(const vp_engine* e, const uint8_t** data, int* h, int* w);      /* host pointer, network resolution */
+int vp_mask_resized_u8(vp_engine* e, uint8_t* dst, int h, int w);              /* nearest, to frame size */
+int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w);              /* bilinear, plane 0 of the logits */
+int vp_input_tensor(vp_engine* e, float* dst_1x3x320x640);                     /* the post-resize network input */
+
+/* ---- asynchronous / device-resident path (bench, multi-GPU) ---------------------------------------------- */
+int vp_upload_frame(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes); /* H2D, frame stays in HBM */
+int vp_enqueue(vp_engine* e);                                                  /* one pass over the resident frame */
+int vp_sync(vp_engine* e);
+int vp_fetch_outputs(vp_engine* e);                                            /* D2H logits + mask, then sync */
+int vp_device_outputs(const vp_engine* e, void** logits_f32, void** mask_u8);  /* device pointers (D2D gathers) */
+int vp_use_graph(vp_engine* e, int enable);                                    /* hipGraph replay (default on) */
+int vp_timer_begin(vp_engine* e);                                              /* hipEvent on the engine stream */
+int vp_timer_end(vp_engine* e, float* elapsed_ms);                             /* records, syncs, returns elapsed */
+
+/* ---- introspection (profiling, per-layer parity tests) --------------------------------------------------- */
+int vp_layer_count(const vp_engine* e);
+int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, double* bytes);
+int vp_profile_layers(vp_engine* e, int iters, float* ms_per_layer, int capacity); /* eager, event per launch */
+int vp_tensor_count(const vp_engine* e);
+int vp_tensor_info(const vp_engine* e, int i, const char** name, int* c, int* h, int* w);
+int vp_tensor_read(vp_engine* e, int i, float* dst_chw);                       /* fp32 CHW copy of an activation */
+
+/* ---- single-operator entry (unit parity tests of the MFMA conv kernel; not used by callers) -------------- */
+/* mode 0: Conv2d k=ks stride 1 pad ks/2, weight [Cout][Cin][ks][ks]; mode 1: ConvTranspose2d k2 s2, weight
+ * [Cin][Cout][2][2].  act: 0 none 1 GELU 2 SiLU.  res_mode: 0 none 1 add 2 mul-add; res has the output shape.
+ * tile/bk/nsplit: -1 = engine heuristic.  in/res/out are fp32 CHW host buffers. */
+int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
+                 int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,
+                 char* err, size_t err_len);
+
+const char* vp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VP_HIP_H_ */

@@ -1,0 +1,83 @@
+"""Unit parity of the MFMA implicit-GEMM conv kernel (csrc/kernels_conv.hip) through the C ABI (vp_op_conv2d)
+against plain PyTorch fp32 ops on the same seeded inputs: ragged sizes, every tile shape, both K-block sizes,
+split-K, pixel-shuffle (ConvTranspose) store, fused bias/GELU/SiLU/residual epilogues, both precisions."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACT = {0: lambda t: t, 1: F.gelu, 2: F.silu}
+
+
+def _h(a):
+    """what an fp16 tensor in HBM holds"""
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _reference(x, w, b, ks, mode, act, res, res_mode, fp16):
+    if fp16:
+        x, w = _h(x), _h(w)
+        res = _h(res) if res is not None else None
+    xt, wt, bt = (torch.from_numpy(v).double() for v in (x, w, b))
+    y = F.conv_transpose2d(xt[None], wt, bt, stride=2) if mode == 1 else F.conv2d(xt[None], wt, bt, padding=ks // 2)
+    y = ACT[act](y)
+    if res_mode == 1:
+        y = y + torch.from_numpy(res).double()[None]
+    elif res_mode == 2:
+        r = torch.from_numpy(res).double()[None]
+        y = y * r + r
+    return y[0].float().numpy()
+
+
+CASES = [
+    # cin, cout, h, w, ks, mode, act, res_mode
+    (32, 64, 16, 24, 3, 0, 1, 0),
+    (40, 24, 13, 9, 3, 0, 0, 0),       # ragged channels and odd image, narrower than any tile
+    (128, 128, 32, 40, 3, 0, 1, 0),
+    (256, 96, 10, 20, 3, 0, 1, 2),     # context-like: 200 pixels, mul-add residual (scene_context.py:56)
+    (80, 160, 20, 40, 1, 0, 0, 1),     # skip-link like 1x1 with residual add
+    (96, 24, 17, 33, 1, 0, 2, 0),      # MBConv-like 1x1 + SiLU
+    (64, 48, 10, 12, 2, 1, 0, 0),      # ConvTranspose2d k2 s2 -> pixel shuffle
+    (64, 3, 24, 40, 3, 0, 0, 0),       # final-layer-like, 3 output channels
+    (3, 32, 8, 8, 3, 0, 0, 0),         # fewer input channels than one K block
+]
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+@pytest.mark.parametrize("case", CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}_k{c[4]}m{c[5]}a{c[6]}r{c[7]}" for c in CASES])
+def test_conv_op_matches_torch(case, precision):
+    from autoware_vision_pilot_amd import lib
+
+    cin, cout, h, w, ks, mode, act, res_mode = case
+    rng = np.random.default_rng(hash(case) % (2**31))
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    k = 2 if mode == 1 else ks
+    wshape = (cin, cout, 2, 2) if mode == 1 else (cout, cin, k, k)
+    wt = (rng.standard_normal(wshape, dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * (1 if mode == 1 else k * k)))))
+    b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+    oh, ow = (2 * h, 2 * w) if mode == 1 else (h, w)
+    res = rng.standard_normal((cout, oh, ow), dtype=np.float32) if res_mode else None
+    ref = _reference(x, wt, b, ks, mode, act, res, res_mode, fp16=(precision == 0))
+    tol = 1.5e-3 if precision == 0 else 2e-5  # fp16: one output rounding (2^-11) + accumulation order
+    for tile, bk, nsplit in [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 32, 3), (3, 32, 1), (0, 64, 1), (2, 64, 2)]:
+        got = lib.op_conv2d(x, wt, b, ks=ks, mode=mode, act=act, res=res, res_mode=res_mode, precision=precision, tile=tile, bk=bk,
+                            nsplit=nsplit)
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert got.shape == ref.shape
+        assert err.max() <= tol, f"tile={tile} bk={bk} nsplit={nsplit}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def test_conv_op_transpose_detecting():
+    """Identity weights with an asymmetric input: catches a swapped output-channel/pixel mapping of the MFMA result."""
+    from autoware_vision_pilot_amd import lib
+
+    cin = cout = 64
+    x = np.arange(cin * 8 * 40, dtype=np.float32).reshape(cin, 8, 40) % 97 - 48.0
+    w = np.zeros((cout, cin, 1, 1), dtype=np.float32)
+    for c in range(cout):
+        w[c, (c * 7 + 3) % cin, 0, 0] = 1.0  # a permutation, not symmetric
+    got = lib.op_conv2d(x, w, np.zeros(cout, np.float32), ks=1, precision=1)
+    ref = x[[(c * 7 + 3) % cin for c in range(cout)]]
+    assert np.array_equal(got, ref)
