@@ -224,6 +224,8 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   const double esz = sp ? 4.0 : 2.0;
   op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
                     (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
+  op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" + std::to_string(conv_tile_px(tile)) +
+              (sp ? ",x3>" : ",x1>") + (pc.nsplit > 1 ? "+splitk" : "");
   op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
   ops_.push_back(std::move(op));
 }
@@ -368,7 +370,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       // squeeze-excite -> per-frame scaled projection weights
       const int sq = std::max(1, cin / 4);
       const int HWz = z->H * z->W;
-      const int nslab = std::max(1, std::min(256, HWz / 64));
+      const int nslab = std::max(1, std::min(32, HWz / 256));
       float* partial = static_cast<float*>(dalloc((size_t)nslab * z->C * sizeof(float)));
       float* scale = static_cast<float*>(dalloc(z->C * sizeof(float)));
       {
@@ -675,6 +677,25 @@ void Engine::finish_plan() {
     op.run = [this](hipStream_t st) { return launch_decode_mask(d_logits_, out_c_, out_h_ * out_w_, decode_mode_, d_mask_, st); };
     ops_.push_back(std::move(op));
   }
+  // kernel tags of the non-GEMM launches (the conv ops set theirs in push_conv_op)
+  auto ends_with = [](const std::string& s, const char* suf) {
+    const size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+  };
+  for (Op& op : ops_) {
+    if (!op.kernel.empty()) continue;
+    const std::string& n = op.name;
+    if (n == "preprocess") op.kernel = "preprocess";
+    else if (n == "decode") op.kernel = "decode_mask";
+    else if (n == "BackboneFeatureFusion") op.kernel = "fusion";
+    else if (ends_with(n, ".avgpool") || ends_with(n, "avgpool")) op.kernel = "pool_partial";
+    else if (ends_with(n, ".fc")) op.kernel = "se_fc";
+    else if (ends_with(n, ".se_scale_w")) op.kernel = "scale_weights";
+    else if (ends_with(n, "context_layer_3")) op.kernel = "ctx_conv1";
+    else if (n.find("context_layer_") != std::string::npos) op.kernel = "fc";
+    else if (ends_with(n, "encoder.0")) op.kernel = "stem";
+    else op.kernel = "dwconv";
+  }
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
   VP_HIP_CHECK(hipDeviceSynchronize());
 }
@@ -814,6 +835,12 @@ void Engine::fetch_outputs() {
   VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
   VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::copy_outputs_device(void* logits_dst, void* mask_dst) {
+  if (logits_dst)
+    VP_HIP_CHECK(hipMemcpyAsync(logits_dst, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+  if (mask_dst) VP_HIP_CHECK(hipMemcpyAsync(mask_dst, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToDevice, stream_));
 }
 
 void Engine::read_input_tensor(float* dst) {

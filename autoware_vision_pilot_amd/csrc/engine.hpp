@@ -42,6 +42,7 @@ struct Act {
 
 struct Op {
   std::string name;
+  std::string kernel;  // kernel instantiation tag (groups launches for the roofline report)
   double flops = 0, bytes = 0;
   std::function<hipError_t(hipStream_t)> run;
 };
@@ -73,6 +74,7 @@ class Engine {
   void enqueue();
   void sync();
   void fetch_outputs();
+  void copy_outputs_device(void* logits_dst, void* mask_dst);
   void mask_resized(uint8_t* dst, int h, int w);
   void depth_resized(float* dst, int h, int w);
   void read_input_tensor(float* dst);

@@ -153,28 +153,40 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
 
 // ------------------------------------------------------------------------------------- squeeze-excite FCs
 // mean -> fc1 -> SiLU -> fc2 -> sigmoid -> scale[C]   (torchvision SqueezeExcitation; 1 workgroup).
-__global__ __launch_bounds__(256) void se_fc_kernel(const SeParams p) {
+// Latency-bound (one workgroup, ~100 KB of weights): 16 waves, 16-byte loads, independent loads unrolled so
+// they overlap instead of forming a dependent chain.
+__global__ __launch_bounds__(1024) void se_fc_kernel(const SeParams p) {
   extern __shared__ float sm[];  // mean[C] + s1[sq]
   float* mean = sm;
   float* s1 = sm + p.C;
-  for (int c = threadIdx.x; c < p.C; c += 256) {
+  for (int c = threadIdx.x; c < p.C; c += 1024) {
     float s = 0.f;
+#pragma unroll 8
     for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
     mean[c] = s * p.inv_hw;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < p.sq; j += 4) {
+  const int C4 = p.C >> 2;
+  const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(mean);
+  for (int j = wave; j < p.sq; j += 16) {
+    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)j * p.C);
     float s = 0.f;
-    for (int c = lane; c < p.C; c += 64) s = fmaf(p.w1[(size_t)j * p.C + c], mean[c], s);
+#pragma unroll 5
+    for (int c = lane; c < C4; c += 64) {
+      const f32x4_t a = wr[c], m = m4[c];
+      s += a[0] * m[0] + a[1] * m[1] + a[2] * m[2] + a[3] * m[3];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) s1[j] = silu_f(s + p.b1[j]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < p.C; c += 256) {
+  for (int c = threadIdx.x; c < p.C; c += 1024) {
     float s = p.b2[c];
-    for (int j = 0; j < p.sq; ++j) s = fmaf(p.w2[(size_t)c * p.sq + j], s1[j], s);
+    const float* wr = p.w2 + (size_t)c * p.sq;
+#pragma unroll 8
+    for (int j = 0; j < p.sq; ++j) s = fmaf(wr[j], s1[j], s);
     p.scale[c] = c < p.Creal ? sigmoid_f(s) : 0.0f;
   }
 }
@@ -310,6 +322,7 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const uint8_t* src,
 // float bilinear up-resize of the depth plane (run_model_node.cpp:100-104); taps from the host; no FMA contraction.
 __global__ __launch_bounds__(256) void resize_bilinear_f32_kernel(const float* src, int sw, const int* yi, const float* yf,
                                                                   const int* xi, const float* xf, int oh, int ow, float* dst) {
+#pragma clang fp contract(off)  // ROCm's __fmul_rn/__fadd_rn are plain * and +: keep them from fusing into v_fma
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= ow) return;
   const int x0 = xi[2 * x], x1 = xi[2 * x + 1], y0 = yi[2 * y], y1 = yi[2 * y + 1];
@@ -364,7 +377,7 @@ hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
   VP_LAUNCH(pool_partial_kernel, dim3(p.nslab), dim3(256), 0, st, p);
 }
 hipError_t launch_se_fc(const SeParams& p, hipStream_t st) {
-  VP_LAUNCH(se_fc_kernel, dim3(1), dim3(256), (p.C + p.sq) * sizeof(float), st, p);
+  VP_LAUNCH(se_fc_kernel, dim3(1), dim3(1024), (p.C + p.sq) * sizeof(float), st, p);
 }
 hipError_t launch_scale_weights(const ScaleWParams& p, hipStream_t st) {
   VP_LAUNCH(scale_weights_kernel, dim3(nblk((long long)p.rows * (p.C >> 3))), dim3(256), 0, st, p);

@@ -203,6 +203,14 @@ int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, d
   if (bytes) *bytes = op.bytes;
   return VP_OK;
 }
+int vp_layer_kernel(const vp_engine* e, int i, const char** kernel) {
+  if (!e || !e->impl || !kernel || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
+  *kernel = e->impl->ops()[i].kernel.c_str();
+  return VP_OK;
+}
+int vp_copy_outputs_device(vp_engine* e, void* logits_dst, void* mask_dst) {
+  return guarded(e, [&](vp::Engine& g) { g.copy_outputs_device(logits_dst, mask_dst); });
+}
 int vp_profile_layers(vp_engine* e, int iters, float* ms, int capacity) {
   int n = 0;
   const int rc = guarded(e, [&](vp::Engine& g) { n = g.profile_layers(iters, ms, capacity); });

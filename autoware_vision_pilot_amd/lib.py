@@ -50,6 +50,8 @@ _SIGS = {
     "vp_timer_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "vp_layer_count": (C.c_int, [_P]),
     "vp_layer_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vp_layer_kernel": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p)]),
+    "vp_copy_outputs_device": (C.c_int, [_P, _P, _P]),
     "vp_profile_layers": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "vp_tensor_count": (C.c_int, [_P]),
     "vp_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -109,11 +111,16 @@ class Engine:
         self.kind = kind
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._lib.vp_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._h = None
+            self._lib.vp_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: globals may already be gone
+            pass
 
     def _ck(self, rc):
         if rc < 0:
@@ -213,6 +220,17 @@ class Engine:
             self._ck(self._lib.vp_layer_info(self._h, i, C.byref(name), C.byref(fl), C.byref(by)))
             out.append((name.value.decode(), fl.value, by.value))
         return out
+
+    def layer_kernels(self):
+        out = []
+        for i in range(self._ck(self._lib.vp_layer_count(self._h))):
+            k = C.c_char_p()
+            self._ck(self._lib.vp_layer_kernel(self._h, i, C.byref(k)))
+            out.append(k.value.decode())
+        return out
+
+    def copy_outputs_device(self, logits_ptr=None, mask_ptr=None):
+        self._ck(self._lib.vp_copy_outputs_device(self._h, logits_ptr, mask_ptr))
 
     def profile_layers(self, iters=10):
         n = self._ck(self._lib.vp_layer_count(self._h))

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the VisionPilot per-frame hot path on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run, one rank
+per GPU).  A *step* is one pass of the hot path over one frame: integer-bilinear preprocess of a synthetic
+1280x720 BGR frame that is already resident in HBM -> SceneSeg forward (EfficientNet-B0 encoder + context +
+neck + head, 367 GFLOP) -> argmax decode, replayed as one hipGraph on the engine's own stream
+(BASELINE.json configs[1]: "SceneSeg 1280x720 batch=1 on 1 MI355X, fp16").  Random-init weights of that
+architecture, synthetic frame: data = "synthetic".
+
+Multi-GPU: the path shards by camera: rank r owns camera r, weights replicated, no data-path
+collective (the reference has none) -> "scaling": "weak".  ``--gather`` adds the optional per-frame RCCL
+all-gather of the per-camera masks (BASELINE configs[3]).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : dominant kernel family's ALGORITHMIC TFLOP/s from per-launch HIP-event timing on the engine
+                 stream vs the dense fp16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
+  cpu_baseline : the CPU oracle (torch fp32 restatement of the reference path) timed on this box's host cores
+                 on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before libvp_hip: one shared HIP runtime)
+
+PEAK_FP16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+FRAME_GFLOP = {"sceneseg": 367.0, "scene3d": 397.0, "domainseg": 366.6, "egolanes": 196.7}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--kind", default="sceneseg")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp16x3"])
+    ap.add_argument("--frame", default="1280x720")
+    ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--latency-iters", type=int, default=100)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+
+    from autoware_vision_pilot_amd import lib, weights as vw
+    from oracle import pre_post, weights  # input generator + seeded state-dict (test infrastructure, not measured)
+
+    fw, fh = (int(v) for v in args.frame.split("x"))
+    seed = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}[args.kind]
+    sd = weights.make_state_dict(args.kind, seed)
+    eng = lib.Engine(args.kind, vw.pack_state_dict(sd), precision=args.precision, gpu_id=local_rank)
+    frame = pre_post.synthetic_frame(fh, fw, 10 + rank)  # camera r
+    eng.upload_frame(frame)  # resident in HBM before the timed region
+    eng.sync()
+
+    gather_buf = mask_t = None
+    if args.gather and dist is not None:
+        mask_t = torch.empty(320 * 640 if args.kind != "egolanes" else 80 * 160, dtype=torch.uint8, device="cuda")
+        gather_buf = torch.empty(world * mask_t.numel(), dtype=torch.uint8, device="cuda")
+
+    def step():
+        eng.enqueue()
+        if gather_buf is not None:
+            eng.copy_outputs_device(None, mask_t.data_ptr())
+            eng.sync()
+            dist.all_gather_into_tensor(gather_buf, mask_t)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fps_total = world * args.steps / elapsed
+
+    # ---- per-frame latency (sync per iteration, benchmark.py:17-47 protocol), rank-local
+    lat = []
+    for _ in range(args.latency_iters):
+        t1 = time.perf_counter()
+        eng.enqueue()
+        eng.sync()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat = np.array(lat)
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: per-launch HIP events on the engine stream (eager replay)
+        ms = eng.profile_layers(10)
+        layers, kernels = eng.layers(), eng.layer_kernels()
+        fam = {}
+        for (name, fl, by), k, t in zip(layers, kernels, ms):
+            f = fam.setdefault(k, dict(ms=0.0, flops=0.0, n=0, worst=("", 0.0)))
+            f["ms"] += float(t)
+            f["flops"] += fl
+            f["n"] += 1
+            if t > f["worst"][1]:
+                f["worst"] = (name, float(t))
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        frame_tflops = FRAME_GFLOP[args.kind] * (fps_total / world) / 1e3
+        roofline = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
+            "kernel": dom, "launches_per_frame": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
+            "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
+            "slowest_layer": d["worst"][0], "slowest_layer_us": round(1e3 * d["worst"][1], 1),
+            "kernel_time_share": round(d["ms"] / float(ms.sum()), 3),
+            "whole_frame": {"achieved": round(frame_tflops, 2), "frac": round(frame_tflops / PEAK_FP16_TFLOPS, 4),
+                            "gflop_per_frame": FRAME_GFLOP[args.kind]},
+            "note": "fp16x3 issues 3 MFMAs per algorithmic product; achieved counts algorithmic FLOPs only",
+        }
+        out = {
+            "metric": "frames/sec (SceneSeg 1280x720 -> 640x320 net input, preprocess+forward+decode)",
+            "value": round(fps_total, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "fp16x3(fp32-class)", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.kind} {fw}x{fh} batch=1, one camera per GPU, {args.precision}",
+                       "frames_per_step_per_gpu": 1, "net_input": "1x3x320x640", "gather": bool(args.gather)},
+            "fps_per_gpu": round(fps_total / world, 2),
+            "p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),
+            "roofline": roofline,
+        }
+        # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import nets
+
+            nthreads = min(os.cpu_count() or 1, 32)
+            torch.set_num_threads(nthreads)
+            tsd = nets.to_torch(sd)
+            n_done, t_cpu = 0, 0.0
+            nets.forward(args.kind, tsd, torch.from_numpy(pre_post.preprocess(frame)))  # warm-up
+            while t_cpu < args.cpu_seconds and n_done < 50:
+                t1 = time.perf_counter()
+                x = torch.from_numpy(pre_post.preprocess(frame))
+                y = nets.forward(args.kind, tsd, x)[0].numpy()
+                pre_post.seg_mask_u8(y) if args.kind != "egolanes" else pre_post.egolanes_priority_mask(y)
+                t_cpu += time.perf_counter() - t1
+                n_done += 1
+            out["cpu_baseline"] = {"value": round(n_done / t_cpu, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+                                   "sample": f"{n_done} frames of the same 1280x720 workload (preprocess+forward+decode), torch "
+                                             f"{torch.__version__} CPU fp32, {t_cpu:.1f} s"}
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -92,6 +92,7 @@ int vp_enqueue(vp_engine* e);                                                  /
 int vp_sync(vp_engine* e);
 int vp_fetch_outputs(vp_engine* e);                                            /* D2H logits + mask, then sync */
 int vp_device_outputs(const vp_engine* e, void** logits_f32, void** mask_u8);  /* device pointers (D2D gathers) */
+int vp_copy_outputs_device(vp_engine* e, void* logits_dst, void* mask_dst);   /* async D2D on the engine stream */
 int vp_use_graph(vp_engine* e, int enable);                                    /* hipGraph replay (default on) */
 int vp_timer_begin(vp_engine* e);                                              /* hipEvent on the engine stream */
 int vp_timer_end(vp_engine* e, float* elapsed_ms);                             /* records, syncs, returns elapsed */
@@ -99,6 +100,7 @@ int vp_timer_end(vp_engine* e, float* elapsed_ms);                             /
 /* ---- introspection (profiling, per-layer parity tests) --------------------------------------------------- */
 int vp_layer_count(const vp_engine* e);
 int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, double* bytes);
+int vp_layer_kernel(const vp_engine* e, int i, const char** kernel_tag);        /* kernel instantiation of launch i */
 int vp_profile_layers(vp_engine* e, int iters, float* ms_per_layer, int capacity); /* eager, event per launch */
 int vp_tensor_count(const vp_engine* e);
 int vp_tensor_info(const vp_engine* e, int i, const char** name, int* c, int* h, int* w);

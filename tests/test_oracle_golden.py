@@ -1,0 +1,126 @@
+"""CPU suite, part 1: the oracle against the committed golden vectors.
+
+tests/golden/*.npz were produced by oracle/pin_against_reference.py, which executes the REFERENCE's own nn.Modules
+(context / neck / heads / feature fusion imported from /root/reference/Models/model_components) on the seeded
+state-dicts.  /root/reference does not exist on the GPU box, so here we only read the fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, pre_post, weights
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+SEEDS = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}
+KINDS = list(SEEDS)
+
+
+def _close(a, b, tol=1e-4):
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max()) <= tol
+
+
+def test_param_counts():
+    # SceneSeg 48.36 M (4.008 M backbone + 44.355 M decoder), EgoLanes 51.9 M
+    assert weights.param_count("sceneseg") == 48362503
+    assert abs(weights.param_count("egolanes") - 51.9e6) < 0.1e6
+    bb = sum(int(np.prod(s)) for _, s, k in weights.backbone_spec("x.") if k not in ("bn_mean", "bn_var"))
+    assert abs(bb - 4.008e6) < 0.01e6
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_decoder_small_against_reference_modules(kind):
+    g = np.load(os.path.join(GOLDEN, f"decoder_small_{kind}.npz"))
+    seed = int(g["weight_seed"])
+    sd = nets.to_torch(weights.make_state_dict(kind, seed))
+    rng = np.random.default_rng(10_000 + seed)
+    c = weights.context_channels(kind)
+    shapes = [(32, 32, 48), (24, 16, 24), (40, 8, 12), (80, 4, 6), (c, 2, 3)]
+    fs = [torch.from_numpy(rng.standard_normal((1,) + s, dtype=np.float32)) for s in shapes]
+    p = weights.PREFIX[kind]
+    with torch.no_grad():
+        nk = nets.neck(sd, p["neck"], fs[4], fs)
+        out = nets.head_egolanes(sd, p["head"], nk) if kind == "egolanes" else nets.head_full_res(sd, p["head"], nk, fs)
+    assert _close(nk[0, ::8].numpy(), g["neck_ds"])
+    assert _close(out[0].numpy(), g["out"])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_context_against_reference_modules(kind):
+    g = np.load(os.path.join(GOLDEN, f"context_{kind}.npz"))
+    seed = int(g["weight_seed"])
+    sd = nets.to_torch(weights.make_state_dict(kind, seed))
+    rng = np.random.default_rng(20_000 + seed)
+    f = torch.from_numpy(np.abs(rng.standard_normal((1, weights.context_channels(kind), 10, 20), dtype=np.float32)))
+    with torch.no_grad():
+        got = nets.context(sd, weights.PREFIX[kind]["context"], f)[0].numpy()
+    assert _close(got.ravel()[g["samples_idx"]], g["samples"])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_full_network_against_golden(kind):
+    g = np.load(os.path.join(GOLDEN, f"full_{kind}.npz"))
+    sd = nets.to_torch(weights.make_state_dict(kind, int(g["weight_seed"])))
+    frame = pre_post.synthetic_frame(720, 1280, int(g["frame_seed"]))
+    x = torch.from_numpy(pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=False))
+    out = nets.forward(kind, sd, x)[0].numpy()
+    assert tuple(out.shape) == tuple(g["shape"])
+    assert _close(out.ravel()[g["samples_idx"]], g["samples"], tol=2e-4)
+    if kind == "sceneseg":
+        cls = pre_post.argmax_classes(out)
+        assert np.array_equal(np.bincount(cls.ravel(), minlength=3), g["hist"]) or (cls != g["classes"]).sum() <= int(g["margin_lt_1e-3"])
+        srt = np.sort(out, axis=0)
+        flips = cls != g["classes"]
+        assert ((srt[-1] - srt[-2])[flips] < 1e-3).all()
+        assert np.array_equal(cls, torch.max(torch.from_numpy(out).permute(1, 2, 0), dim=2)[1].numpy())  # scene_seg_infer.py:54
+    elif kind == "egolanes":
+        assert (pre_post.egolanes_priority_mask(out) != g["mask"]).mean() < 1e-3
+    elif kind == "domainseg":
+        assert (np.packbits(out[0] > 0) != g["mask_packed"]).mean() < 1e-3
+    else:
+        assert _close(out[0, ::8, ::8], g["depth_ds8"], tol=2e-4)
+
+
+def test_preprocess_fixture_and_properties():
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    assert np.array_equal(pre_post.resize_bilinear_u8(g["frame"], 40, 80), g["resized"])
+    assert np.array_equal(pre_post.resize_bilinear_u8(g["frame"][:20, :30], 47, 61), g["up"])
+    # identity at scale 1, constant images stay constant, plane-order bookkeeping
+    img = pre_post.synthetic_frame(320, 640, 3, smooth=False)
+    assert np.array_equal(pre_post.resize_bilinear_u8(img), img)
+    const = np.full((100, 200, 3), 77, dtype=np.uint8)
+    assert (pre_post.resize_bilinear_u8(const) == 77).all()
+    a = pre_post.preprocess(img, input_is_bgr=True, planes_rgb=False)
+    b = pre_post.preprocess(img[..., ::-1], input_is_bgr=False, planes_rgb=True)
+    assert np.array_equal(a[0, ::-1], b[0])
+    # torchvision ToTensor+Normalize semantics (scene_seg_infer.py:15-20) on an RGB image
+    t = torch.from_numpy(img).permute(2, 0, 1).float().div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    assert np.array_equal(pre_post.preprocess(img, input_is_bgr=False, planes_rgb=True)[0], t.sub(mean).div(std).numpy())
+
+
+def test_decode_definitions():
+    rng = np.random.default_rng(0)
+    lg = rng.standard_normal((3, 17, 23), dtype=np.float32)
+    lg[:, 0, 0] = 1.5  # exact three-way tie -> class 0
+    lg[1:, 0, 1] = 9.0  # tie between 1 and 2 -> class 1
+    cls = pre_post.argmax_classes(lg)
+    assert cls[0, 0] == 0 and cls[0, 1] == 1
+    assert np.array_equal(cls, torch.max(torch.from_numpy(lg).permute(1, 2, 0), dim=2)[1].numpy())
+    m = pre_post.seg_mask_u8(lg)
+    assert set(np.unique(m)) <= {0, 255} and np.array_equal(m == 255, cls == 1)
+    one = lg[:1].copy()
+    one[0, 0, 0] = 0.0  # run_model_node.cpp:168 '> 0' is strict
+    assert pre_post.seg_mask_u8(one)[0, 0] == 0
+    lab = pre_post.egolanes_priority_mask(lg)
+    ref = np.full(lg.shape[1:], 255, np.uint8)
+    ref[lg[0] > 0] = 0
+    ref[lg[1] > 0] = 1
+    ref[lg[2] > 0] = 2
+    assert np.array_equal(lab, ref)
+    assert np.array_equal(pre_post.egolanes_planes(lg, 0.0), (lg > 0).astype(np.float32))
+    # nearest / bilinear resize: identity at scale 1, integer up-scale replicates
+    assert np.array_equal(pre_post.resize_nearest_u8(m, 17, 23), m)
+    assert np.array_equal(pre_post.resize_nearest_u8(m, 34, 46), np.repeat(np.repeat(m, 2, 0), 2, 1))
+    assert np.array_equal(pre_post.resize_bilinear_f32(lg[0], 17, 23), lg[0])
