@@ -1,0 +1,135 @@
+// Shared epilogue of the MFMA conv kernels.
+//
+// The MFMA result layout gives every lane 4 consecutive output channels of ONE pixel per register group; storing
+// that directly means 8-byte pieces scattered over 32 pixels per store instruction (measured: the memory-bound
+// upsample / skip layers ran at 0.3-0.8 TB/s).  Instead the accumulators go through LDS:
+//   phase 1 (fully unrolled, a few dozen ds_write_b128): fp32 accumulators -> stage[pixel][channel]
+//   phase 2 (compact runtime loop): each lane takes 8 consecutive channels of one pixel: bias + activation +
+//            residual in fp32, (hi, lo) split, ONE 16-byte store per plane; 8 lanes cover 128 contiguous bytes.
+// Keeping phase 2 out of the unrolled code also keeps the kernels small enough for full unrolling, which is what
+// keeps the accumulator array in registers (a partially unrolled epilogue pushed it to scratch memory).
+#pragma once
+#include "kernels.hpp"
+
+namespace vp {
+
+// bias + activation + residual + split + store for 8 consecutive output channels of pixel m.
+__device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, int m, int co, float v[8]) {
+  {
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = apply_act(v[r] + b0[r], p.act);
+      v[4 + r] = apply_act(v[4 + r] + b1[r], p.act);
+    }
+  }
+  if (p.store_mode == STORE_NCHW_F32) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (co + r < p.Creal) p.out_f32[(size_t)(co + r) * M + m] = v[r];
+    return;
+  }
+  size_t o;
+  if (p.store_mode == STORE_SHUFFLE2) {
+    const int q = co / p.Cstore, c = co - q * p.Cstore;
+    const int y = m / p.W, x = m - y * p.W;
+    o = ((size_t)(2 * y + (q >> 1)) * (2 * p.W) + (2 * x + (q & 1))) * p.Cstore + c;
+  } else {
+    o = (size_t)m * p.Cstore + co;
+  }
+  if (p.res_mode != RES_NONE) {
+    const h8_t rh = *reinterpret_cast<const h8_t*>(p.res_hi + o);
+    float r8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) r8[r] = (float)rh[r];
+    if (p.res_lo) {
+      const h8_t rl = *reinterpret_cast<const h8_t*>(p.res_lo + o);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) r8[r] += (float)rl[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (p.res_mode == RES_ADD) ? (v[r] + r8[r]) : (v[r] * r8[r] + r8[r]);
+  }
+  h8_t hi;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) hi[r] = (half_t)v[r];
+  *reinterpret_cast<h8_t*>(p.out_hi + o) = hi;
+  if (p.out_lo) {
+    h8_t lo;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lo[r] = (half_t)(v[r] - (float)hi[r]);
+    *reinterpret_cast<h8_t*>(p.out_lo + o) = lo;
+  }
+}
+
+// Pixel maps: local pixel index of the workgroup tile -> linear pixel m of the image, or -1 outside.
+struct PixLinear {
+  int m0, M;
+  __device__ __forceinline__ int operator()(int q) const {
+    const int m = m0 + q;
+    return m < M ? m : -1;
+  }
+};
+template <int TW>
+struct PixPatch {
+  int y0, x0, H, W;
+  __device__ __forceinline__ int operator()(int q) const {
+    const int y = y0 + q / TW, x = x0 + q % TW;
+    return (y < H && x < W) ? y * W + x : -1;
+  }
+};
+
+// One epilogue pass over the channel slice [co_base, co_base + 32*WCO) of a PXT-pixel workgroup tile.
+//   accs[j] : this wave's NT accumulator tiles of the pass (32 channels x 32 pixels each, MFMA C layout:
+//             lane&31 = pixel, register 4g+r = channel 8g + 4*(lane>>5) + r)
+//   wco,wpx : wave coordinates; the wave's channel sub-slice is co_base + wco*32, its pixels (wpx*NT + j)*32 + lane&31.
+// Caller guarantees all LDS reads of the main loop are done (a barrier was passed) and calls this from all 256 threads.
+template <int PXT, int WCO, int NT, class PixMap>
+__device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* stage, const f32x16_t (&accs)[NT], int co_base, int wco,
+                                              int wpx, const PixMap& pix, int M, int zsplit) {
+  constexpr int COP = 32 * WCO;           // channels per pass
+  constexpr int PITCH = COP * 4 + 16;     // bytes per staged pixel row (+16: conflict-free ds_write_b128)
+  constexpr int CPR = COP / 8;            // 8-channel pieces per row
+  constexpr int RPI = 256 / CPR;          // rows per iteration of phase 2
+  const int tid = threadIdx.x, lane = tid & 63;
+  // ---- phase 1
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    char* row = stage + ((wpx * NT + j) * 32 + (lane & 31)) * PITCH + (wco * 32 + 4 * (lane >> 5)) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4_t v = {accs[j][4 * g + 0], accs[j][4 * g + 1], accs[j][4 * g + 2], accs[j][4 * g + 3]};
+      *reinterpret_cast<f32x4_t*>(row + g * 32) = v;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2
+  const int c8 = tid % CPR;
+  const int co = co_base + c8 * 8;
+  if (co < p.Ncols) {
+    for (int r = tid / CPR; r < PXT; r += RPI) {
+      const int m = pix(r);
+      if (m < 0) continue;
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
+      if (p.nsplit > 1) {
+        float* dst = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co;
+        *reinterpret_cast<f32x4_t*>(dst) = s0;
+        *reinterpret_cast<f32x4_t*>(dst + 4) = s1;
+      } else {
+        float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        epilogue_store8(p, M, m, co, v);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <int PXT, int WCO>
+constexpr int epilogue_stage_bytes() {
+  return PXT * (32 * WCO * 4 + 16);
+}
+
+hipError_t launch_splitk_finish(const ConvGemmParams& p, hipStream_t st);  // kernels_conv.hip
+
+}  // namespace vp

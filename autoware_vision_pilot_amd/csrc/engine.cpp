@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace vp {
@@ -182,8 +183,8 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
   int ns = 1;
   if (o.nsplit > 0) {
     ns = o.nsplit;
-  } else if (blocks < 256) {
-    ns = (int)std::min<long long>(cdiv(512, blocks), std::max(1, S / 4));
+  } else if (blocks < 128 && S >= 32) {  // split-K pays only for long K loops: it costs a second (finish) launch
+    ns = (int)std::min<long long>(cdiv(384, blocks), std::max(1, S / 8));
     ns = std::max(1, std::min(ns, 32));
   }
   pc->nsplit = std::min(ns, std::max(1, S));
@@ -224,9 +225,16 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   const double esz = sp ? 4.0 : 2.0;
   op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
                     (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
-  op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" + std::to_string(conv_tile_px(tile)) +
-              (sp ? ",x3>" : ",x1>") + (pc.nsplit > 1 ? "+splitk" : "");
-  op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
+  if (tile >= 100) {
+    const int ht = tile - 100;
+    op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3>" : ",x1>") +
+                (pc.nsplit > 1 ? "+splitk" : "");
+    op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
+  } else {
+    op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
+                std::to_string(conv_tile_px(tile)) + (sp ? ",x3>" : ",x1>") + (pc.nsplit > 1 ? "+splitk" : "");
+    op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
+  }
   ops_.push_back(std::move(op));
 }
 
@@ -238,14 +246,49 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   const int M = in->H * in->W;
   const int ncols = round_up(cout, 32);
   PackedConv pc;
-  choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   const int taps = ks * ks;
+  // ---- 3x3: LDS-resident halo kernel (kernels_conv3x3.hip) unless overridden (tile >= 100 selects a halo tile)
+  int halo = -1;
+  if (ks == 3 && in->H >= 8 && in->W >= 16) {
+    static const char* env = std::getenv("VP_CONV3X3");
+    const bool force_v1 = (env && std::strcmp(env, "v1") == 0) || (o.tile >= 0 && o.tile < 100);
+    if (o.tile >= 100) {
+      halo = o.tile - 100;
+    } else if (!force_v1) {
+      auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
+      const long long t256 = cdiv(in->H, 16) * cdiv(in->W, 16), t128 = cdiv(in->H, 8) * cdiv(in->W, 16);
+      if (ncols <= 32) {
+        halo = 4;
+      } else if (ncols % 128 != 0) {
+        halo = (!split() && t256 * cdiv(ncols, 64) >= 400) ? 2 : 3;
+      } else {
+        halo = (!split() && t256 * (ncols / 128) >= 400) ? 0 : 1;
+      }
+    }
+    if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
+  }
+  if (halo >= 0) {
+    pc.tile = 100 + halo;
+    pc.bk = 32;
+    pc.CoutW = round_up(ncols, halo_tile_co(halo));
+    const int KC = cin_pad / 32;
+    const long long blocks = (long long)((in->H + halo_tile_th(halo) - 1) / halo_tile_th(halo)) * ((in->W + 15) / 16) *
+                             (pc.CoutW / halo_tile_co(halo));
+    int ns = 1;
+    if (o.nsplit > 0) ns = o.nsplit;
+    else if (blocks < 256) ns = (int)std::min<long long>((512 + blocks - 1) / blocks, std::max(1, KC / 2));
+    pc.nsplit = std::max(1, std::min(ns, KC));
+  } else {
+    choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
+  }
   std::vector<half_t> hi((size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int t = 0; t < taps; ++t) {
         const float v = w[((size_t)co * cin + ci) * taps + t];
-        const size_t d = ((size_t)t * pc.CoutW + co) * cin_pad + ci;
+        // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
+        const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + (ci & 31))
+                                   : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;
         split_half(v, &h, &l);
         hi[d] = h;
@@ -342,8 +385,19 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         y = add_conv(bp + std::to_string(j), x, f.w, f.b, cexp, 1, o);
         ++j;
       }
-      // depthwise
+      // depthwise (+ fused squeeze-excite average-pool partials: pixel slabs x channel groups, deterministic)
       Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
+      const int sq = std::max(1, cin / 4);
+      const int HWz = z->H * z->W;
+      int nslab;
+      {
+        const int CG = z->C >> 3;
+        const int CGL = CG >= 32 ? 32 : (CG >= 16 ? 16 : (CG >= 8 ? 8 : 4));
+        const int ngroups = (CG + CGL - 1) / CGL, PXL = 256 / CGL;
+        nslab = std::max(1, std::min(128, (512 + ngroups - 1) / ngroups));
+        nslab = std::min(nslab, std::max(1, HWz / (PXL * 2)));
+      }
+      float* partial = static_cast<float*>(dalloc((size_t)nslab * z->C * sizeof(float)));
       {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         const int kk = S.k * S.k;
@@ -359,6 +413,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         dp.b = dupload(bk);
         dp.k = S.k;
         dp.stride = stride;
+        dp.partial = partial;
+        dp.nslab = nslab;
         Op op;
         op.name = bp + std::to_string(j);
         op.flops = 2.0 * kk * cexp * z->H * z->W;
@@ -368,18 +424,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         ++j;
       }
       // squeeze-excite -> per-frame scaled projection weights
-      const int sq = std::max(1, cin / 4);
-      const int HWz = z->H * z->W;
-      const int nslab = std::max(1, std::min(32, HWz / 256));
-      float* partial = static_cast<float*>(dalloc((size_t)nslab * z->C * sizeof(float)));
-      float* scale = static_cast<float*>(dalloc(z->C * sizeof(float)));
+      float* s1 = static_cast<float*>(dalloc(sq * sizeof(float)));
+      SeParams se{};
       {
-        PoolParams pp{z->view(), partial, nslab};
-        Op op;
-        op.name = bp + std::to_string(j) + ".avgpool";
-        op.bytes = (split() ? 4.0 : 2.0) * z->elems();
-        op.run = [pp](hipStream_t st) { return launch_pool_partial(pp, st); };
-        ops_.push_back(std::move(op));
         const std::string sp = bp + std::to_string(j);
         const HostTensor& w1 = blob.get(sp + ".fc1.weight");
         const HostTensor& b1 = blob.get(sp + ".fc1.bias");
@@ -393,7 +440,6 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           for (int q = 0; q < sq; ++q) w2p[(size_t)c * sq + q] = w2.data[(size_t)c * sq + q];
           b2p[c] = b2.data[c];
         }
-        SeParams se{};
         se.partial = partial;
         se.nslab = nslab;
         se.C = z->C;
@@ -404,11 +450,12 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         se.b1 = dupload(b1.data);
         se.w2 = dupload(w2p);
         se.b2 = dupload(b2p);
-        se.scale = scale;
+        se.scale = nullptr;
+        se.s1 = s1;
         Op op2;
         op2.name = sp + ".fc";
-        op2.flops = 4.0 * sq * cexp;
-        op2.run = [se](hipStream_t st) { return launch_se_fc(se, st); };
+        op2.flops = 2.0 * sq * cexp;
+        op2.run = [se](hipStream_t st) { return launch_se_fc1(se, st); };
         ops_.push_back(std::move(op2));
         ++j;
       }
@@ -431,15 +478,20 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         }
         ScaleWParams sw{};
         sw.w = dupload(wf);
-        sw.scale = scale;
+        sw.scale = nullptr;
         sw.rows = pc.CoutW;
         sw.C = z->C;
+        sw.s1 = s1;
+        sw.w2 = se.w2;
+        sw.b2 = se.b2;
+        sw.sq = sq;
+        sw.Creal = cexp;
         sw.out_hi = static_cast<half_t*>(dalloc(wf.size() * sizeof(half_t)));
         sw.out_lo = split() ? static_cast<half_t*>(dalloc(wf.size() * sizeof(half_t))) : nullptr;
         Op op;
         op.name = bp + std::to_string(j) + ".se_scale_w";
         op.bytes = 6.0 * wf.size();
-        op.run = [sw](hipStream_t st) { return launch_scale_weights(sw, st); };
+        op.run = [sw](hipStream_t st) { return launch_se_scale_weights(sw, st); };
         ops_.push_back(std::move(op));
         pc.w_hi = sw.out_hi;
         pc.w_lo = sw.out_lo;
@@ -465,7 +517,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
 // scene_context.py:25-57 (== depth_context.py, auto_steer_context.py with 1456 channels)
 Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const Act* deep, int cctx) {
   const int HW = deep->H * deep->W;
-  const int nslab = 8;
+  const int nslab = 1;  // 200 pixels: one slab, the pool kernel spreads over channels
   float* partial = static_cast<float*>(dalloc((size_t)nslab * deep->C * sizeof(float)));
   {
     PoolParams pp{deep->view(), partial, nslab};

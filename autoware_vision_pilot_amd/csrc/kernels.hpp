@@ -28,6 +28,8 @@ struct DwParams {
   const float* w;  // [k*k][C]
   const float* b;  // [C]
   int k, stride;
+  float* partial;  // [nslab][C] per-slab channel sums of the OUTPUT (squeeze-excite average pool, fused)
+  int nslab;
 };
 
 struct PoolParams {
@@ -44,7 +46,8 @@ struct SeParams {
   const float* b1;  // [sq]
   const float* w2;  // [C][sq]
   const float* b2;  // [C]
-  float* scale;     // [C]
+  float* scale;     // [C]   (single-workgroup variant only)
+  float* s1;        // [sq]  output of the squeeze FC (multi-workgroup variant)
 };
 
 struct ScaleWParams {
@@ -53,6 +56,11 @@ struct ScaleWParams {
   half_t* out_hi;
   half_t* out_lo;  // may be null
   int rows, C;
+  // fused excite FC (se_scale_weights_kernel): scale[c] = sigmoid(b2[c] + w2[c][:] . s1)
+  const float* s1;
+  const float* w2;  // [C][sq]
+  const float* b2;  // [C]
+  int sq, Creal;
 };
 
 struct FcParams {
@@ -86,13 +94,19 @@ struct FusionParams {
 hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st);
 int conv_tile_co(int tile);
 int conv_tile_px(int tile);
+// 3x3 halo kernel (kernels_conv3x3.hip); weights packed [cin/32][9][CoutW][32].
+// halo tile ids: 0 = 128co x 16x16 px, 1 = 128co x 8x16, 2 = 64co x 16x16, 3 = 64co x 8x16, 4 = 32co x 8x16
+hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st);
+int halo_tile_co(int tile);
+int halo_tile_px(int tile);
+int halo_tile_th(int tile);
 
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
-hipError_t launch_se_fc(const SeParams& p, hipStream_t st);
-hipError_t launch_scale_weights(const ScaleWParams& p, hipStream_t st);
+hipError_t launch_se_fc1(const SeParams& p, hipStream_t st);
+hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st);
 hipError_t launch_fc(const FcParams& p, hipStream_t st);
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st);
 hipError_t launch_fusion(const FusionParams& p, hipStream_t st);

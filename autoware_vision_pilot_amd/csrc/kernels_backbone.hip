@@ -1,0 +1,290 @@
+// EfficientNet-B0 encoder pieces that are NOT GEMMs (torchvision efficientnet_b0().features as used by
+// Models/model_components/backbone.py:9-22) and the context MLP (scene_context.py:27-38).  All HBM / latency bound:
+// the rules that matter are 16-byte accesses along the channel axis, enough independent loads in flight per lane,
+// and as few launches as possible (every launch costs >= ~4 us of the 2 ms frame):
+//   stem            conv 3x3/s2 3->32 + BN + SiLU, fp32 planes in -> NHWC out
+//   dwconv_pool     depthwise k x k (+BN folded) + SiLU, FUSED with the squeeze-excite average pool: each
+//                   workgroup owns a pixel slab x channel group and emits its per-channel partial sums
+//                   (deterministic two-level reduction, no atomics, the tensor is not re-read)
+//   se_fc1          squeeze FC + SiLU (one wave per unit)
+//   se_scale_w      excite FC + sigmoid fused into the per-frame scaling of the projection weights
+//   pool_partial    stand-alone channel sums (context block's global average pool)
+//   fc              dense layer of the context MLP, one wave per two outputs, input vector staged in LDS
+#include "act_io.hpp"
+
+namespace vp {
+
+// -------------------------------------------------------------------------------------------------- stem
+__global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
+  __shared__ float ws[27 * 32 + 32];
+  for (int i = threadIdx.x; i < 27 * 32 + 32; i += 256) ws[i] = i < 27 * 32 ? p.w[i] : p.b[i - 27 * 32];
+  __syncthreads();
+  const int OH = p.H / 2, OW = p.W / 2;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int g = t & 3, pix = t >> 2;  // 4 threads per pixel, 8 output channels each
+  if (pix >= OH * OW) return;
+  const int oy = pix / OW, ox = pix - oy * OW;
+  float in[27];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox + kx - 1;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float v = p.in[((size_t)ci * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)];
+        in[(ci * 3 + ky) * 3 + kx] = ok ? v : 0.0f;
+      }
+    }
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = ws[27 * 32 + g * 8 + i];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float* wk = ws + k * 32 + g * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(in[k], wk[i], acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = silu_f(acc[i]);
+  store8(p.out, (size_t)pix * 32 + g * 8, acc);
+}
+
+// ------------------------------------------------------------------------- depthwise conv + SiLU + pool partials
+// Grid = (pixel slabs, channel groups); workgroup = CGL channel-octet lanes x PXL pixel lanes.  Branch-free taps
+// (clamped address + mask) so the K loads of a kernel row are in flight together.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
+  __shared__ float red[256 * 8];
+  const int CG = p.in.C >> 3;
+  const int CGL = CG >= 32 ? 32 : (CG >= 16 ? 16 : (CG >= 8 ? 8 : 4));
+  const int PXL = 256 / CGL;
+  const int cl = threadIdx.x % CGL, pl = threadIdx.x / CGL;
+  const int cg = blockIdx.y * CGL + cl;
+  const int OH = p.out.H, OW = p.out.W, HWo = OH * OW;
+  const int per = (HWo + p.nslab - 1) / p.nslab;
+  const int begin = blockIdx.x * per, end = min(begin + per, HWo);
+  constexpr int pad = (K - 1) / 2;
+  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (cg < CG) {
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8), b1 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8 + 4);
+    for (int pix = begin + pl; pix < end; pix += PXL) {
+      const int oy = pix / OW, ox = pix - oy * OW;
+      float acc[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * p.stride + ky - pad;
+        const bool yok = (unsigned)iy < (unsigned)p.in.H;
+        const int iyc = yok ? iy : 0;
+        float v[K][8];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = ox * p.stride + kx - pad;
+          const bool ok = yok && (unsigned)ix < (unsigned)p.in.W;
+          load8(p.in, ((size_t)iyc * p.in.W + (ok ? ix : 0)) * p.in.C + cg * 8, v[kx]);
+          if (!ok) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[kx][i] = 0.0f;
+          }
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float* wk = p.w + (size_t)(ky * K + kx) * p.in.C + cg * 8;
+          const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wk), w1 = *reinterpret_cast<const f32x4_t*>(wk + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { acc[i] = fmaf(v[kx][i], w0[i], acc[i]); acc[4 + i] = fmaf(v[kx][4 + i], w1[i], acc[4 + i]); }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[i] = silu_f(acc[i]);
+        sum[i] += acc[i];
+      }
+      store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = sum[i];
+  __syncthreads();
+  if (pl == 0 && cg < CG) {
+    for (int q = 1; q < PXL; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum[i] += red[(q * CGL + cl) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.partial[(size_t)blockIdx.x * p.in.C + cg * 8 + i] = sum[i];
+  }
+}
+
+// ------------------------------------------------------------------------------- stand-alone channel sums
+__global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
+  __shared__ float red[256 * 8];
+  const int CG = p.in.C >> 3;
+  const int HW = p.in.H * p.in.W;
+  const int CGL = CG >= 32 ? 32 : (CG >= 16 ? 16 : (CG >= 8 ? 8 : 4));
+  const int PXL = 256 / CGL;
+  const int cl = threadIdx.x % CGL, pl = threadIdx.x / CGL;
+  const int cg = blockIdx.y * CGL + cl;
+  const int per = (HW + p.nslab - 1) / p.nslab;
+  const int begin = blockIdx.x * per, end = min(begin + per, HW);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (cg < CG) {
+    int px = begin + pl;
+    for (; px + 3 * PXL < end; px += 4 * PXL) {
+      float v0[8], v1[8], v2[8], v3[8];
+      load8(p.in, (size_t)px * p.in.C + cg * 8, v0);
+      load8(p.in, (size_t)(px + PXL) * p.in.C + cg * 8, v1);
+      load8(p.in, (size_t)(px + 2 * PXL) * p.in.C + cg * 8, v2);
+      load8(p.in, (size_t)(px + 3 * PXL) * p.in.C + cg * 8, v3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+    }
+    for (; px < end; px += PXL) {
+      float v[8];
+      load8(p.in, (size_t)px * p.in.C + cg * 8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += v[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+  __syncthreads();
+  if (pl == 0 && cg < CG) {
+    for (int q = 1; q < PXL; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += red[(q * CGL + cl) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.partial[(size_t)blockIdx.x * p.in.C + cg * 8 + i] = acc[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------- squeeze-excite FCs
+// Squeeze FC: the workgroup rebuilds the channel means from the slab partials into LDS once, then one wave per
+// squeeze unit does a 16-byte-wide dot product (all loads of a row in flight).
+__global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
+  extern __shared__ __attribute__((aligned(16))) float mean[];
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
+    mean[c] = s * p.inv_hw;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= p.sq) return;
+  const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)j * p.C);
+  const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(mean);
+  const int C4 = p.C >> 2;
+  float s = 0.f;
+#pragma unroll 6
+  for (int c = lane; c < C4; c += 64) {
+    const f32x4_t a = wr[c], m = m4[c];
+    s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) p.s1[j] = silu_f(s + p.b1[j]);
+}
+
+// Excite FC fused into the per-frame projection-weight scaling: batch is 1, so the SE channel gate commutes into
+// the K axis of the following 1x1 projection (W'[n][k] = W[n][k] * gate[k]) and the activation tensor is never
+// re-written.  A workgroup owns 32 input channels: computes their sigmoid gates once, then scales that 32-wide
+// column slice of every weight row.
+__global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams p) {
+  __shared__ float gate[32];
+  const int c0 = blockIdx.x * 32;
+  if (threadIdx.x < 32) {
+    const int c = c0 + threadIdx.x;
+    float s = p.b2[c];
+    const float* wr = p.w2 + (size_t)c * p.sq;
+#pragma unroll 8
+    for (int j = 0; j < p.sq; ++j) s = fmaf(wr[j], p.s1[j], s);
+    gate[threadIdx.x] = c < p.Creal ? sigmoid_f(s) : 0.0f;
+  }
+  __syncthreads();
+  const int oct = threadIdx.x & 3;
+  float g[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g[i] = gate[oct * 8 + i];
+  for (int row = threadIdx.x >> 2; row < p.rows; row += 64) {
+    const size_t off = (size_t)row * p.C + c0 + oct * 8;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p.w + off), b = *reinterpret_cast<const f32x4_t*>(p.w + off + 4);
+    h8_t h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = (i < 4 ? a[i] : b[i - 4]) * g[i];
+      h[i] = (half_t)v;
+      l[i] = (half_t)(v - (float)h[i]);
+    }
+    *reinterpret_cast<h8_t*>(p.out_hi + off) = h;
+    if (p.out_lo) *reinterpret_cast<h8_t*>(p.out_lo + off) = l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ context MLP
+// out[n] = act(b[n] + sum_k W[n][k] x[k]) (scene_context.py:28-38).  x (optionally the average pool rebuilt from
+// slab partials, scene_context.py:27) is staged in LDS once per workgroup; each wave produces two outputs.
+__global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  for (int k = threadIdx.x; k < p.K; k += 256) {
+    float xv;
+    if (p.partial) {
+      xv = 0.f;
+      for (int q = 0; q < p.nslab; ++q) xv += p.partial[(size_t)q * p.Kstride + k];
+      xv *= p.inv_hw;
+    } else {
+      xv = p.x[k];
+    }
+    xs[k] = xv;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(xs);
+  const int K4 = p.K >> 2;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int n = blockIdx.x * 8 + wave * 2 + r;
+    if (n >= p.N) continue;
+    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w + (size_t)n * p.K);
+    float s = 0.f;
+#pragma unroll 6
+    for (int k = lane; k < K4; k += 64) {
+      const f32x4_t a = wr[k], m = x4[k];
+      s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) p.out[n] = apply_act(s + p.b[n], p.act);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_stem(const StemParams& p, hipStream_t st) {
+  VP_LAUNCH(stem_kernel, dim3(nblk((long long)(p.H / 2) * (p.W / 2) * 4)), dim3(256), 0, st, p);
+}
+hipError_t launch_dwconv(const DwParams& p, hipStream_t st) {
+  const int CG = p.in.C >> 3, CGL = slab_cgl(p.in.C);
+  const dim3 grid(p.nslab, (CG + CGL - 1) / CGL);
+  if (p.k == 3) VP_LAUNCH(dwconv_pool_kernel<3>, grid, dim3(256), 0, st, p);
+  if (p.k == 5) VP_LAUNCH(dwconv_pool_kernel<5>, grid, dim3(256), 0, st, p);
+  return hipErrorInvalidValue;
+}
+hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
+  const int CG = p.in.C >> 3, CGL = slab_cgl(p.in.C);
+  VP_LAUNCH(pool_partial_kernel, dim3(p.nslab, (CG + CGL - 1) / CGL), dim3(256), 0, st, p);
+}
+hipError_t launch_se_fc1(const SeParams& p, hipStream_t st) {
+  VP_LAUNCH(se_fc1_kernel, dim3((p.sq + 3) / 4), dim3(256), p.C * sizeof(float), st, p);
+}
+hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st) {
+  VP_LAUNCH(se_scale_weights_kernel, dim3(p.C / 32), dim3(256), 0, st, p);
+}
+hipError_t launch_fc(const FcParams& p, hipStream_t st) {
+  VP_LAUNCH(fc_kernel, dim3((p.N + 7) / 8), dim3(256), p.K * sizeof(float), st, p);
+}
+
+}  // namespace vp

@@ -17,51 +17,10 @@
 // Pipeline: register-staged global->LDS double buffer, one barrier per K step; LDS rows padded by 16 B
 // (80 B / 144 B row pitch: conflict-free for ds_read_b128's 16-lane groups).
 // fp16x3 mode (SPLIT): both operands carry a hi and a lo fp16 plane; three MFMAs per tile pair.
-#include "kernels.hpp"
+#include "conv_epilogue.hpp"
 
 namespace vp {
 
-__device__ __forceinline__ void epilogue_store4(const ConvGemmParams& p, int M, int m, int co, float v[4]) {
-  const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + co);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r] + b[r], p.act);
-
-  if (p.store_mode == STORE_NCHW_F32) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (co + r < p.Creal) p.out_f32[(size_t)(co + r) * M + m] = v[r];
-    return;
-  }
-  size_t o;
-  if (p.store_mode == STORE_SHUFFLE2) {
-    const int q = co / p.Cstore, c = co - q * p.Cstore;
-    const int y = m / p.W, x = m - y * p.W;
-    o = ((size_t)(2 * y + (q >> 1)) * (2 * p.W) + (2 * x + (q & 1))) * p.Cstore + c;
-  } else {
-    o = (size_t)m * p.Cstore + co;
-  }
-  if (p.res_mode != RES_NONE) {
-    const h4_t rh = *reinterpret_cast<const h4_t*>(p.res_hi + o);
-    float r4[4] = {(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
-    if (p.res_lo) {
-      const h4_t rl = *reinterpret_cast<const h4_t*>(p.res_lo + o);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) r4[r] += (float)rl[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (p.res_mode == RES_ADD) ? (v[r] + r4[r]) : (v[r] * r4[r] + r4[r]);
-  }
-  h4_t hi;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) hi[r] = (half_t)v[r];
-  *reinterpret_cast<h4_t*>(p.out_hi + o) = hi;
-  if (p.out_lo) {
-    h4_t lo;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lo[r] = (half_t)(v[r] - (float)hi[r]);
-    *reinterpret_cast<h4_t*>(p.out_lo + o) = lo;
-  }
-}
 
 template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
@@ -109,10 +68,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     b_lds[i] = row * ROWB + ch * 16;
   }
 
-  uint4 ra_hi[A_ITERS], rb_hi[B_ITERS], ra_lo[SPLIT ? A_ITERS : 1], rb_lo[SPLIT ? B_ITERS : 1];
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  // staging registers: native vector type + unconditional (clamped) loads, so they stay in VGPRs (conditional
+  // definitions carried around the K loop sent them to scratch)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 ra_hi[A_ITERS], rb_hi[B_ITERS], ra_lo[SPLIT ? A_ITERS : 1], rb_lo[SPLIT ? B_ITERS : 1];
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    ra_hi[i] = zero4;
+    if (i < (SPLIT ? A_ITERS : 1)) ra_lo[i] = zero4;
+  }
 
-  auto load_regs = [&](int s) {
+  auto load_regs = [&](int s) __attribute__((always_inline)) {
     const int tap = s / KC;
     const int c0 = (s - tap * KC) * BK;
     const int ky = tap / p.ks;
@@ -121,33 +88,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) {
-        ra_hi[i] = *reinterpret_cast<const uint4*>(p.w_hi + wbase + a_off[i]);
-        if constexpr (SPLIT) ra_lo[i] = *reinterpret_cast<const uint4*>(p.w_lo + wbase + a_off[i]);
+        ra_hi[i] = *reinterpret_cast<const u32x4*>(p.w_hi + wbase + a_off[i]);
+        if constexpr (SPLIT) ra_lo[i] = *reinterpret_cast<const u32x4*>(p.w_lo + wbase + a_off[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       const int yy = b_y[i] + dy, xx = b_x[i] + dx;
       const bool ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
-      const size_t g = ((size_t)yy * p.W + xx) * p.Cin + c0 + b_ch[i];
-      rb_hi[i] = ok ? *reinterpret_cast<const uint4*>(p.in_hi + g) : zero4;
-      if constexpr (SPLIT) rb_lo[i] = ok ? *reinterpret_cast<const uint4*>(p.in_lo + g) : zero4;
+      const size_t g = ok ? ((size_t)yy * p.W + xx) * p.Cin + c0 + b_ch[i] : 0;  // offset 0 is always valid
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(p.in_hi + g);
+      rb_hi[i] = ok ? vh : zero4;
+      if constexpr (SPLIT) {
+        const u32x4 vl = *reinterpret_cast<const u32x4*>(p.in_lo + g);
+        rb_lo[i] = ok ? vl : zero4;
+      }
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf) __attribute__((always_inline)) {
     char* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) {
-        *reinterpret_cast<uint4*>(st + OFF_AHI + a_lds[i]) = ra_hi[i];
-        if constexpr (SPLIT) *reinterpret_cast<uint4*>(st + OFF_ALO + a_lds[i]) = ra_lo[i];
+        *reinterpret_cast<u32x4*>(st + OFF_AHI + a_lds[i]) = ra_hi[i];
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st + OFF_ALO + a_lds[i]) = ra_lo[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       if (B_CHUNKS % 256 == 0 || tid + 256 * i < B_CHUNKS) {
-        *reinterpret_cast<uint4*>(st + OFF_BHI + b_lds[i]) = rb_hi[i];
-        if constexpr (SPLIT) *reinterpret_cast<uint4*>(st + OFF_BLO + b_lds[i]) = rb_lo[i];
+        *reinterpret_cast<u32x4*>(st + OFF_BHI + b_lds[i]) = rb_hi[i];
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st + OFF_BLO + b_lds[i]) = rb_lo[i];
       }
     }
   };
@@ -161,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
-  const int a_frag = OFF_AHI + (wco * MT * 32) * ROWB + frag_off;
+  const int a_frag = OFF_AHI + (wco * 32) * ROWB + frag_off;  // wave owns channel tiles i*WCO + wco (contiguous per epilogue pass)
   const int b_frag = OFF_BHI + (wpx * NT * 32) * ROWB + frag_off;
 
   if (s_begin < s_end) {
@@ -171,15 +142,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   __syncthreads();
   for (int s = s_begin; s < s_end; ++s) {
     const int buf = (s - s_begin) & 1;
-    if (s + 1 < s_end) load_regs(s + 1);
+    load_regs(s + 1 < s_end ? s + 1 : s);  // unconditional: see staging-register note above
     const char* st = smem + buf * STAGE;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       h8_t a[MT], b[NT], alo[SPLIT ? MT : 1], blo[SPLIT ? NT : 1];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        a[i] = *reinterpret_cast<const h8_t*>(st + a_frag + i * 32 * ROWB + kk * 32);
-        if constexpr (SPLIT) alo[i] = *reinterpret_cast<const h8_t*>(st + (OFF_ALO - OFF_AHI) + a_frag + i * 32 * ROWB + kk * 32);
+        a[i] = *reinterpret_cast<const h8_t*>(st + a_frag + i * WCO * 32 * ROWB + kk * 32);
+        if constexpr (SPLIT) alo[i] = *reinterpret_cast<const h8_t*>(st + (OFF_ALO - OFF_AHI) + a_frag + i * WCO * 32 * ROWB + kk * 32);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -201,49 +172,44 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds pixel (lane&31), registers hold 4 groups of 4 consecutive output channels
+  // ---- epilogue through LDS (conv_epilogue.hpp); the main loop's last barrier has retired every LDS read
+  const PixLinear pix{m0, M};
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int m = m0 + (wpx * NT + j) * 32 + (lane & 31);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = co0 + (wco * MT + i) * 32 + 8 * g + 4 * (lane >> 5);
-        if (m < M && co < p.Ncols) {
-          float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (p.nsplit > 1) {
-            f32x4_t o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4_t*>(p.partial + ((size_t)blockIdx.z * M + m) * p.CoutW + co) = o;
-          } else {
-            epilogue_store4(p, M, m, co, v);
-          }
-        }
-      }
-    }
+  for (int i = 0; i < MT; ++i) epilogue_pass<PX_TILE, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, blockIdx.z);
 }
 
 // Sums the split-K partial slabs in a fixed order (deterministic) and runs the shared epilogue.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams p) {
   const int M = p.H * p.W;
-  const int groups = p.Ncols >> 2;
+  const int groups = p.Ncols >> 3;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long)M * groups) return;
-  const int m = (int)(t / groups), co = (int)(t % groups) * 4;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const int m = (int)(t / groups), co = (int)(t % groups) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int z = 0; z < p.nsplit; ++z) {
-    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(p.partial + ((size_t)z * M + m) * p.CoutW + co);
+    const float* src = p.partial + ((size_t)z * M + m) * p.CoutW + co;
+    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(src), q1 = *reinterpret_cast<const f32x4_t*>(src + 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += q[r];
+    for (int r = 0; r < 4; ++r) {
+      v[r] += q0[r];
+      v[4 + r] += q1[r];
+    }
   }
-  epilogue_store4(p, M, m, co, v);
+  epilogue_store8(p, M, m, co, v);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+hipError_t launch_splitk_finish(const ConvGemmParams& p, hipStream_t st) {
+  const long long n = (long long)p.H * p.W * (p.Ncols >> 3);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
 template <int BK, int CO, int PX, int WCO, int WPX, bool SPLIT>
 static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int ROWB = BK * 2 + 16;
-  constexpr int lds = 2 * (CO + PX) * ROWB * (SPLIT ? 2 : 1);
+  constexpr int lds_main = 2 * (CO + PX) * ROWB * (SPLIT ? 2 : 1);
+  constexpr int lds = lds_main > epilogue_stage_bytes<PX, WCO>() ? lds_main : epilogue_stage_bytes<PX, WCO>();
   auto k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -256,11 +222,7 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (p.nsplit > 1) {
-    const long long n = (long long)M * (p.Ncols >> 2);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
-    e = hipGetLastError();
-  }
+  if (p.nsplit > 1) e = launch_splitk_finish(p, st);
   return e;
 }
 

@@ -1,0 +1,237 @@
+// 3x3 / stride 1 / pad 1 convolution, second generation: input halo tile resident in LDS.
+//
+// The decoder's 3x3 convs are ~96 % of the frame's FLOPs.  The generic implicit-GEMM kernel
+// (kernels_conv.hip) re-stages the pixel operand from global memory for every tap, which makes it L1/LDS-write
+// bound (~160 TFLOP/s measured, profiles/r01_*).  Here a workgroup owns a TH x TW patch of output pixels and a
+// CO_TILE slice of output channels and, per 32-channel input chunk,
+//   * stages the (TH+2) x (TW+2) x 32 input halo ONCE into LDS and reuses it for all 9 taps: the MFMA pixel
+//     operand of tap (ky,kx) is the same LDS image read at a shifted per-lane address (im2col never exists);
+//   * streams one [CO_TILE][32] weight tile per tap from a tap-major repacked weight tensor
+//     [cin/32][9][CoutW][32], so every tile is one contiguous, fully coalesced 2-8 KiB block;
+//   * overlaps the next tap's weight tile and one sixth of the next chunk's halo (global -> registers) with the
+//     current tap's MFMAs, writes them to the other LDS buffers afterwards: one barrier per tap.
+// Global->LDS traffic per FLOP drops ~6x vs the generic kernel; LDS rows keep the 80-byte pitch
+// (conflict-free ds_read_b128).  Result layout, epilogue and split-K protocol are shared with kernels_conv.hip.
+#include <type_traits>
+
+#include "conv_epilogue.hpp"
+
+namespace vp {
+
+template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams p) {
+  static_assert(WCO * WPX == 4, "4 waves");
+  constexpr int ROWB = 80, CH = 4;  // 32 channels = 64 B + 16 B pad
+  constexpr int PX = TH * TW, HWD = TW + 2, HHT = TH + 2, HPX = HHT * HWD;
+  constexpr int HCHUNKS = HPX * CH, HP = (HCHUNKS + 255) / 256;
+  static_assert(HP <= 9, "halo must be loadable in 9 tap steps");
+  constexpr int WCHUNKS = CO_TILE * CH, WP = (WCHUNKS + 255) / 256;
+  constexpr int MT = CO_TILE / WCO / 32, NT = PX / WPX / 32;
+  static_assert(MT >= 1 && NT >= 1, "wave tile");
+  constexpr int NPL = SPLIT ? 2 : 1;
+  constexpr int HALO_BYTES = HPX * ROWB, W_BYTES = CO_TILE * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo_base = smem;                             // [2][NPL][HALO_BYTES]
+  char* const w_base = smem + 2 * NPL * HALO_BYTES;         // [2][NPL][W_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave / WPX, wpx = wave % WPX;
+  const int tiles_x = (p.W + TW - 1) / TW;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int y0 = tyi * TH, x0 = txi * TW;
+  const int co0 = blockIdx.y * CO_TILE;
+  const int KC = p.Cin >> 5;
+  const int c_begin = (int)(((long long)KC * blockIdx.z) / p.nsplit);
+  const int c_end = (int)(((long long)KC * (blockIdx.z + 1)) / p.nsplit);
+  const int M = p.H * p.W;
+
+  // ---- staging assignment (compile-time indexed after unrolling)
+  int h_goff[HP], h_lds[HP];
+#pragma unroll
+  for (int pc = 0; pc < HP; ++pc) {
+    const int hidx = tid + 256 * pc;
+    const int hp = hidx >> 2, ch = hidx & 3;
+    const int hy = hp / HWD, hx = hp - hy * HWD;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool in_tile = hidx < HCHUNKS;
+    const bool ok = in_tile && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    h_goff[pc] = ok ? (gy * p.W + gx) * p.Cin + ch * 8 : -1;
+    h_lds[pc] = in_tile ? hp * ROWB + ch * 16 : -1;
+  }
+  int w_goff[WP], w_lds[WP];
+#pragma unroll
+  for (int pc = 0; pc < WP; ++pc) {
+    const int idx = tid + 256 * pc;
+    const int row = idx >> 2, ch = idx & 3;
+    const bool ok = idx < WCHUNKS;
+    w_goff[pc] = ok ? (co0 + row) * 32 + ch * 8 : -1;
+    w_lds[pc] = row * ROWB + ch * 16;
+  }
+  const size_t w_step = (size_t)p.CoutW * 32;  // elements per (chunk, tap) weight tile row-set
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // ---- fragment addressing
+  int b_ofs[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int q = (wpx * NT + j) * 32 + (lane & 31);
+    b_ofs[j] = ((q / TW) * HWD + (q % TW)) * ROWB + (lane >> 5) * 16;
+  }
+  const int a_ofs = (wco * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;  // wave owns channel tiles i*WCO + wco
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // Staging registers.  Everything below is written with macros over compile-time tap / piece indices instead of
+  // lambdas: closures capturing the accumulators by reference kept them in scratch memory (640 B/lane).
+  u32x4 rw_hi[WP], rw_lo[SPLIT ? WP : 1], rh_hi = zero4, rh_lo = zero4;
+#pragma unroll
+  for (int pc = 0; pc < WP; ++pc) {
+    rw_hi[pc] = zero4;
+    if (pc < (SPLIT ? WP : 1)) rw_lo[pc] = zero4;
+  }
+
+#define VP_LOAD_W(SIDX)                                                                               \
+  {                                                                                                   \
+    const size_t base_ = (size_t)(SIDX) * w_step;                                                     \
+    _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
+      rw_hi[pc] = *reinterpret_cast<const u32x4*>(p.w_hi + base_ + w_goff[pc]);                       \
+      if constexpr (SPLIT) rw_lo[pc] = *reinterpret_cast<const u32x4*>(p.w_lo + base_ + w_goff[pc]);  \
+    }                                                                                                 \
+  }
+#define VP_STORE_W(BUF)                                                                               \
+  {                                                                                                   \
+    char* dst_ = w_base + (BUF) * NPL * W_BYTES;                                                      \
+    _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
+      *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = rw_hi[pc];                                        \
+      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = rw_lo[pc];         \
+    }                                                                                                 \
+  }
+  // out-of-image halo pixels: load from offset 0 (always valid) and zero the value, so the access stays a plain
+  // global_load (a pointer select turned it into flat_load)
+#define VP_LOAD_H(PC, C)                                                                              \
+  {                                                                                                   \
+    const int g_ = h_goff[PC];                                                                        \
+    const int o_ = (g_ >= 0 ? g_ : 0) + (C) * 32;                                                     \
+    u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in_hi + o_);                                         \
+    rh_hi = g_ >= 0 ? v_ : zero4;                                                                     \
+    if constexpr (SPLIT) {                                                                            \
+      u32x4 l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                                       \
+      rh_lo = g_ >= 0 ? l_ : zero4;                                                                   \
+    }                                                                                                 \
+  }
+#define VP_STORE_H(PC, BUF)                                                                           \
+  if (h_lds[PC] >= 0) {                                                                               \
+    char* dst_ = halo_base + (BUF) * NPL * HALO_BYTES;                                                \
+    *reinterpret_cast<u32x4*>(dst_ + h_lds[PC]) = rh_hi;                                              \
+    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + HALO_BYTES + h_lds[PC]) = rh_lo;            \
+  }
+#define VP_TAP(T)                                                                                     \
+  {                                                                                                   \
+    const bool more_ = next_chunk || ((T) < 8);                                                       \
+    /* next tile (c,T+1) or (c+1,0): chunk-major, tap-minor storage; loads are unconditional (clamped) so */ \
+    /* the staging registers have a single definition per step and never fall back to scratch            */ \
+    VP_LOAD_W(c * 9 + (T) + (more_ ? 1 : 0))                                                          \
+    if constexpr ((T) < HP) VP_LOAD_H((T) < HP ? (T) : 0, next_chunk ? c + 1 : c)                     \
+    constexpr int tap_ofs_ = (((T) / 3) * HWD + ((T) % 3)) * ROWB;                                    \
+    const char* wbuf_ = w_base + wb * NPL * W_BYTES;                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
+      h8_t a_[MT], b_[NT], alo_[SPLIT ? MT : 1], blo_[SPLIT ? NT : 1];                                \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                \
+        a_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + a_ofs + i * WCO * 32 * ROWB + kk * 32);              \
+        if constexpr (SPLIT) alo_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + W_BYTES + a_ofs + i * WCO * 32 * ROWB + kk * 32); \
+      }                                                                                               \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
+        b_[j] = *reinterpret_cast<const h8_t*>(hbuf + b_ofs[j] + tap_ofs_ + kk * 32);                 \
+        if constexpr (SPLIT) blo_[j] = *reinterpret_cast<const h8_t*>(hbuf + HALO_BYTES + b_ofs[j] + tap_ofs_ + kk * 32); \
+      }                                                                                               \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) { \
+        if constexpr (SPLIT) {                                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo_[i], b_[j], acc[i][j], 0, 0, 0);     \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i], blo_[j], acc[i][j], 0, 0, 0);     \
+        }                                                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i], b_[j], acc[i][j], 0, 0, 0);         \
+      }                                                                                               \
+    }                                                                                                 \
+    if (more_) VP_STORE_W(wb ^ 1)                                                                     \
+    if constexpr ((T) < HP) {                                                                         \
+      if (next_chunk) VP_STORE_H((T) < HP ? (T) : 0, hb ^ 1)                                          \
+    }                                                                                                 \
+    __syncthreads();                                                                                  \
+    wb ^= 1;                                                                                          \
+  }
+
+  // ---- prologue: halo(c_begin) and weights(c_begin, tap 0)
+  if (c_begin < c_end) {
+#pragma unroll
+    for (int pc = 0; pc < HP; ++pc) {
+      VP_LOAD_H(pc, c_begin)
+      VP_STORE_H(pc, 0)
+    }
+    VP_LOAD_W(c_begin * 9)
+    VP_STORE_W(0)
+  }
+  __syncthreads();
+
+  int hb = 0, wb = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    const bool next_chunk = (c + 1 < c_end);
+    const char* hbuf = halo_base + hb * NPL * HALO_BYTES;
+    VP_TAP(0) VP_TAP(1) VP_TAP(2) VP_TAP(3) VP_TAP(4) VP_TAP(5) VP_TAP(6) VP_TAP(7) VP_TAP(8)
+    hb ^= 1;
+  }
+#undef VP_TAP
+#undef VP_STORE_H
+#undef VP_LOAD_H
+#undef VP_STORE_W
+#undef VP_LOAD_W
+
+  // ---- epilogue through LDS (conv_epilogue.hpp): accumulators -> stage[pixel][channel] -> coalesced 16-byte stores
+  const PixPatch<TW> pix{y0, x0, p.H, p.W};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) epilogue_pass<PX, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, blockIdx.z);
+}
+
+template <int CO, int TH, int TW, int WCO, int WPX, bool SPLIT>
+static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds_main = 2 * (SPLIT ? 2 : 1) * ((TH + 2) * (TW + 2) + CO) * 80;
+  constexpr int lds = lds_main > epilogue_stage_bytes<TH * TW, WCO>() ? lds_main : epilogue_stage_bytes<TH * TW, WCO>();
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.CoutW / CO, p.nsplit);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (p.nsplit > 1) e = launch_splitk_finish(p, st);
+  return e;
+}
+
+// halo tile ids: 0 = 128co x (16x16)px, 1 = 128co x (8x16)px, 2 = 64co x (16x16)px, 3 = 64co x (8x16)px, 4 = 32co x (8x16)px
+hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st) {
+#define VP_HCASE(T, CO, TH, TW, WCO, WPX) \
+  if (tile == T) return split ? launch_halo_cfg<CO, TH, TW, WCO, WPX, true>(p, st) : launch_halo_cfg<CO, TH, TW, WCO, WPX, false>(p, st);
+  VP_HCASE(1, 128, 8, 16, 2, 2)
+  VP_HCASE(3, 64, 8, 16, 2, 2)
+  VP_HCASE(4, 32, 8, 16, 1, 4)
+#undef VP_HCASE
+  if (tile == 0) return split ? hipErrorInvalidValue : launch_halo_cfg<128, 16, 16, 2, 2, false>(p, st);
+  if (tile == 2) return split ? hipErrorInvalidValue : launch_halo_cfg<64, 16, 16, 2, 2, false>(p, st);
+  return hipErrorInvalidValue;
+}
+int halo_tile_co(int tile) { return tile <= 1 ? 128 : (tile <= 3 ? 64 : 32); }
+int halo_tile_px(int tile) { return (tile == 0 || tile == 2) ? 256 : 128; }
+int halo_tile_th(int tile) { return (tile == 0 || tile == 2) ? 16 : 8; }
+
+}  // namespace vp

@@ -61,7 +61,10 @@ def test_conv_op_matches_torch(case, precision):
     res = rng.standard_normal((cout, oh, ow), dtype=np.float32) if res_mode else None
     ref = _reference(x, wt, b, ks, mode, act, res, res_mode, fp16=(precision == 0))
     tol = 1.5e-3 if precision == 0 else 2e-5  # fp16: one output rounding (2^-11) + accumulation order
-    for tile, bk, nsplit in [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 32, 3), (3, 32, 1), (0, 64, 1), (2, 64, 2)]:
+    cfgs = [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 32, 3), (3, 32, 1), (0, 64, 1), (2, 64, 2)]
+    if ks == 3 and mode == 0 and h >= 8 and w >= 16:  # LDS-halo 3x3 kernel tiles (kernels_conv3x3.hip)
+        cfgs += [(100, -1, 1), (101, -1, 2), (102, -1, 1), (103, -1, 3), (104, -1, 1)]
+    for tile, bk, nsplit in cfgs:
         got = lib.op_conv2d(x, wt, b, ks=ks, mode=mode, act=act, res=res, res_mode=res_mode, precision=precision, tile=tile, bk=bk,
                             nsplit=nsplit)
         err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
