@@ -1,0 +1,126 @@
+// HipBackend -- drop-in for autoware_pov::vision::InferenceBackend
+// (VisionPilot/middleware_recipes/common/include/inference_backend_base.hpp:14-27), built on the C ABI of
+// libvp_hip.so (include/vp_hip.h).  Same construction / call / error conventions as OnnxRuntimeBackend
+// (common/backends/onnx_runtime_backend.cpp:9-101) and TensorRTBackend (tensorrt_backend.cpp:35-217):
+//   * ctor(model_path, precision, gpu_id) throws std::runtime_error / std::invalid_argument on failure;
+//   * doInference(const cv::Mat& bgr8) returns false after logging on a runtime failure;
+//   * getRawTensorData() returns HOST fp32 NCHW logits owned by the backend, valid until the next doInference;
+//     getters throw std::runtime_error before the first inference (onnx_runtime_backend.cpp:86-91);
+//   * one instance per node / thread, not re-entrant, no global state.
+// `model_path` is a VPW1 weight blob (autoware_vision_pilot_amd/weights.py export_checkpoint converts the reference
+// .pth).  precision: "fp16" (fast) or "fp32" (fp16x3 parity mode).  Header-only; include it from the node exactly
+// where onnx_runtime_backend.hpp is included.
+#ifndef HIP_BACKEND_HPP_
+#define HIP_BACKEND_HPP_
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "inference_backend_base.hpp"  // the reference's abstract base
+#include "vp_hip.h"
+
+#ifndef LOG_ERROR
+#include <cstdio>
+#define VP_ADAPTER_LOG_ERROR(...) (std::fprintf(stderr, __VA_ARGS__), std::fprintf(stderr, "\n"))
+#else
+#define VP_ADAPTER_LOG_ERROR(...) LOG_ERROR(__VA_ARGS__)
+#endif
+
+namespace autoware_pov::vision
+{
+
+class HipBackend : public InferenceBackend
+{
+public:
+  // model_type: "segmentation" (SceneSeg), "depth" (Scene3D), "domain" (DomainSeg), "egolanes" -- the node's
+  // `model_type` parameter (run_model_node.cpp:35) selects the network the same way it selects the post-process.
+  HipBackend(const std::string & model_path, const std::string & precision, int gpu_id,
+             const std::string & model_type = "segmentation")
+  {
+    int kind;
+    if (model_type == "segmentation") kind = VP_SCENESEG;
+    else if (model_type == "depth") kind = VP_SCENE3D;
+    else if (model_type == "domain") kind = VP_DOMAINSEG;
+    else if (model_type == "egolanes") kind = VP_EGOLANES;
+    else throw std::invalid_argument("HipBackend: unknown model_type '" + model_type + "'");
+    int prec;
+    if (precision == "fp16") prec = VP_FP16;
+    else if (precision == "fp32" || precision == "fp16x3") prec = VP_FP16X3;
+    else throw std::invalid_argument("HipBackend: precision must be fp16 or fp32, got '" + precision + "'");
+    char err[512] = {0};
+    const int rc = vp_create(&engine_, kind, model_path.c_str(), prec, gpu_id, err, sizeof(err));
+    if (rc != VP_OK) {
+      if (rc == VP_ERR_ARG) throw std::invalid_argument(std::string("HipBackend: ") + err);
+      throw std::runtime_error(std::string("HipBackend: ") + err);
+    }
+    // middleware 'common' convention: BGR8 frame in, B,G,R planes with BGR-ordered constants
+    // (onnx_runtime_backend.cpp:47-57); the EgoLanes engines use RGB planes (onnxruntime_engine.cpp:80-100)
+    vp_set_input_format(engine_, VP_BGR8, kind == VP_EGOLANES ? VP_PLANES_RGB : VP_PLANES_BGR);
+    vp_input_hw(engine_, &in_h_, &in_w_);
+  }
+  ~HipBackend() override { vp_destroy(engine_); }
+  HipBackend(const HipBackend &) = delete;
+  HipBackend & operator=(const HipBackend &) = delete;
+
+  bool doInference(const cv::Mat & input_image) override
+  {
+    if (input_image.empty() || input_image.type() != CV_8UC3) {
+      VP_ADAPTER_LOG_ERROR("HipBackend: expected a non-empty CV_8UC3 (BGR8) image");
+      return false;
+    }
+    const int rc = vp_infer(engine_, input_image.data, input_image.rows, input_image.cols, static_cast<int>(input_image.step));
+    if (rc != VP_OK) {
+      VP_ADAPTER_LOG_ERROR("HIP inference failed: %s", vp_last_error(engine_));
+      return false;
+    }
+    ran_ = true;
+    return true;
+  }
+
+  const float * getRawTensorData() const override
+  {
+    const float * data = nullptr;
+    int64_t shape[4];
+    if (!ran_ || vp_logits(engine_, &data, shape) != VP_OK)
+      throw std::runtime_error("Inference has not been run yet. Call doInference() first.");
+    return data;
+  }
+  std::vector<int64_t> getTensorShape() const override
+  {
+    const float * data = nullptr;
+    int64_t shape[4];
+    if (!ran_ || vp_logits(engine_, &data, shape) != VP_OK)
+      throw std::runtime_error("Inference has not been run yet. Call doInference() first.");
+    return {shape[0], shape[1], shape[2], shape[3]};
+  }
+  int getModelInputHeight() const override { return in_h_; }
+  int getModelInputWidth() const override { return in_w_; }
+
+  // ---- beyond the base interface: decode + resize done on the GPU, replacing the node's CPU loops
+  // (run_model_node.cpp:144-177) and MasksVisualizationKernels::createMaskFromTensor{CUDA,HIP}.
+  // Returns false (caller falls back to its CPU loop) on failure, like the reference helpers.
+  bool createMask(cv::Mat & output_mask, const cv::Size & frame_size)
+  {
+    if (!ran_) return false;
+    output_mask.create(frame_size, CV_8UC1);
+    if (!output_mask.isContinuous()) return false;
+    return vp_mask_resized_u8(engine_, output_mask.data, frame_size.height, frame_size.width) == VP_OK;
+  }
+  bool createDepth(cv::Mat & output_depth, const cv::Size & frame_size)
+  {
+    if (!ran_) return false;
+    output_depth.create(frame_size, CV_32FC1);
+    if (!output_depth.isContinuous()) return false;
+    return vp_depth_resized_f32(engine_, reinterpret_cast<float *>(output_depth.data), frame_size.height, frame_size.width) == VP_OK;
+  }
+
+private:
+  vp_engine * engine_ = nullptr;
+  int in_h_ = 0, in_w_ = 0;
+  bool ran_ = false;
+};
+
+}  // namespace autoware_pov::vision
+
+#endif  // HIP_BACKEND_HPP_

@@ -1,0 +1,96 @@
+// Compile + behaviour check of the C++ drop-in adapters against libvp_hip.so.
+//   adapter_check                      -> construction-failure conventions (no GPU needed)
+//   adapter_check <kind> <blob> <out>  -> one synthetic 720p BGR frame through HipBackend (kind = segmentation|depth|
+//                                         domain) or EgoLanesHipEngine (kind = egolanes); writes logits + mask to <out>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "egolanes_hip_engine.hpp"
+#include "hip_backend.hpp"
+
+using autoware_pov::vision::HipBackend;
+using autoware_pov::vision::egolanes::EgoLanesHipEngine;
+
+static int fail(const char * what)
+{
+  std::fprintf(stderr, "adapter_check FAILED: %s\n", what);
+  return 1;
+}
+
+int main(int argc, char ** argv)
+{
+  // --- error conventions (onnx_runtime_backend.cpp:86-91, tensorrt_backend.cpp:58, run_model_node.cpp:45)
+  try {
+    HipBackend b("/nonexistent/model.vpw", "fp16", 0, "segmentation");
+    return fail("ctor with a missing weight file must throw");
+  } catch (const std::runtime_error &) {
+  } catch (const std::invalid_argument &) {
+    return fail("missing file must be runtime_error, not invalid_argument");
+  }
+  try {
+    HipBackend b("x.vpw", "fp16", 0, "detector");
+    return fail("unknown model_type must throw invalid_argument");
+  } catch (const std::invalid_argument &) {
+  }
+  try {
+    HipBackend b("x.vpw", "int8", 0);
+    return fail("unknown precision must throw invalid_argument");
+  } catch (const std::invalid_argument &) {
+  }
+  try {
+    EgoLanesHipEngine e("/nonexistent/model.vpw");
+    return fail("EgoLanes ctor with a missing weight file must throw");
+  } catch (const std::runtime_error &) {
+  }
+  if (argc < 4) {
+    std::puts("adapter_check: construction-failure conventions OK");
+    return 0;
+  }
+  // --- one frame through the drop-in classes, exactly as RunModelNode::onImage / lateralInferenceThread call them
+  const std::string kind = argv[1], blob = argv[2], out = argv[3];
+  cv::Mat frame(720, 1280, CV_8UC3);
+  for (int y = 0; y < 720; ++y)
+    for (int x = 0; x < 1280 * 3; ++x) frame.data[(size_t)y * frame.step + x] = (uint8_t)((x * 7 + y * 13 + (x ^ y)) & 255);
+  std::ofstream f(out, std::ios::binary);
+  f.write(reinterpret_cast<const char *>(frame.data), (std::streamsize)frame.step * 720);
+  if (kind == "egolanes") {
+    EgoLanesHipEngine e(blob, "hip", "fp32");
+    try {
+      e.getRawTensorData();
+      return fail("getRawTensorData before inference must throw");
+    } catch (const std::runtime_error &) {
+    }
+    auto seg = e.inference(frame, 0.0f);
+    if (seg.height != 80 || seg.width != 160 || seg.ego_left.empty()) return fail("LaneSegmentation geometry");
+    const auto shape = e.getTensorShape();
+    if (shape.size() != 4 || shape[1] != 3) return fail("egolanes tensor shape");
+    f.write(reinterpret_cast<const char *>(e.getRawTensorData()), sizeof(float) * 3 * 80 * 160);
+    f.write(reinterpret_cast<const char *>(seg.ego_left.data), sizeof(float) * 80 * 160);
+  } else {
+    HipBackend b(blob, "fp32", 0, kind);
+    try {
+      b.getRawTensorData();
+      return fail("getRawTensorData before doInference must throw");
+    } catch (const std::runtime_error &) {
+    }
+    if (b.getModelInputHeight() != 320 || b.getModelInputWidth() != 640) return fail("model input size");
+    if (!b.doInference(frame)) return fail("doInference returned false");
+    const auto shape = b.getTensorShape();
+    const size_t n = (size_t)shape[1] * shape[2] * shape[3];
+    f.write(reinterpret_cast<const char *>(b.getRawTensorData()), sizeof(float) * n);
+    cv::Mat mask;
+    if (kind == "depth") {
+      if (!b.createDepth(mask, frame.size())) return fail("createDepth");
+      f.write(reinterpret_cast<const char *>(mask.data), sizeof(float) * 720 * 1280);
+    } else {
+      if (!b.createMask(mask, frame.size())) return fail("createMask");
+      f.write(reinterpret_cast<const char *>(mask.data), 720 * 1280);
+    }
+    cv::Mat bad(10, 10, CV_8UC1);
+    if (b.doInference(bad)) return fail("doInference must reject a non-BGR8 image with false");
+  }
+  std::puts("adapter_check: frame OK");
+  return 0;
+}

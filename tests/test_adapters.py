@@ -1,0 +1,54 @@
+"""The C++ drop-in adapters (adapters/hip_backend.hpp, adapters/egolanes_hip_engine.hpp) compiled against stand-in
+OpenCV / reference headers: construction-failure conventions on CPU, and on a GPU one frame driven exactly as
+RunModelNode::onImage (run_model_node.cpp:79-104,177) / lateralInferenceThread (main.cpp:505-517) drive the
+reference backends, compared with the C-ABI results obtained through the ctypes binding."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "adapters", "test", "adapter_check")
+
+
+def _build():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "adapters")], check=True, capture_output=True)
+
+
+def test_adapter_error_conventions():
+    _build()
+    r = subprocess.run([BIN], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "conventions OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mtype,kind", [("segmentation", "sceneseg"), ("depth", "scene3d"), ("egolanes", "egolanes")])
+def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, engines, mtype, kind):
+    from autoware_vision_pilot_amd import lib, weights as vw
+    from oracle import pre_post
+
+    _build()
+    blob = tmp_path / f"{kind}.vpw"
+    blob.write_bytes(vw.pack_state_dict(state_dicts(kind)))
+    out = tmp_path / "out.bin"
+    r = subprocess.run([BIN, mtype, str(blob), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    frame = raw[:720 * 1280 * 3].reshape(720, 1280, 3)
+    rest = raw[720 * 1280 * 3:]
+    eng = engines(kind, "fp16x3")
+    eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB if kind == "egolanes" else lib.VP_PLANES_BGR)
+    eng.infer(frame)
+    lg = eng.logits()
+    n = lg.size * 4
+    assert np.array_equal(rest[:n].view(np.float32).reshape(lg.shape), lg)
+    tail = rest[n:]
+    if kind == "sceneseg":
+        assert np.array_equal(tail.reshape(720, 1280), pre_post.resize_nearest_u8(pre_post.seg_mask_u8(lg), 720, 1280))
+    elif kind == "scene3d":
+        assert np.array_equal(tail.view(np.float32).reshape(720, 1280), pre_post.resize_bilinear_f32(lg[0], 720, 1280))
+    else:
+        assert np.array_equal(tail.view(np.float32).reshape(80, 160), pre_post.egolanes_planes(lg)[0])
+    eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
