@@ -70,11 +70,26 @@ struct PixLinear {
     return m < M ? m : -1;
   }
 };
+// Lane -> pixel map of a 32-pixel MFMA column tile over a 2 x 16 pixel patch.  ds_read_b128 serves a wave in the
+// fixed 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}; giving each group ONE 16-pixel row makes its 16
+// addresses consecutive halo pixels, which the 80-byte pitch spreads over all 16 bank slots (the natural
+// lanes 0-15 = row 0 / 16-31 = row 1 map is 2-way conflicted: measured 41 % of LDS cycles).
+__device__ __forceinline__ void lane_to_px16(int c, int& rowbit, int& px) {
+  if (c < 4) { rowbit = 0; px = c; }
+  else if (c < 12) { rowbit = 1; px = c - 4; }
+  else if (c < 16) { rowbit = 0; px = c - 8; }
+  else if (c < 20) { rowbit = 1; px = c - 8; }
+  else if (c < 28) { rowbit = 0; px = c - 12; }
+  else { rowbit = 1; px = c - 16; }
+}
 template <int TW>
 struct PixPatch {
+  static_assert(TW == 16, "patch kernels use 16-pixel-wide tiles");
   int y0, x0, H, W;
   __device__ __forceinline__ int operator()(int q) const {
-    const int y = y0 + q / TW, x = x0 + q % TW;
+    int rowbit, px;
+    lane_to_px16(q & 31, rowbit, px);
+    const int y = y0 + 2 * (q >> 5) + rowbit, x = x0 + px;
     return (y < H && x < W) ? y * W + x : -1;
   }
 };

@@ -175,7 +175,7 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
     tile = 2;
   }
   pc->tile = tile;
-  pc->bk = o.bk > 0 ? o.bk : 32;
+  pc->bk = o.bk > 0 ? o.bk : 64;  // 128-byte rows per load, half the K steps of BK=32
   if (cin_pad % pc->bk != 0) pc->bk = 32;
   pc->CoutW = round_up(ncols, conv_tile_co(tile));
   const long long blocks = cdiv(M, conv_tile_px(tile)) * (pc->CoutW / conv_tile_co(tile));
@@ -348,6 +348,19 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
   static const Stage stages[7] = {{1, 3, 1, 32, 16, 1}, {6, 3, 2, 16, 24, 2}, {6, 5, 2, 24, 40, 2}, {6, 3, 2, 40, 80, 3},
                                   {6, 5, 1, 80, 112, 3}, {6, 5, 2, 112, 192, 4}, {6, 3, 1, 192, 320, 1}};
   std::vector<Act*> stage_out;
+  // ---- squeeze-excite pool accumulators of all 16 MBConv blocks: one arena, one memset node per frame
+  constexpr int kSeBlocks = 16, kSeStride = 1536 * kSeReplicas;
+  const size_t se_words = (size_t)kSeBlocks * kSeStride;
+  unsigned long long* se_arena = static_cast<unsigned long long*>(dalloc(se_words * sizeof(unsigned long long)));
+  int se_block = 0;
+  {
+    Op op;
+    op.name = "se_pool_zero";
+    op.kernel = "zero_u64";
+    op.bytes = 8.0 * se_words;
+    op.run = [se_arena, se_words](hipStream_t st) { return launch_zero_u64(se_arena, se_words, st); };
+    ops_.push_back(std::move(op));
+  }
   // ---- features[0]: stem
   Act* x;
   {
@@ -385,19 +398,12 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         y = add_conv(bp + std::to_string(j), x, f.w, f.b, cexp, 1, o);
         ++j;
       }
-      // depthwise (+ fused squeeze-excite average-pool partials: pixel slabs x channel groups, deterministic)
+      // depthwise (+ fused squeeze-excite average pool: int64 fixed-point channel sums, zeroed once per frame)
       Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
       const int sq = std::max(1, cin / 4);
       const int HWz = z->H * z->W;
-      int nslab;
-      {
-        const int CG = z->C >> 3;
-        const int CGL = CG >= 32 ? 32 : (CG >= 16 ? 16 : (CG >= 8 ? 8 : 4));
-        const int ngroups = (CG + CGL - 1) / CGL, PXL = 256 / CGL;
-        nslab = std::max(1, std::min(128, (512 + ngroups - 1) / ngroups));
-        nslab = std::min(nslab, std::max(1, HWz / (PXL * 2)));
-      }
-      float* partial = static_cast<float*>(dalloc((size_t)nslab * z->C * sizeof(float)));
+      if (se_block >= kSeBlocks || z->C * kSeReplicas > kSeStride) throw std::runtime_error("SE arena too small");
+      unsigned long long* sums = se_arena + (size_t)(se_block++) * kSeStride;
       {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         const int kk = S.k * S.k;
@@ -413,8 +419,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         dp.b = dupload(bk);
         dp.k = S.k;
         dp.stride = stride;
-        dp.partial = partial;
-        dp.nslab = nslab;
+        dp.sums = sums;
         Op op;
         op.name = bp + std::to_string(j);
         op.flops = 2.0 * kk * cexp * z->H * z->W;
@@ -440,8 +445,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           for (int q = 0; q < sq; ++q) w2p[(size_t)c * sq + q] = w2.data[(size_t)c * sq + q];
           b2p[c] = b2.data[c];
         }
-        se.partial = partial;
-        se.nslab = nslab;
+        se.sums = sums;
+        se.partial = nullptr;
+        se.nslab = 0;
         se.C = z->C;
         se.Creal = cexp;
         se.sq = sq;

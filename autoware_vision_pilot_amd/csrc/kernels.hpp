@@ -28,8 +28,9 @@ struct DwParams {
   const float* w;  // [k*k][C]
   const float* b;  // [C]
   int k, stride;
-  float* partial;  // [nslab][C] per-slab channel sums of the OUTPUT (squeeze-excite average pool, fused)
-  int nslab;
+  // squeeze-excite average pool, fused: per-channel sums of the OUTPUT accumulated as 2^24 fixed-point int64
+  // (integer atomics are associative -> bit-deterministic regardless of workgroup order); zeroed once per frame
+  unsigned long long* sums;  // [kSeReplicas][C]
 };
 
 struct PoolParams {
@@ -39,6 +40,7 @@ struct PoolParams {
 };
 
 struct SeParams {
+  const unsigned long long* sums;  // [kSeReplicas][C] fixed-point channel sums (see DwParams); null -> use `partial`
   const float* partial;  // [nslab][C]
   int nslab, C, Creal, sq;
   float inv_hw;
@@ -106,6 +108,8 @@ hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
 hipError_t launch_se_fc1(const SeParams& p, hipStream_t st);
+hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st);
+constexpr int kSeReplicas = 8;  // the fused average pool spreads its atomics over 8 replica rows (workgroup id & 7)
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st);
 hipError_t launch_fc(const FcParams& p, hipStream_t st);
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st);

@@ -52,9 +52,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
   store8(p.out, (size_t)pix * 32 + g * 8, acc);
 }
 
-// ------------------------------------------------------------------------- depthwise conv + SiLU + pool partials
-// Grid = (pixel slabs, channel groups); workgroup = CGL channel-octet lanes x PXL pixel lanes.  Branch-free taps
-// (clamped address + mask) so the K loads of a kernel row are in flight together.
+// ------------------------------------------------------------------------- depthwise conv + SiLU + pool sums
+// Workgroup = CGL channel-octet lanes x PXL pixel lanes, ONE output pixel per thread (maximum parallelism: these
+// layers are latency-bound), all K*K taps loaded before the first FMA (branch-free: clamped address + mask).
+// The squeeze-excite average pool is fused: pixel lanes are reduced through LDS in a fixed order, then one
+// integer atomicAdd per channel per workgroup on a 2^24 fixed-point int64 accumulator.  Integer addition is
+// associative, so the result is bit-identical run to run whatever the workgroup order (fp32 atomics would not be).
+constexpr float kPoolFix = 16777216.0f;  // 2^24
+
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
   __shared__ float red[256 * 8];
@@ -64,58 +69,61 @@ __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
   const int cl = threadIdx.x % CGL, pl = threadIdx.x / CGL;
   const int cg = blockIdx.y * CGL + cl;
   const int OH = p.out.H, OW = p.out.W, HWo = OH * OW;
-  const int per = (HWo + p.nslab - 1) / p.nslab;
-  const int begin = blockIdx.x * per, end = min(begin + per, HWo);
+  const int pix = blockIdx.x * PXL + pl;
   constexpr int pad = (K - 1) / 2;
-  float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (cg < CG) {
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8), b1 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8 + 4);
-    for (int pix = begin + pl; pix < end; pix += PXL) {
-      const int oy = pix / OW, ox = pix - oy * OW;
-      float acc[8];
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool live = cg < CG && pix < HWo;
+  if (live) {
+    const int oy = pix / OW, ox = pix - oy * OW;
+    h8_t vh[K * K], vl[K * K];
+    bool ok[K * K];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * p.stride + ky - pad;
+      const bool yok = (unsigned)iy < (unsigned)p.in.H;
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * p.stride + ky - pad;
-        const bool yok = (unsigned)iy < (unsigned)p.in.H;
-        const int iyc = yok ? iy : 0;
-        float v[K][8];
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const int ix = ox * p.stride + kx - pad;
-          const bool ok = yok && (unsigned)ix < (unsigned)p.in.W;
-          load8(p.in, ((size_t)iyc * p.in.W + (ok ? ix : 0)) * p.in.C + cg * 8, v[kx]);
-          if (!ok) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[kx][i] = 0.0f;
-          }
-        }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const float* wk = p.w + (size_t)(ky * K + kx) * p.in.C + cg * 8;
-          const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wk), w1 = *reinterpret_cast<const f32x4_t*>(wk + 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { acc[i] = fmaf(v[kx][i], w0[i], acc[i]); acc[4 + i] = fmaf(v[kx][4 + i], w1[i], acc[4 + i]); }
-        }
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * p.stride + kx - pad;
+        const bool o = yok && (unsigned)ix < (unsigned)p.in.W;
+        const size_t off = ((size_t)(o ? iy : 0) * p.in.W + (o ? ix : 0)) * p.in.C + cg * 8;
+        ok[ky * K + kx] = o;
+        vh[ky * K + kx] = *reinterpret_cast<const h8_t*>(p.in.hi + off);
+        if (p.in.lo) vl[ky * K + kx] = *reinterpret_cast<const h8_t*>(p.in.lo + off);
       }
+    }
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8), b1 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      const float* wk = p.w + (size_t)t * p.in.C + cg * 8;
+      const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wk), w1 = *reinterpret_cast<const f32x4_t*>(wk + 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        acc[i] = silu_f(acc[i]);
-        sum[i] += acc[i];
+        float v = (float)vh[t][i];
+        if (p.in.lo) v += (float)vl[t][i];
+        v = ok[t] ? v : 0.0f;
+        acc[i] = fmaf(v, i < 4 ? w0[i] : w1[i - 4], acc[i]);
       }
-      store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = silu_f(acc[i]);
+    store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = sum[i];
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = live ? acc[i] : 0.0f;
   __syncthreads();
   if (pl == 0 && cg < CG) {
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = red[cl * 8 + i];
     for (int q = 1; q < PXL; ++q)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sum[i] += red[(q * CGL + cl) * 8 + i];
+      for (int i = 0; i < 8; ++i) s[i] += red[(q * CGL + cl) * 8 + i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) p.partial[(size_t)blockIdx.x * p.in.C + cg * 8 + i] = sum[i];
+    for (int i = 0; i < 8; ++i)
+      atomicAdd(p.sums + (size_t)(blockIdx.x & (kSeReplicas - 1)) * p.in.C + cg * 8 + i,
+                (unsigned long long)(long long)__float2ll_rn(s[i] * kPoolFix));
   }
 }
 
@@ -168,8 +176,15 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
   extern __shared__ __attribute__((aligned(16))) float mean[];
   for (int c = threadIdx.x; c < p.C; c += 256) {
     float s = 0.f;
+    if (p.sums) {
+      long long t = 0;
+#pragma unroll
+      for (int r = 0; r < kSeReplicas; ++r) t += (long long)p.sums[(size_t)r * p.C + c];
+      s = (float)((double)t * (1.0 / 16777216.0));
+    } else {
 #pragma unroll 4
-    for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
+      for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
+    }
     mean[c] = s * p.inv_hw;
   }
   __syncthreads();
@@ -196,14 +211,21 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
 // column slice of every weight row.
 __global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams p) {
   __shared__ float gate[32];
+  __shared__ float part[8][32];
   const int c0 = blockIdx.x * 32;
-  if (threadIdx.x < 32) {
-    const int c = c0 + threadIdx.x;
-    float s = p.b2[c];
+  {  // 8 partial dot products per channel (fixed summation order), then one lane per channel finishes
+    const int cl = threadIdx.x & 31, jp = threadIdx.x >> 5, c = c0 + cl;
     const float* wr = p.w2 + (size_t)c * p.sq;
-#pragma unroll 8
-    for (int j = 0; j < p.sq; ++j) s = fmaf(wr[j], p.s1[j], s);
-    gate[threadIdx.x] = c < p.Creal ? sigmoid_f(s) : 0.0f;
+    float s = 0.f;
+    for (int j = jp; j < p.sq; j += 8) s = fmaf(wr[j], p.s1[j], s);
+    part[jp][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float t = p.b2[c];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += part[q][cl];
+      gate[cl] = c < p.Creal ? sigmoid_f(t) : 0.0f;
+    }
   }
   __syncthreads();
   const int oct = threadIdx.x & 3;
@@ -262,13 +284,23 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   }
 }
 
+// Zeroes the squeeze-excite accumulators once per frame (a kernel, not hipMemsetAsync: the memset was not replayed
+// by the captured graph on this ROCm, so the sums kept growing from frame to frame).
+__global__ __launch_bounds__(256) void zero_u64_kernel(unsigned long long* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0ull;
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
+hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st) {
+  VP_LAUNCH(zero_u64_kernel, dim3(nblk((long long)n)), dim3(256), 0, st, p, n);
+}
 hipError_t launch_stem(const StemParams& p, hipStream_t st) {
   VP_LAUNCH(stem_kernel, dim3(nblk((long long)(p.H / 2) * (p.W / 2) * 4)), dim3(256), 0, st, p);
 }
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st) {
-  const int CG = p.in.C >> 3, CGL = slab_cgl(p.in.C);
-  const dim3 grid(p.nslab, (CG + CGL - 1) / CGL);
+  const int CG = p.in.C >> 3, CGL = slab_cgl(p.in.C), PXL = 256 / CGL;
+  const dim3 grid((p.out.H * p.out.W + PXL - 1) / PXL, (CG + CGL - 1) / CGL);
   if (p.k == 3) VP_LAUNCH(dwconv_pool_kernel<3>, grid, dim3(256), 0, st, p);
   if (p.k == 5) VP_LAUNCH(dwconv_pool_kernel<5>, grid, dim3(256), 0, st, p);
   return hipErrorInvalidValue;

@@ -22,7 +22,7 @@
 namespace vp {
 
 
-template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT>
+template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves per workgroup");
   constexpr int ROWB = BK * 2 + 16;   // LDS row pitch in bytes
@@ -68,60 +68,64 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     b_lds[i] = row * ROWB + ch * 16;
   }
 
-  // staging registers: native vector type + unconditional (clamped) loads, so they stay in VGPRs (conditional
-  // definitions carried around the K loop sent them to scratch)
+  // Staging registers: a DEPTH-deep ring of K-step tiles, indexed by COMPILE-TIME slots (the K loop is unrolled by
+  // DEPTH; macros, not lambdas: closures / runtime indices push these arrays and the accumulators into scratch).
+  // Each global load is issued DEPTH-1 steps before its LDS store, so the ~1-2 us first-touch latency of tensors
+  // written by the previous kernel (other XCDs' L2 -> MALL/HBM) is paid once per DEPTH steps, not every step.
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 ra_hi[A_ITERS], rb_hi[B_ITERS], ra_lo[SPLIT ? A_ITERS : 1], rb_lo[SPLIT ? B_ITERS : 1];
+  u32x4 ra_hi[DEPTH][A_ITERS], rb_hi[DEPTH][B_ITERS], ra_lo[DEPTH][SPLIT ? A_ITERS : 1], rb_lo[DEPTH][SPLIT ? B_ITERS : 1];
 #pragma unroll
-  for (int i = 0; i < A_ITERS; ++i) {
-    ra_hi[i] = zero4;
-    if (i < (SPLIT ? A_ITERS : 1)) ra_lo[i] = zero4;
+  for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      ra_hi[d][i] = zero4;
+      if (i < (SPLIT ? A_ITERS : 1)) ra_lo[d][i] = zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      rb_hi[d][i] = zero4;
+      if (i < (SPLIT ? B_ITERS : 1)) rb_lo[d][i] = zero4;
+    }
   }
+  const int s_last = s_end - 1;
 
-  auto load_regs = [&](int s) __attribute__((always_inline)) {
-    const int tap = s / KC;
-    const int c0 = (s - tap * KC) * BK;
-    const int ky = tap / p.ks;
-    const int dy = ky - half_k, dx = (tap - ky * p.ks) - half_k;
-    const size_t wbase = (size_t)tap * p.CoutW * p.Cin + c0;
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) {
-        ra_hi[i] = *reinterpret_cast<const u32x4*>(p.w_hi + wbase + a_off[i]);
-        if constexpr (SPLIT) ra_lo[i] = *reinterpret_cast<const u32x4*>(p.w_lo + wbase + a_off[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-      const int yy = b_y[i] + dy, xx = b_x[i] + dx;
-      const bool ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
-      const size_t g = ok ? ((size_t)yy * p.W + xx) * p.Cin + c0 + b_ch[i] : 0;  // offset 0 is always valid
-      const u32x4 vh = *reinterpret_cast<const u32x4*>(p.in_hi + g);
-      rb_hi[i] = ok ? vh : zero4;
-      if constexpr (SPLIT) {
-        const u32x4 vl = *reinterpret_cast<const u32x4*>(p.in_lo + g);
-        rb_lo[i] = ok ? vl : zero4;
-      }
-    }
-  };
-  auto store_lds = [&](int buf) __attribute__((always_inline)) {
-    char* st = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) {
-        *reinterpret_cast<u32x4*>(st + OFF_AHI + a_lds[i]) = ra_hi[i];
-        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st + OFF_ALO + a_lds[i]) = ra_lo[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_ITERS; ++i) {
-      if (B_CHUNKS % 256 == 0 || tid + 256 * i < B_CHUNKS) {
-        *reinterpret_cast<u32x4*>(st + OFF_BHI + b_lds[i]) = rb_hi[i];
-        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st + OFF_BLO + b_lds[i]) = rb_lo[i];
-      }
-    }
-  };
+#define VP_LOAD(SLOT, SIDX)                                                                                   \
+  {                                                                                                           \
+    const int s_ = (SIDX) < s_last ? (SIDX) : s_last; /* clamped: loads stay unconditional */                  \
+    const int tap_ = s_ / KC;                                                                                 \
+    const int c0_ = (s_ - tap_ * KC) * BK;                                                                    \
+    const int ky_ = tap_ / p.ks;                                                                              \
+    const int dy_ = ky_ - half_k, dx_ = (tap_ - ky_ * p.ks) - half_k;                                         \
+    const size_t wbase_ = (size_t)tap_ * p.CoutW * p.Cin + c0_;                                               \
+    _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
+      ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + wbase_ + a_off[i]);                           \
+      if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + wbase_ + a_off[i]);      \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) {                                                     \
+      const int yy_ = b_y[i] + dy_, xx_ = b_x[i] + dx_;                                                       \
+      const bool ok_ = ((unsigned)yy_ < (unsigned)p.H) && ((unsigned)xx_ < (unsigned)p.W);                    \
+      const size_t g_ = ok_ ? ((size_t)yy_ * p.W + xx_) * p.Cin + c0_ + b_ch[i] : 0; /* 0 is always valid */  \
+      const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in_hi + g_);                                        \
+      rb_hi[SLOT][i] = ok_ ? vh_ : zero4;                                                                     \
+      if constexpr (SPLIT) {                                                                                  \
+        const u32x4 vl_ = *reinterpret_cast<const u32x4*>(p.in_lo + g_);                                      \
+        rb_lo[SLOT][i] = ok_ ? vl_ : zero4;                                                                   \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+#define VP_STORE(SLOT, BUF)                                                                                   \
+  {                                                                                                           \
+    char* st_ = smem + (BUF) * STAGE;                                                                         \
+    _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
+      *reinterpret_cast<u32x4*>(st_ + OFF_AHI + a_lds[i]) = ra_hi[SLOT][i];                                   \
+      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st_ + OFF_ALO + a_lds[i]) = ra_lo[SLOT][i];              \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) if (B_CHUNKS % 256 == 0 || tid + 256 * i < B_CHUNKS) { \
+      *reinterpret_cast<u32x4*>(st_ + OFF_BHI + b_lds[i]) = rb_hi[SLOT][i];                                   \
+      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st_ + OFF_BLO + b_lds[i]) = rb_lo[SLOT][i];              \
+    }                                                                                                         \
+  }
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -135,42 +139,55 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int a_frag = OFF_AHI + (wco * 32) * ROWB + frag_off;  // wave owns channel tiles i*WCO + wco (contiguous per epilogue pass)
   const int b_frag = OFF_BHI + (wpx * NT * 32) * ROWB + frag_off;
 
+  // prologue: steps 0..DEPTH-1 in flight; step 0 -> LDS buffer 0; slot 0 refills with step DEPTH
   if (s_begin < s_end) {
-    load_regs(s_begin);
-    store_lds(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) VP_LOAD(d, s_begin + d)
+    VP_STORE(0, 0)
+    VP_LOAD(0, s_begin + DEPTH)
   }
   __syncthreads();
-  for (int s = s_begin; s < s_end; ++s) {
-    const int buf = (s - s_begin) & 1;
-    load_regs(s + 1 < s_end ? s + 1 : s);  // unconditional: see staging-register note above
-    const char* st = smem + buf * STAGE;
+  int buf = 0;
+  for (int sb = s_begin; sb < s_end; sb += DEPTH) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      h8_t a[MT], b[NT], alo[SPLIT ? MT : 1], blo[SPLIT ? NT : 1];
+    for (int d = 0; d < DEPTH; ++d) {
+      const int s = sb + d;  // (s - s_begin) % DEPTH == d
+      if (s < s_end) {
+        const char* st = smem + buf * STAGE;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        a[i] = *reinterpret_cast<const h8_t*>(st + a_frag + i * WCO * 32 * ROWB + kk * 32);
-        if constexpr (SPLIT) alo[i] = *reinterpret_cast<const h8_t*>(st + (OFF_ALO - OFF_AHI) + a_frag + i * WCO * 32 * ROWB + kk * 32);
-      }
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          h8_t a[MT], b[NT], alo[SPLIT ? MT : 1], blo[SPLIT ? NT : 1];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        b[j] = *reinterpret_cast<const h8_t*>(st + b_frag + j * 32 * ROWB + kk * 32);
-        if constexpr (SPLIT) blo[j] = *reinterpret_cast<const h8_t*>(st + (OFF_BLO - OFF_BHI) + b_frag + j * 32 * ROWB + kk * 32);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if constexpr (SPLIT) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], blo[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MT; ++i) {
+            a[i] = *reinterpret_cast<const h8_t*>(st + a_frag + i * WCO * 32 * ROWB + kk * 32);
+            if constexpr (SPLIT) alo[i] = *reinterpret_cast<const h8_t*>(st + (OFF_ALO - OFF_AHI) + a_frag + i * WCO * 32 * ROWB + kk * 32);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            b[j] = *reinterpret_cast<const h8_t*>(st + b_frag + j * 32 * ROWB + kk * 32);
+            if constexpr (SPLIT) blo[j] = *reinterpret_cast<const h8_t*>(st + (OFF_BLO - OFF_BHI) + b_frag + j * 32 * ROWB + kk * 32);
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              if constexpr (SPLIT) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], blo[j], acc[i][j], 0, 0, 0);
+              }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
+        // step s+1 (loaded DEPTH-1 steps ago) -> the other LDS buffer; its slot refills with step s+1+DEPTH
+        if (s + 1 < s_end) VP_STORE((d + 1) % DEPTH, buf ^ 1)
+        VP_LOAD((d + 1) % DEPTH, s + 1 + DEPTH)
+        __syncthreads();
+        buf ^= 1;
+      }
     }
-    if (s + 1 < s_end) store_lds(buf ^ 1);
-    __syncthreads();
   }
+#undef VP_STORE
+#undef VP_LOAD
 
   // ---- epilogue through LDS (conv_epilogue.hpp); the main loop's last barrier has retired every LDS read
   const PixLinear pix{m0, M};
@@ -210,7 +227,10 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int ROWB = BK * 2 + 16;
   constexpr int lds_main = 2 * (CO + PX) * ROWB * (SPLIT ? 2 : 1);
   constexpr int lds = lds_main > epilogue_stage_bytes<PX, WCO>() ? lds_main : epilogue_stage_bytes<PX, WCO>();
-  auto k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT>;
+  // prefetch depth: as deep as the register budget allows (staging = DEPTH * (A+B chunks) * 16 B per lane)
+  constexpr int chunks = ((CO + PX) * (BK / 8) + 255) / 256 * (SPLIT ? 2 : 1);
+  constexpr int DEPTH = chunks <= 4 ? 4 : (chunks <= 8 ? 3 : 2);
+  auto k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

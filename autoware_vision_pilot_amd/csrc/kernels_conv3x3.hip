@@ -24,12 +24,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
   constexpr int ROWB = 80, CH = 4;  // 32 channels = 64 B + 16 B pad
   constexpr int PX = TH * TW, HWD = TW + 2, HHT = TH + 2, HPX = HHT * HWD;
   constexpr int HCHUNKS = HPX * CH, HP = (HCHUNKS + 255) / 256;
-  static_assert(HP <= 9, "halo must be loadable in 9 tap steps");
+  static_assert(HP <= 7, "halo pieces are loaded at taps 0..HP-1 and stored two taps later");
   constexpr int WCHUNKS = CO_TILE * CH, WP = (WCHUNKS + 255) / 256;
   constexpr int MT = CO_TILE / WCO / 32, NT = PX / WPX / 32;
   static_assert(MT >= 1 && NT >= 1, "wave tile");
   constexpr int NPL = SPLIT ? 2 : 1;
-  constexpr int HALO_BYTES = HPX * ROWB, W_BYTES = CO_TILE * ROWB;
+  constexpr int WROW = 64;  // weight tile rows are unpadded; 16-byte chunks XOR-swizzled by (row>>2)&3: conflict-free ds_read_b128 AND ds_write_b128
+  constexpr int HALO_BYTES = HPX * ROWB, W_BYTES = CO_TILE * WROW;
+  static_assert(TW == 16, "lane->pixel map assumes 16-pixel-wide patches");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo_base = smem;                             // [2][NPL][HALO_BYTES]
   char* const w_base = smem + 2 * NPL * HALO_BYTES;         // [2][NPL][W_BYTES]
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
     const int row = idx >> 2, ch = idx & 3;
     const bool ok = idx < WCHUNKS;
     w_goff[pc] = ok ? (co0 + row) * 32 + ch * 8 : -1;
-    w_lds[pc] = row * ROWB + ch * 16;
+    w_lds[pc] = row * WROW + ((ch ^ ((row >> 2) & 3)) << 4);
   }
   const size_t w_step = (size_t)p.CoutW * 32;  // elements per (chunk, tap) weight tile row-set
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -76,9 +78,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int q = (wpx * NT + j) * 32 + (lane & 31);
-    b_ofs[j] = ((q / TW) * HWD + (q % TW)) * ROWB + (lane >> 5) * 16;
+    int rowbit, px;
+    lane_to_px16(q & 31, rowbit, px);  // conflict-free lane -> pixel map (conv_epilogue.hpp)
+    b_ofs[j] = ((2 * (q >> 5) + rowbit) * HWD + px) * ROWB + (lane >> 5) * 16;
   }
-  const int a_ofs = (wco * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;  // wave owns channel tiles i*WCO + wco
+  const int a_ofs = (wco * 32 + (lane & 31)) * WROW;  // wave owns channel tiles i*WCO + wco
+  const int a_swz = ((lane & 31) >> 2) & 3;
+  const int a_sw[2] = {(((lane >> 5)) ^ a_swz) << 4, ((2 + (lane >> 5)) ^ a_swz) << 4};
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -88,64 +94,71 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // Staging registers.  Everything below is written with macros over compile-time tap / piece indices instead of
-  // lambdas: closures capturing the accumulators by reference kept them in scratch memory (640 B/lane).
-  u32x4 rw_hi[WP], rw_lo[SPLIT ? WP : 1], rh_hi = zero4, rh_lo = zero4;
+  // Staging registers: a 3-deep ring of per-tap weight tiles and a 3-deep ring of halo pieces, indexed by
+  // COMPILE-TIME tap numbers (macros, not lambdas or runtime loops: closures / dynamic indices push these arrays and
+  // the accumulators into scratch memory).  Ring depth 3 divides the 9 taps, so slot = tap % 3 everywhere.
+  // Every load is issued 2-3 tap steps before its LDS store: HBM/MALL latency (~1-2 us for first-touch weights) is
+  // hidden behind ~3 taps of MFMAs instead of one.
+  u32x4 rw_hi[3][WP], rw_lo[3][SPLIT ? WP : 1], rh_hi[3], rh_lo[3];
 #pragma unroll
-  for (int pc = 0; pc < WP; ++pc) {
-    rw_hi[pc] = zero4;
-    if (pc < (SPLIT ? WP : 1)) rw_lo[pc] = zero4;
+  for (int r = 0; r < 3; ++r) {
+    rh_hi[r] = zero4;
+    rh_lo[r] = zero4;
+#pragma unroll
+    for (int pc = 0; pc < WP; ++pc) {
+      rw_hi[r][pc] = zero4;
+      if (pc < (SPLIT ? WP : 1)) rw_lo[r][pc] = zero4;
+    }
   }
+  const int s_last = c_end * 9 - 1;
 
-#define VP_LOAD_W(SIDX)                                                                               \
+#define VP_LOAD_W(SLOT, SIDX)                                                                         \
   {                                                                                                   \
-    const size_t base_ = (size_t)(SIDX) * w_step;                                                     \
+    const int si_ = (SIDX) < s_last ? (SIDX) : s_last; /* clamped: loads stay unconditional */         \
+    const size_t base_ = (size_t)si_ * w_step;                                                        \
     _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
-      rw_hi[pc] = *reinterpret_cast<const u32x4*>(p.w_hi + base_ + w_goff[pc]);                       \
-      if constexpr (SPLIT) rw_lo[pc] = *reinterpret_cast<const u32x4*>(p.w_lo + base_ + w_goff[pc]);  \
+      rw_hi[SLOT][pc] = *reinterpret_cast<const u32x4*>(p.w_hi + base_ + w_goff[pc]);                 \
+      if constexpr (SPLIT) rw_lo[SLOT][pc] = *reinterpret_cast<const u32x4*>(p.w_lo + base_ + w_goff[pc]); \
     }                                                                                                 \
   }
-#define VP_STORE_W(BUF)                                                                               \
+#define VP_STORE_W(SLOT, BUF)                                                                         \
   {                                                                                                   \
     char* dst_ = w_base + (BUF) * NPL * W_BYTES;                                                      \
     _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
-      *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = rw_hi[pc];                                        \
-      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = rw_lo[pc];         \
+      *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = rw_hi[SLOT][pc];                                  \
+      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = rw_lo[SLOT][pc];   \
     }                                                                                                 \
   }
   // out-of-image halo pixels: load from offset 0 (always valid) and zero the value, so the access stays a plain
   // global_load (a pointer select turned it into flat_load)
-#define VP_LOAD_H(PC, C)                                                                              \
+#define VP_LOAD_H(SLOT, PC, C)                                                                        \
   {                                                                                                   \
     const int g_ = h_goff[PC];                                                                        \
     const int o_ = (g_ >= 0 ? g_ : 0) + (C) * 32;                                                     \
     u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in_hi + o_);                                         \
-    rh_hi = g_ >= 0 ? v_ : zero4;                                                                     \
+    rh_hi[SLOT] = g_ >= 0 ? v_ : zero4;                                                               \
     if constexpr (SPLIT) {                                                                            \
       u32x4 l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                                       \
-      rh_lo = g_ >= 0 ? l_ : zero4;                                                                   \
+      rh_lo[SLOT] = g_ >= 0 ? l_ : zero4;                                                             \
     }                                                                                                 \
   }
-#define VP_STORE_H(PC, BUF)                                                                           \
+#define VP_STORE_H(SLOT, PC, BUF)                                                                     \
   if (h_lds[PC] >= 0) {                                                                               \
     char* dst_ = halo_base + (BUF) * NPL * HALO_BYTES;                                                \
-    *reinterpret_cast<u32x4*>(dst_ + h_lds[PC]) = rh_hi;                                              \
-    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + HALO_BYTES + h_lds[PC]) = rh_lo;            \
+    *reinterpret_cast<u32x4*>(dst_ + h_lds[PC]) = rh_hi[SLOT];                                        \
+    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + HALO_BYTES + h_lds[PC]) = rh_lo[SLOT];      \
   }
 #define VP_TAP(T)                                                                                     \
   {                                                                                                   \
-    const bool more_ = next_chunk || ((T) < 8);                                                       \
-    /* next tile (c,T+1) or (c+1,0): chunk-major, tap-minor storage; loads are unconditional (clamped) so */ \
-    /* the staging registers have a single definition per step and never fall back to scratch            */ \
-    VP_LOAD_W(c * 9 + (T) + (more_ ? 1 : 0))                                                          \
-    if constexpr ((T) < HP) VP_LOAD_H((T) < HP ? (T) : 0, next_chunk ? c + 1 : c)                     \
+    /* halo piece T of the NEXT chunk: issued now, stored two taps later */                           \
+    if constexpr ((T) < HP) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c)            \
     constexpr int tap_ofs_ = (((T) / 3) * HWD + ((T) % 3)) * ROWB;                                    \
     const char* wbuf_ = w_base + wb * NPL * W_BYTES;                                                  \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
       h8_t a_[MT], b_[NT], alo_[SPLIT ? MT : 1], blo_[SPLIT ? NT : 1];                                \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                \
-        a_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + a_ofs + i * WCO * 32 * ROWB + kk * 32);              \
-        if constexpr (SPLIT) alo_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + W_BYTES + a_ofs + i * WCO * 32 * ROWB + kk * 32); \
+        a_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + a_ofs + i * WCO * 32 * WROW + a_sw[kk]);        \
+        if constexpr (SPLIT) alo_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + W_BYTES + a_ofs + i * WCO * 32 * WROW + a_sw[kk]); \
       }                                                                                               \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
         b_[j] = *reinterpret_cast<const h8_t*>(hbuf + b_ofs[j] + tap_ofs_ + kk * 32);                 \
@@ -159,23 +172,28 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i], b_[j], acc[i][j], 0, 0, 0);         \
       }                                                                                               \
     }                                                                                                 \
-    if (more_) VP_STORE_W(wb ^ 1)                                                                     \
-    if constexpr ((T) < HP) {                                                                         \
-      if (next_chunk) VP_STORE_H((T) < HP ? (T) : 0, hb ^ 1)                                          \
+    /* weight tile of step s+1 (loaded 3 steps ago) -> the other LDS buffer; its slot then refills with step s+4 */ \
+    if (next_chunk || ((T) < 8)) VP_STORE_W(((T) + 1) % 3, wb ^ 1)                                    \
+    VP_LOAD_W(((T) + 1) % 3, c * 9 + (T) + 4)                                                         \
+    if constexpr ((T) >= 2 && (T) - 2 < HP) {                                                         \
+      if (next_chunk) VP_STORE_H(((T) - 2) % 3, (T) >= 2 ? (T) - 2 : 0, hb ^ 1)                       \
     }                                                                                                 \
     __syncthreads();                                                                                  \
     wb ^= 1;                                                                                          \
   }
 
-  // ---- prologue: halo(c_begin) and weights(c_begin, tap 0)
+  // ---- prologue: halo(c_begin) -> LDS, weights(step 0) -> LDS, weights(steps 1..3) -> ring slots 1, 2, 0
   if (c_begin < c_end) {
 #pragma unroll
     for (int pc = 0; pc < HP; ++pc) {
-      VP_LOAD_H(pc, c_begin)
-      VP_STORE_H(pc, 0)
+      VP_LOAD_H(0, pc, c_begin)
+      VP_STORE_H(0, pc, 0)
     }
-    VP_LOAD_W(c_begin * 9)
-    VP_STORE_W(0)
+    VP_LOAD_W(0, c_begin * 9)
+    VP_STORE_W(0, 0)
+    VP_LOAD_W(1, c_begin * 9 + 1)
+    VP_LOAD_W(2, c_begin * 9 + 2)
+    VP_LOAD_W(0, c_begin * 9 + 3)
   }
   __syncthreads();
 
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
 
 template <int CO, int TH, int TW, int WCO, int WPX, bool SPLIT>
 static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
-  constexpr int lds_main = 2 * (SPLIT ? 2 : 1) * ((TH + 2) * (TW + 2) + CO) * 80;
+  constexpr int lds_main = 2 * (SPLIT ? 2 : 1) * ((TH + 2) * (TW + 2) * 80 + CO * 64);
   constexpr int lds = lds_main > epilogue_stage_bytes<TH * TW, WCO>() ? lds_main : epilogue_stage_bytes<TH * TW, WCO>();
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT>;

@@ -223,3 +223,21 @@ def test_errors_are_loud(engines):
     eng = engines("sceneseg", "fp16")
     with pytest.raises(ValueError):
         eng.infer(np.zeros((10, 10), dtype=np.uint8))
+
+
+def test_no_state_leaks_between_frames(engines, frame720):
+    """Per-frame accumulators (SE pool sums, split-K slabs) must be re-initialised by every replay: A, B, A -> A."""
+    from oracle import pre_post
+
+    other = pre_post.synthetic_frame(720, 1280, 77)
+    for kind, prec in (("sceneseg", "fp16x3"), ("egolanes", "fp16")):
+        eng = engines(kind, prec)
+        eng.infer(frame720)
+        a1 = eng.logits()
+        eng.infer(other)
+        b = eng.logits()
+        for _ in range(3):
+            eng.infer(frame720)
+        a2 = eng.logits()
+        assert np.array_equal(a1, a2), f"{kind}/{prec}: state leaked between frames"
+        assert not np.array_equal(a1, b)
