@@ -1,6 +1,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -226,7 +227,45 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
                     (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
   if (tile >= 100) {
-    const int ht = tile - 100;
+    int ht = tile - 100;
+    // ---- optional per-layer tile autotune (VP_AUTOTUNE=1 enables; measured +-1 % on the frames-in-flight bench, so
+    // the static heuristic is the default): time the tile shapes that share this weight packing and keep the fastest.  The K order per output is identical for every tile, so the choice never changes a result bit.
+    static const char* at_env = std::getenv("VP_AUTOTUNE");
+    const bool explicit_tile = o.tile >= 100;
+    if (!explicit_tile && at_env && at_env[0] == '1' && kind_ >= 0) {
+      std::vector<int> cand;
+      for (int c : {0, 1, 2, 3, 4}) {
+        if (sp && (c == 0 || c == 2)) continue;
+        if (pc.CoutW % halo_tile_co(c) != 0) continue;
+        if (halo_tile_co(c) > pc.CoutW) continue;
+        if (ncols <= 32 && c != 4) continue;
+        if (ncols > 32 && c == 4) continue;
+        cand.push_back(c);
+      }
+      // Cost = wall time of 6 launches spread over 3 streams: the engine is meant to run with several frames in
+      // flight, so what counts is the CU-time a tile shape consumes under contention, not its latency alone.
+      hipStream_t ts[3] = {stream_, nullptr, nullptr};
+      VP_HIP_CHECK(hipStreamCreateWithFlags(&ts[1], hipStreamNonBlocking));
+      VP_HIP_CHECK(hipStreamCreateWithFlags(&ts[2], hipStreamNonBlocking));
+      double best = 1e30;
+      int best_c = ht;
+      for (int c : cand) {
+        hipError_t e = launch_conv3x3_halo(p, c, sp, stream_);  // warm-up (also sets the LDS attribute)
+        if (e != hipSuccess) continue;
+        VP_HIP_CHECK(hipStreamSynchronize(stream_));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < 6 && e == hipSuccess; ++r) e = launch_conv3x3_halo(p, c, sp, ts[r % 3]);
+        for (hipStream_t s : ts) VP_HIP_CHECK(hipStreamSynchronize(s));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (e == hipSuccess && us < best) {
+          best = us;
+          best_c = c;
+        }
+      }
+      hipStreamDestroy(ts[1]);
+      hipStreamDestroy(ts[2]);
+      ht = best_c;
+    }
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3>" : ",x1>") +
                 (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
