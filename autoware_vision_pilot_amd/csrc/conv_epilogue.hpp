@@ -8,34 +8,42 @@
 //            residual in fp32, (hi, lo) split, ONE 16-byte store per plane; 8 lanes cover 128 contiguous bytes.
 // Keeping phase 2 out of the unrolled code also keeps the kernels small enough for full unrolling, which is what
 // keeps the accumulator array in registers (a partially unrolled epilogue pushed it to scratch memory).
+// Phase 2 is instantiated per (store mode, residual mode, activation) combination the networks use, so the row
+// loop carries no mode branches (the all-runtime version was ~1600 instructions per pass; SQ_ACTIVE_INST showed
+// waves of the memory-bound layers spending 40 % of their life issuing it).
 #pragma once
 #include "kernels.hpp"
 
 namespace vp {
 
 // bias + activation + residual + split + store for 8 consecutive output channels of pixel m.
+// STORE / RES / ACT >= 0 fix the mode at compile time; -1 reads it from the parameter block.
+template <int STORE = -1, int RES = -1, int ACT = -1>
 __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, int m, int co, float v[8], const f32x4_t& b0,
                                                 const f32x4_t& b1) {
+  const int act = ACT >= 0 ? ACT : p.act;
+  const int res_mode = RES >= 0 ? RES : p.res_mode;
+  const int store_mode = STORE >= 0 ? STORE : p.store_mode;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    v[r] = apply_act(v[r] + b0[r], p.act);
-    v[4 + r] = apply_act(v[4 + r] + b1[r], p.act);
+    v[r] = apply_act(v[r] + b0[r], act);
+    v[4 + r] = apply_act(v[4 + r] + b1[r], act);
   }
-  if (p.store_mode == STORE_NCHW_F32) {
+  if (store_mode == STORE_NCHW_F32) {
 #pragma unroll
     for (int r = 0; r < 8; ++r)
       if (co + r < p.Creal) p.out_f32[(size_t)(co + r) * M + m] = v[r];
     return;
   }
   size_t o;
-  if (p.store_mode == STORE_SHUFFLE2) {
+  if (store_mode == STORE_SHUFFLE2) {
     const int q = co / p.Cstore, c = co - q * p.Cstore;
     const int y = m / p.W, x = m - y * p.W;
     o = ((size_t)(2 * y + (q >> 1)) * (2 * p.W) + (2 * x + (q & 1))) * p.Cstore + c;
   } else {
     o = (size_t)m * p.Cstore + co;
   }
-  if (p.res_mode != RES_NONE) {
+  if (res_mode != RES_NONE) {
     const h8_t rh = *reinterpret_cast<const h8_t*>(p.res_hi + o);
     float r8[8];
 #pragma unroll
@@ -46,7 +54,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, 
       for (int r = 0; r < 8; ++r) r8[r] += (float)rl[r];
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = (p.res_mode == RES_ADD) ? (v[r] + r8[r]) : (v[r] * r8[r] + r8[r]);
+    for (int r = 0; r < 8; ++r) v[r] = (res_mode == RES_ADD) ? (v[r] + r8[r]) : (v[r] * r8[r] + r8[r]);
   }
   h8_t hi;
 #pragma unroll
@@ -92,6 +100,22 @@ struct PixPatch {
   }
 };
 
+// phase 2 row loop, one instantiation per mode combination (see header comment)
+template <int STORE, int RES, int ACT, int PXT, int RPI, int PITCH, class PixMap>
+__device__ __forceinline__ void epilogue_rows(const ConvGemmParams& p, const char* stage, int r0, int c8, int co, const PixMap& pix,
+                                              int M) {
+  const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+#pragma unroll 2
+  for (int r = r0; r < PXT; r += RPI) {
+    const int m = pix(r);
+    if (m < 0) continue;
+    const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+    const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
+    float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+    epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1);
+  }
+}
+
 // One epilogue pass over the channel slice [co_base, co_base + 32*WCO) of a PXT-pixel workgroup tile.
 //   accs[j] : this wave's NT accumulator tiles of the pass (32 channels x 32 pixels each, MFMA C layout:
 //             lane&31 = pixel, register 4g+r = channel 8g + 4*(lane>>5) + r)
@@ -117,25 +141,30 @@ __device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* sta
   }
   __syncthreads();
   // ---- phase 2
-  const int c8 = tid % CPR;
+  const int c8 = tid % CPR, r0 = tid / CPR;
   const int co = co_base + c8 * 8;
   if (co < p.Ncols) {
-    // the lane's 8 channels are the same for every row: bias is loaded once, not per row
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
-#pragma unroll 2
-    for (int r = tid / CPR; r < PXT; r += RPI) {
-      const int m = pix(r);
-      if (m < 0) continue;
-      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
-      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
-      if (p.nsplit > 1) {
+    if (p.nsplit > 1) {
+      for (int r = r0; r < PXT; r += RPI) {
+        const int m = pix(r);
+        if (m < 0) continue;
         float* dst = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co;
-        *reinterpret_cast<f32x4_t*>(dst) = s0;
-        *reinterpret_cast<f32x4_t*>(dst + 4) = s1;
-      } else {
-        float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        epilogue_store8(p, M, m, co, v, b0, b1);
+        *reinterpret_cast<f32x4_t*>(dst) = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+        *reinterpret_cast<f32x4_t*>(dst + 4) = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
       }
+    } else {
+      const int key = p.store_mode * 100 + p.res_mode * 10 + p.act;
+#define VP_ROWS(S, R, A) epilogue_rows<S, R, A, PXT, RPI, PITCH>(p, stage, r0, c8, co, pix, M)
+      switch (key) {
+        case STORE_NHWC * 100 + RES_NONE * 10 + ACT_GELU: VP_ROWS(STORE_NHWC, RES_NONE, ACT_GELU); break;   // decoder 3x3
+        case STORE_NHWC * 100 + RES_NONE * 10 + ACT_SILU: VP_ROWS(STORE_NHWC, RES_NONE, ACT_SILU); break;   // MBConv expand
+        case STORE_NHWC * 100 + RES_NONE * 10 + ACT_NONE: VP_ROWS(STORE_NHWC, RES_NONE, ACT_NONE); break;   // MBConv project
+        case STORE_NHWC * 100 + RES_ADD * 10 + ACT_NONE: VP_ROWS(STORE_NHWC, RES_ADD, ACT_NONE); break;     // residual / skip link
+        case STORE_SHUFFLE2 * 100 + RES_NONE * 10 + ACT_NONE: VP_ROWS(STORE_SHUFFLE2, RES_NONE, ACT_NONE); break;  // ConvTranspose
+        case STORE_NCHW_F32 * 100 + RES_NONE * 10 + ACT_NONE: VP_ROWS(STORE_NCHW_F32, RES_NONE, ACT_NONE); break;  // logits
+        default: VP_ROWS(-1, -1, -1); break;                                                                 // e.g. ctx mul-add
+      }
+#undef VP_ROWS
     }
   }
   __syncthreads();

@@ -22,7 +22,9 @@
 namespace vp {
 
 
-template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH>
+// K1: kernel size 1 (1x1 conv / ConvTranspose-as-GEMM) -- the tap/bounds arithmetic of the general path cost ~190
+// instructions per K step against 8 MFMAs; the K1 path is one 32-bit add per load.
+template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH, bool K1>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves per workgroup");
   constexpr int ROWB = BK * 2 + 16;   // LDS row pitch in bytes
@@ -56,6 +58,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     a_lds[i] = row * ROWB + ch * 16;
   }
   int b_y[B_ITERS], b_x[B_ITERS], b_lds[B_ITERS], b_ch[B_ITERS];
+  int a_off32[A_ITERS], b_off32[B_ITERS];  // K1 fast path: element offsets of the K=0 chunk (-1 = row outside the image)
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) a_off32[i] = (int)a_off[i];
 #pragma unroll
   for (int i = 0; i < B_ITERS; ++i) {
     const int idx = tid + 256 * i, row = idx / CH, ch = idx % CH;
@@ -66,6 +71,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     b_x[i] = m - y * p.W;
     b_ch[i] = ch * 8;
     b_lds[i] = row * ROWB + ch * 16;
+    b_off32[i] = ok ? m * p.Cin + ch * 8 : -1;
   }
 
   // Staging registers: a DEPTH-deep ring of K-step tiles, indexed by COMPILE-TIME slots (the K loop is unrolled by
@@ -93,6 +99,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #define VP_LOAD(SLOT, SIDX)                                                                                   \
   {                                                                                                           \
     const int s_ = (SIDX) < s_last ? (SIDX) : s_last; /* clamped: loads stay unconditional */                  \
+    if constexpr (K1) { /* 1x1 / ConvTranspose GEMM: no tap arithmetic, 32-bit offsets, one add per load */   \
+      const int c0_ = s_ * BK;                                                                                \
+      _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
+        ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + (a_off32[i] + c0_));                        \
+        if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + (a_off32[i] + c0_));   \
+      }                                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) {                                                   \
+        const bool ok_ = b_off32[i] >= 0;                                                                     \
+        const int g_ = (ok_ ? b_off32[i] : 0) + c0_;                                                          \
+        const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in_hi + g_);                                      \
+        rb_hi[SLOT][i] = ok_ ? vh_ : zero4;                                                                   \
+        if constexpr (SPLIT) {                                                                                \
+          const u32x4 vl_ = *reinterpret_cast<const u32x4*>(p.in_lo + g_);                                    \
+          rb_lo[SLOT][i] = ok_ ? vl_ : zero4;                                                                 \
+        }                                                                                                     \
+      }                                                                                                       \
+    } else {                                                                                                  \
     const int tap_ = s_ / KC;                                                                                 \
     const int c0_ = (s_ - tap_ * KC) * BK;                                                                    \
     const int ky_ = tap_ / p.ks;                                                                              \
@@ -113,8 +136,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         rb_lo[SLOT][i] = ok_ ? vl_ : zero4;                                                                   \
       }                                                                                                       \
     }                                                                                                         \
+    }                                                                                                         \
   }
-#define VP_STORE(SLOT, BUF)                                                                                   \
+#define VP_STORE(SLOT, BUF)                                                                                  \
   {                                                                                                           \
     char* st_ = smem + (BUF) * STAGE;                                                                         \
     _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
@@ -231,12 +255,13 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   // prefetch depth: as deep as the register budget allows (staging = DEPTH * (A+B chunks) * 16 B per lane)
   constexpr int chunks = ((CO + PX) * (BK / 8) + 255) / 256 * (SPLIT ? 2 : 1);
   constexpr int DEPTH = chunks <= 4 ? 4 : (chunks <= 8 ? 3 : 2);
-  auto k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const bool k1 = p.ks == 1;
+  auto k = k1 ? conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, true> : conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, false>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[k1]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[k1] = true;
   }
   const int M = p.H * p.W;
   dim3 grid((M + PX - 1) / PX, p.CoutW / CO, p.nsplit);
