@@ -22,7 +22,11 @@ struct ActView {
   int H, W, C;  // C = padded channel count
 };
 
-enum ActFn { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3 };
+// ACT_*_F16 (base | 4): the VP_FP16 engines' variants -- results are rounded to fp16 (2^-11 relative) anyway, so the
+// activation may trade fp32-class accuracy for VALU instructions (measured on gfx950: VALU work does NOT hide behind
+// another wave's MFMAs, tools/mfma_valu_overlap.hip, so epilogue instructions are paid in full).  VP_FP16X3 (the
+// parity mode) always uses the base codes.
+enum ActFn { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_F16 = 4, ACT_GELU_F16 = 5, ACT_SILU_F16 = 6, ACT_SIGMOID_F16 = 7 };
 enum ResMode { RES_NONE = 0, RES_ADD = 1, RES_MULADD = 2 };  // MULADD: out = v*res + res  (scene_context.py:56)
 enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_NCHW_F32 = 2 };
 
@@ -66,10 +70,28 @@ __device__ __forceinline__ float gelu_exact(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// VP_FP16 variants.  GELU(x) = x * Phi(x) with Phi(x) = sigmoid(g(x)), g = logit(Phi) approximated by an odd
+// degree-9 polynomial (minimax fit of the GELU error over [0,10]; coefficients below carry the -log2(e) factor of
+// exp2): max |error| 3.4e-6 in fp32 arithmetic, two orders below the fp16 rounding of the stored result, monotone tails
+// (x -> +-inf gives x and -0).  7 packable fp32 ops + v_exp_f32 + v_rcp_f32 per value (the erf form: ~16 + 2).
+__device__ __forceinline__ float gelu_f16(float x) {
+  const float t = x * x;
+  float q = fmaf(t, -3.228988134651445e-06f, 8.823812095215544e-05f);
+  q = fmaf(q, t, 0.0003602745709940791f);
+  q = fmaf(q, t, -0.10522668808698654f);
+  q = fmaf(q, t, -2.3020453453063965f);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * q));
+}
+__device__ __forceinline__ float sigmoid_f16(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+__device__ __forceinline__ float silu_f16(float x) { return x * sigmoid_f16(x); }
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ACT_GELU) return gelu_exact(v);
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_SIGMOID) return sigmoid_f(v);
+  if (act == ACT_GELU_F16) return gelu_f16(v);
+  if (act == ACT_SILU_F16) return silu_f16(v);
+  if (act == ACT_SIGMOID_F16) return sigmoid_f16(v);
   return v;
 }
 

@@ -158,6 +158,8 @@ __device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* sta
       switch (key) {
         case STORE_NHWC * 100 + RES_NONE * 10 + ACT_GELU: VP_ROWS(STORE_NHWC, RES_NONE, ACT_GELU); break;   // decoder 3x3
         case STORE_NHWC * 100 + RES_NONE * 10 + ACT_SILU: VP_ROWS(STORE_NHWC, RES_NONE, ACT_SILU); break;   // MBConv expand
+        case STORE_NHWC * 100 + RES_NONE * 10 + ACT_GELU_F16: VP_ROWS(STORE_NHWC, RES_NONE, ACT_GELU_F16); break;
+        case STORE_NHWC * 100 + RES_NONE * 10 + ACT_SILU_F16: VP_ROWS(STORE_NHWC, RES_NONE, ACT_SILU_F16); break;
         case STORE_NHWC * 100 + RES_NONE * 10 + ACT_NONE: VP_ROWS(STORE_NHWC, RES_NONE, ACT_NONE); break;   // MBConv project
         case STORE_NHWC * 100 + RES_ADD * 10 + ACT_NONE: VP_ROWS(STORE_NHWC, RES_ADD, ACT_NONE); break;     // residual / skip link
         case STORE_SHUFFLE2 * 100 + RES_NONE * 10 + ACT_NONE: VP_ROWS(STORE_SHUFFLE2, RES_NONE, ACT_NONE); break;  // ConvTranspose
@@ -173,6 +175,55 @@ __device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* sta
 template <int PXT, int WCO>
 constexpr int epilogue_stage_bytes() {
   return PXT * (32 * WCO * 4 + 16);
+}
+
+// Single-pass epilogue for the hot case (fp16 tensors, bias + GELU, no residual, NHWC store) of the 3x3 kernels:
+// bias + GELU + fp16 conversion happen in REGISTERS on the whole accumulator set (straight-line code: MT*NT*16
+// independent chains per lane, so the ~16-op GELU chains interleave instead of serialising in a 2-pass row loop),
+// the fp16 tile is staged once in LDS as [pixel][CO channels] and leaves as 16-byte rows (256 B contiguous per pixel).
+// Measured on decode_layer_8 the generic 2-pass fp32-staged epilogue + prologue was 32 K of the workgroup's 77 K cycles.
+template <int PXT, int CO, int WCO, int MT, int NT, class PixMap>
+__device__ __forceinline__ void epilogue_gelu_fp16(const ConvGemmParams& p, char* stage, f32x16_t (&acc)[MT][NT], int co0, int wco,
+                                                   int wpx, const PixMap& pix) {
+  constexpr int PITCH = CO * 2 + 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  __syncthreads();  // the stage aliases the main loop's LDS buffers
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int cl = (i * WCO + wco) * 32 + 4 * (lane >> 5);  // channel (within the CO tile) of register group g=0, r=0
+    f32x4_t b[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4_t*>(p.bias + co0 + cl + 8 * g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      char* row = stage + ((wpx * NT + j) * 32 + (lane & 31)) * PITCH + cl * 2;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4_t h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v;  // read the accumulator out of its AGPR here, not in one 128-register burst after the main loop
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));
+          h[r] = (half_t)gelu_f16(v + b[g][r]);
+        }
+        *reinterpret_cast<h4_t*>(row + g * 16) = h;
+        __builtin_amdgcn_sched_barrier(0);  // keep the GELU chains from interleaving across groups (VGPR pressure -> occupancy)
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = CO / 8;
+  for (int idx = tid; idx < PXT * CPR; idx += 256) {
+    const int r = idx / CPR, c8 = idx - r * CPR;
+    const int m = pix(r);
+    const int co = co0 + c8 * 8;
+    if (m < 0 || co >= p.Ncols) continue;
+    *reinterpret_cast<h8_t*>(p.out_hi + (size_t)m * p.Cstore + co) = *reinterpret_cast<const h8_t*>(stage + r * PITCH + c8 * 16);
+  }
+}
+template <int PXT, int CO>
+constexpr int epilogue_fp16_stage_bytes() {
+  return PXT * (CO * 2 + 16);
 }
 
 hipError_t launch_splitk_finish(const ConvGemmParams& p, hipStream_t st);  // kernels_conv.hip

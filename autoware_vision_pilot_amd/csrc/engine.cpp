@@ -205,7 +205,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.ks = ks;
   p.Ncols = ncols;
   p.CoutW = pc.CoutW;
-  p.act = o.act;
+  p.act = (o.act != ACT_NONE && !split()) ? (o.act | ACT_F16) : o.act;  // VP_FP16: reduced-instruction activations (common.hpp)
   p.res_mode = o.res_mode;
   p.res_hi = o.res ? o.res->hi : nullptr;
   p.res_lo = o.res ? o.res->lo : nullptr;

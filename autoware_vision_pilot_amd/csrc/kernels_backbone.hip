@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     for (int i = 0; i < 8; ++i) acc[i] = fmaf(in[k], wk[i], acc[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = silu_f(acc[i]);
+  for (int i = 0; i < 8; ++i) acc[i] = p.out.lo ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
   store8(p.out, (size_t)pix * 32 + g * 8, acc);
 }
 
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = silu_f(acc[i]);
+    for (int i = 0; i < 8; ++i) acc[i] = p.out.lo ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
     store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
   }
 #pragma unroll

@@ -20,7 +20,9 @@ namespace vp {
 
 // ABL: ablation bits for tools/halo_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA,
 // 4 = no LDS fragment reads, 8 = no barrier); always 0 in the library.
-template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0>
+// FASTEPI: single-pass register GELU + fp16-staged epilogue (conv_epilogue.hpp epilogue_gelu_fp16); the launcher
+// selects it when the layer is bias + ACT_GELU_F16 (VP_FP16 engines), no residual, NHWC, no split-K.
+template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0, bool FASTEPI = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves");
   constexpr int ROWB = 80, CH = 4;  // 32 channels = 64 B + 16 B pad
@@ -192,6 +194,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
     wb ^= 1;                                                                                          \
   }
 
+  if constexpr ((ABL & 48) != 0) {  // experiment: de-phase the workgroups that share a CU
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);  // HW_ID.TG_ID
+    const bool late = (ABL & 16) ? (tg & 1) : ((blockIdx.x >> 8) & 1);
+    if (late)
+      for (int k = 0; k < p.ks - 3; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- prologue: halo(c_begin) -> LDS, weights(step 0) -> LDS, weights(steps 1..3) -> ring slots 1, 2, 0
   if (c_begin < c_end) {
 #pragma unroll
@@ -222,21 +230,28 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
 
   // ---- epilogue through LDS (conv_epilogue.hpp): accumulators -> stage[pixel][channel] -> coalesced 16-byte stores
   const PixPatch<TW> pix{y0, x0, p.H, p.W};
+  if constexpr (FASTEPI) {
+    epilogue_gelu_fp16<PX, CO_TILE, WCO, MT, NT>(p, smem, acc, co0, wco, wpx, pix);
+  } else {
 #pragma unroll
-  for (int i = 0; i < MT; ++i) epilogue_pass<PX, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, blockIdx.z);
+    for (int i = 0; i < MT; ++i) epilogue_pass<PX, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, blockIdx.z);
+  }
 }
 
 template <int CO, int TH, int TW, int WCO, int WPX, bool SPLIT>
 static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds_main = 2 * (SPLIT ? 2 : 1) * ((TH + 2) * (TW + 2) * 80 + CO * 64);
-  constexpr int lds = lds_main > epilogue_stage_bytes<TH * TW, WCO>() ? lds_main : epilogue_stage_bytes<TH * TW, WCO>();
+  constexpr int lds_a = lds_main > epilogue_stage_bytes<TH * TW, WCO>() ? lds_main : epilogue_stage_bytes<TH * TW, WCO>();
+  constexpr int lds = lds_a > epilogue_fp16_stage_bytes<TH * TW, CO>() ? lds_a : epilogue_fp16_stage_bytes<TH * TW, CO>();
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  const bool fast = !SPLIT && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1 &&
+                    p.out_lo == nullptr;
+  auto k = fast ? conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, !SPLIT> : conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, false>;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[fast]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done[fast] = true;
   }
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.CoutW / CO, p.nsplit);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);

@@ -18,11 +18,12 @@ using namespace vp;
     }                                                                             \
   } while (0)
 
-template <int CO, int TH, int TW, int ABL>
+template <int CO, int TH, int TW, int ABL, bool FAST = false>
 static float time_variant(const ConvGemmParams& p, int iters) {
   constexpr int lds_main = 2 * ((TH + 2) * (TW + 2) * 80 + CO * 64);
-  constexpr int lds = lds_main > epilogue_stage_bytes<TH * TW, 2>() ? lds_main : epilogue_stage_bytes<TH * TW, 2>();
-  auto k = conv3x3_halo_kernel<CO, TH, TW, 2, 2, false, ABL>;
+  constexpr int lds_a = lds_main > epilogue_stage_bytes<TH * TW, 2>() ? lds_main : epilogue_stage_bytes<TH * TW, 2>();
+  constexpr int lds = lds_a > epilogue_fp16_stage_bytes<TH * TW, CO>() ? lds_a : epilogue_fp16_stage_bytes<TH * TW, CO>();
+  auto k = conv3x3_halo_kernel<CO, TH, TW, 2, 2, false, ABL, FAST>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.CoutW / CO, 1);
   hipEvent_t a, b;
@@ -66,7 +67,7 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   p.ks = 3;
   p.Ncols = Cout;
   p.CoutW = Cout;
-  p.act = ACT_GELU;
+  p.act = ACT_GELU_F16;
   p.out_hi = out;
   p.Cstore = Cout;
   p.Creal = Cout;
@@ -75,10 +76,16 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   const int it = 20;
   const float t0 = time_variant<CO, TH, TW, 0>(p, it), t1 = time_variant<CO, TH, TW, 1>(p, it), t2 = time_variant<CO, TH, TW, 2>(p, it),
               t4 = time_variant<CO, TH, TW, 4>(p, it), t8 = time_variant<CO, TH, TW, 8>(p, it), t5 = time_variant<CO, TH, TW, 5>(p, it),
-              t13 = time_variant<CO, TH, TW, 13>(p, it), t7 = time_variant<CO, TH, TW, 7>(p, it);
+              t13 = time_variant<CO, TH, TW, 13>(p, it), t7 = time_variant<CO, TH, TW, 7>(p, it), tf = time_variant<CO, TH, TW, 0, true>(p, it),
+              tf7 = time_variant<CO, TH, TW, 7, true>(p, it);
+  for (int g = 1; g <= 4; ++g) {
+    ConvGemmParams q = p;
+    q.ks = 3 + g;
+    std::printf("  stagger sleep x%d: by TG_ID %7.1f us | by block>>8 %7.1f us\n", g, time_variant<CO, TH, TW, 16, true>(q, it), time_variant<CO, TH, TW, 32, true>(q, it));
+  }
   std::printf("%-28s %6.1f GF | full %7.1f us (%6.1f TF) | noGlobal %7.1f | noMFMA %7.1f | noLdsRead %7.1f | noBarrier %7.1f | "
-              "noGlobal+noLdsRead %7.1f | mfma+barrier-free-only %7.1f | nothing-but-loop %7.1f\n",
-              name, gflop, t0, gflop / t0 * 1e-3 * 1e3 / 1e3 * 1e3, t1, t2, t4, t8, t5, t13, t7);
+              "noGlobal+noLdsRead %7.1f | mfma+barrier-free-only %7.1f | nothing-but-loop %7.1f | FASTEPI full %7.1f (%6.1f TF) nothing %7.1f\n",
+              name, gflop, t0, gflop / t0 * 1e3, t1, t2, t4, t8, t5, t13, t7, tf, gflop / tf * 1e3, tf7);
   hipFree(in);
   hipFree(out);
   hipFree(w);
