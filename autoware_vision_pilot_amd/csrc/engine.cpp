@@ -302,6 +302,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         halo = (!split() && t256 * cdiv(ncols, 64) >= 400) ? 2 : 3;
       } else {
         halo = (!split() && t256 * (ncols / 128) >= 400) ? 0 : 1;
+        // between half and one full machine of 128-channel tiles: 64-channel tiles double the workgroup count with
+        // no split-K partial traffic (decode_layer_5: 46 us vs 57 us with a 3-way split, profiles/r01_splitk_ablation.txt)
+        if (halo == 1 && t128 * (ncols / 128) < 256 && t128 * (ncols / 64) >= 256) halo = 3;
       }
     }
     if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
@@ -313,9 +316,19 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     const int KC = cin_pad / 32;
     const long long blocks = (long long)((in->H + halo_tile_th(halo) - 1) / halo_tile_th(halo)) * ((in->W + 15) / 16) *
                              (pc.CoutW / halo_tile_co(halo));
+    // split-K: aim at ONE machine-wide wave of workgroups (256); go towards two only while the K loop per slice stays
+    // long (> 6 chunks = 54 tap steps), and keep the fp32 partials (written + re-read by the finish kernel at
+    // ~4.5 TB/s) under ~24 MB.  Measured per layer in profiles/r01_splitk_ablation.txt.
     int ns = 1;
-    if (o.nsplit > 0) ns = o.nsplit;
-    else if (blocks < 256) ns = (int)std::min<long long>((512 + blocks - 1) / blocks, std::max(1, KC / 2));
+    if (o.nsplit > 0) {
+      ns = o.nsplit;
+    } else if (blocks < 256) {
+      ns = (int)((256 + blocks - 1) / blocks);
+      while (KC / ns > 6 && blocks * ns < 512) ++ns;
+      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
+      while (ns > 2 && ns * slice_mb > 24.0) --ns;
+      ns = std::min(ns, std::max(1, KC / 2));
+    }
     pc.nsplit = std::max(1, std::min(ns, KC));
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);

@@ -25,7 +25,7 @@ static float time_variant(const ConvGemmParams& p, int iters) {
   constexpr int lds = lds_a > epilogue_fp16_stage_bytes<TH * TW, CO>() ? lds_a : epilogue_fp16_stage_bytes<TH * TW, CO>();
   auto k = conv3x3_halo_kernel<CO, TH, TW, 2, 2, false, ABL, FAST>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW), p.CoutW / CO, 1);
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW) * (p.CoutW / CO) * p.nsplit);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
@@ -93,7 +93,62 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   return 0;
 }
 
-int main() {
+// split-K neck shapes: kernel only (partials written), finish kernel timed separately
+template <int CO, int TH, int TW>
+static int run_split(const char* name, int H, int W, int Cin, int Cout, int nsplit) {
+  const size_t in_n = (size_t)H * W * Cin, out_n = (size_t)H * W * Cout, w_n = (size_t)9 * Cout * Cin;
+  half_t *in, *out, *w;
+  float *bias, *partial;
+  CK(hipMalloc(&in, in_n * 2));
+  CK(hipMalloc(&out, out_n * 2));
+  CK(hipMalloc(&w, w_n * 2));
+  CK(hipMalloc(&bias, Cout * 4));
+  CK(hipMalloc(&partial, (size_t)nsplit * H * W * Cout * 4));
+  std::vector<half_t> h(in_n > w_n ? in_n : w_n);
+  unsigned s = 12345;
+  for (auto& v : h) {
+    s = s * 1664525u + 1013904223u;
+    v = (half_t)(((int)(s >> 9) % 2001 - 1000) * 0.001f);
+  }
+  CK(hipMemcpy(in, h.data(), in_n * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(w, h.data(), w_n * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(bias, 0, Cout * 4));
+  ConvGemmParams p{};
+  p.in_hi = in; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.act = ACT_GELU_F16; p.out_hi = out; p.Cstore = Cout; p.Creal = Cout; p.nsplit = nsplit; p.partial = partial;
+  const double gflop = 2.0 * H * W * (double)Cout * Cin * 9 / 1e9;
+  const int it = 20;
+  const float t0 = time_variant<CO, TH, TW, 0>(p, it), t1 = time_variant<CO, TH, TW, 1>(p, it), t2 = time_variant<CO, TH, TW, 2>(p, it),
+              t4 = time_variant<CO, TH, TW, 4>(p, it), t8 = time_variant<CO, TH, TW, 8>(p, it), t7 = time_variant<CO, TH, TW, 7>(p, it),
+              t15 = time_variant<CO, TH, TW, 15>(p, it);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  launch_splitk_finish(p, 0);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < it; ++i) launch_splitk_finish(p, 0);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float fms = 0;
+  hipEventElapsedTime(&fms, a, b);
+  const int blocks = ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * (Cout / CO) * nsplit;
+  std::printf("%-34s ns=%2d blocks=%4d %5.1f GF | full %6.1f us (%5.1f TF) | noGlobal %6.1f | noMFMA %6.1f | noLdsRead %6.1f | noBarrier %6.1f | "
+              "nothing-but-loop %6.1f | nothing, no barrier %6.1f | finish %5.1f us\n",
+              name, nsplit, blocks, gflop, t0, gflop / t0 * 1e3, t1, t2, t4, t8, t7, t15, fms * 1000.0f / it);
+  hipFree(in); hipFree(out); hipFree(w); hipFree(bias); hipFree(partial);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) {
+    for (int ns : {1, 2, 4, 8, 15}) run_split<128, 8, 16>("dec0 1920->512 20x40 t8x16", 20, 40, 1920, 512, ns);
+    for (int ns : {1, 2, 4, 8, 15}) run_split<64, 8, 16>("dec0 1920->512 20x40 co64 t8x16", 20, 40, 1920, 512, ns);
+    for (int ns : {1, 2, 4, 8}) run_split<128, 8, 16>("dec1 512->512 20x40 t8x16", 20, 40, 512, 512, ns);
+    for (int ns : {1, 2, 3, 6}) run_split<128, 8, 16>("dec2 768->512 40x80 t8x16", 40, 80, 768, 512, ns);
+    for (int ns : {1, 2, 3, 6}) run_split<128, 8, 16>("dec3 512->512 40x80 t8x16", 40, 80, 512, 512, ns);
+    for (int ns : {1, 2, 3}) run_split<128, 8, 16>("dec5 512->256 80x160 t8x16", 80, 160, 512, 256, ns);
+    for (int ns : {1, 2, 3}) run_split<64, 8, 16>("dec5 512->256 80x160 co64 t8x16", 80, 160, 512, 256, ns);
+    return 0;
+  }
   run_shape<128, 16, 16>("dec8 128->128 320x640 t16x16", 320, 640, 128, 128);
   run_shape<128, 8, 16>("dec8 128->128 320x640 t8x16", 320, 640, 128, 128);
   run_shape<128, 16, 16>("dec6 256->256 160x320 t16x16", 160, 320, 256, 256);
