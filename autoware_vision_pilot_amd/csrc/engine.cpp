@@ -401,10 +401,11 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
                                   {6, 5, 1, 80, 112, 3}, {6, 5, 2, 112, 192, 4}, {6, 3, 1, 192, 320, 1}};
   std::vector<Act*> stage_out;
   // ---- squeeze-excite pool accumulators of all 16 MBConv blocks: one arena, one memset node per frame
-  constexpr int kSeBlocks = 16, kSeStride = 1536 * kSeReplicas;
-  const size_t se_words = (size_t)kSeBlocks * kSeStride;
+  constexpr int kSeBlocks = 16;
+  const size_t se_words = (size_t)kSeBlocks * 1536 * 8 + (size_t)6 * 256 * kSeMaxReplicas;  // >= sum of replicas*C below (checked)
   unsigned long long* se_arena = static_cast<unsigned long long*>(dalloc(se_words * sizeof(unsigned long long)));
   int se_block = 0;
+  size_t se_used = 0;
   {
     Op op;
     op.name = "se_pool_zero";
@@ -454,8 +455,18 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
       const int sq = std::max(1, cin / 4);
       const int HWz = z->H * z->W;
-      if (se_block >= kSeBlocks || z->C * kSeReplicas > kSeStride) throw std::runtime_error("SE arena too small");
-      unsigned long long* sums = se_arena + (size_t)(se_block++) * kSeStride;
+      // replica rows for the pool atomics: ~8 workgroups per row, 8..64 rows
+      int se_rep = 8;
+      {
+        const int cg8 = z->C >> 3;  // lane layout of dwconv_pool_kernel (act_io.hpp slab_cgl)
+        const int pxl = 256 / (cg8 >= 32 ? 32 : (cg8 >= 16 ? 16 : (cg8 >= 8 ? 8 : 4)));
+        const int nbx = (HWz + pxl - 1) / pxl;
+        while (se_rep < kSeMaxReplicas && se_rep * 16 <= nbx) se_rep *= 2;
+      }
+      if (se_used + (size_t)se_rep * z->C > se_words) throw std::runtime_error("SE arena too small");
+      unsigned long long* sums = se_arena + se_used;
+      se_used += (size_t)se_rep * z->C;
+      ++se_block;
       {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         const int kk = S.k * S.k;
@@ -472,6 +483,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         dp.k = S.k;
         dp.stride = stride;
         dp.sums = sums;
+        dp.replicas = se_rep;
         Op op;
         op.name = bp + std::to_string(j);
         op.flops = 2.0 * kk * cexp * z->H * z->W;
@@ -498,6 +510,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           b2p[c] = b2.data[c];
         }
         se.sums = sums;
+        se.replicas = se_rep;
         se.partial = nullptr;
         se.nslab = 0;
         se.C = z->C;

@@ -30,7 +30,8 @@ struct DwParams {
   int k, stride;
   // squeeze-excite average pool, fused: per-channel sums of the OUTPUT accumulated as 2^24 fixed-point int64
   // (integer atomics are associative -> bit-deterministic regardless of workgroup order); zeroed once per frame
-  unsigned long long* sums;  // [kSeReplicas][C]
+  unsigned long long* sums;  // [replicas][C]
+  int replicas;              // power of two <= kSeMaxReplicas: workgroup x-index & (replicas-1) picks the row
 };
 
 struct PoolParams {
@@ -40,7 +41,8 @@ struct PoolParams {
 };
 
 struct SeParams {
-  const unsigned long long* sums;  // [kSeReplicas][C] fixed-point channel sums (see DwParams); null -> use `partial`
+  const unsigned long long* sums;  // [replicas][C] fixed-point channel sums (see DwParams); null -> use `partial`
+  int replicas;
   const float* partial;  // [nslab][C]
   int nslab, C, Creal, sq;
   float inv_hw;
@@ -109,7 +111,9 @@ hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
 hipError_t launch_se_fc1(const SeParams& p, hipStream_t st);
 hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st);
-constexpr int kSeReplicas = 8;  // the fused average pool spreads its atomics over 8 replica rows (workgroup id & 7)
+// The fused average pool spreads its atomics over `replicas` rows: same-address atomics serialise in L2 (measured:
+// 100+ per address cost 30 us on the 80x160 layers), so layers with many workgroups get up to 64 rows.
+constexpr int kSeMaxReplicas = 64;
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st);
 hipError_t launch_fc(const FcParams& p, hipStream_t st);
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
       for (int i = 0; i < 8; ++i) s[i] += red[(q * CGL + cl) * 8 + i];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      atomicAdd(p.sums + (size_t)(blockIdx.x & (kSeReplicas - 1)) * p.in.C + cg * 8 + i,
+      atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * p.in.C + cg * 8 + i,
                 (unsigned long long)(long long)__float2ll_rn(s[i] * kPoolFix));
   }
 }
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
     float s = 0.f;
     if (p.sums) {
       long long t = 0;
-#pragma unroll
-      for (int r = 0; r < kSeReplicas; ++r) t += (long long)p.sums[(size_t)r * p.C + c];
+#pragma unroll 8
+      for (int r = 0; r < p.replicas; ++r) t += (long long)p.sums[(size_t)r * p.C + c];
       s = (float)((double)t * (1.0 / 16777216.0));
     } else {
 #pragma unroll 4
