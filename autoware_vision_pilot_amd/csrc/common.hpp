@@ -50,6 +50,12 @@ struct ConvGemmParams {
   float* out_f32;      // STORE_NCHW_F32: [Creal][H*W]
   int Creal;
   int nsplit;          // split-K factor (grid.z); >1 -> partial sums go to `partial`
+  // K extension of the ConvTranspose GEMM (STORE_SHUFFLE2 only): the 1x1 skip-link conv of the SAME output pixel is
+  // accumulated in the same pass.  K columns [Cin, Cin+Cin2) read a second tensor of size 2H x 2W x Cin2 at the
+  // output pixel (2y+dy, 2x+dx) of the workgroup's quadrant; weight rows are Cin+Cin2 wide.  in2_delta_* = element
+  // distance from in_hi/in_lo to that tensor's planes (one base pointer keeps the loads plain global loads).
+  int Cin2;
+  long long in2_delta_hi, in2_delta_lo;
   float* partial;      // [nsplit][M][CoutW] fp32 scratch
 };
 

@@ -216,6 +216,11 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.out_f32 = o.logits_out;
   p.Creal = cout_real;
   p.nsplit = pc.nsplit;
+  if (o.in2) {
+    p.Cin2 = o.in2->C;
+    p.in2_delta_hi = o.in2->hi - in->hi;
+    p.in2_delta_lo = (in->lo && o.in2->lo) ? o.in2->lo - in->lo : 0;
+  }
   const int M = in->H * in->W;
   p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
   const int tile = pc.tile, bk = pc.bk;
@@ -226,6 +231,10 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   const double esz = sp ? 4.0 : 2.0;
   op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
                     (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
+  if (o.in2) {  // fused skip-link: extra K columns read at every OUTPUT pixel
+    op.flops += 2.0 * M * 4.0 * cout_real * o.in2->Creal;
+    op.bytes += esz * ((double)M * 4.0 * o.in2->Creal + (double)cout_real * o.in2->Creal);
+  }
   if (tile >= 100) {
     int ht = tile - 100;
     // ---- optional per-layer tile autotune (VP_AUTOTUNE=1 enables; measured +-1 % on the frames-in-flight bench, so
@@ -390,6 +399,60 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
   pc.w_lo = split() ? dupload(lo) : nullptr;
   pc.bias = dupload(bias);
   push_conv_op(name, in, pc, 1, ncols, o, out, STORE_SHUFFLE2, cout);
+  return out;
+}
+
+// d = ConvTranspose2d(k2,s2)(x) + Conv1x1(skip) in ONE GEMM (scene_neck.py:29-31 and the other up/skip pairs): the
+// skip conv's input channels are appended to the K axis (kernels_conv.hip, K extension), biases are summed.  The
+// intermediate up-sampled tensor is never written or re-read (it was the largest HBM stream of these layers) and the
+// skip-link launch disappears.  Falls back to the two-op form when a workgroup's channel tile would straddle
+// pixel-shuffle quadrants.
+Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_name, const Act* in, const Act* skip_in,
+                            const std::vector<float>& wt, const std::vector<float>& bt, const std::vector<float>& ws,
+                            const std::vector<float>& bs, int cout) {
+  const int cin = in->Creal, cin_pad = in->C, cs = skip_in->Creal, cs_pad = skip_in->C;
+  if (wt.size() != (size_t)cin * cout * 4) throw std::runtime_error("convT weight size mismatch: " + up_name);
+  if (ws.size() != (size_t)cout * cs) throw std::runtime_error("skip conv weight size mismatch: " + skip_name);
+  if (skip_in->H != in->H * 2 || skip_in->W != in->W * 2) throw std::runtime_error("skip tensor size mismatch: " + skip_name);
+  static const char* env = std::getenv("VP_FUSE_SKIP");
+  const int cpad = round_up(cout, 32);
+  const int ncols = 4 * cpad;
+  ConvOpts o;
+  o.in2 = skip_in;
+  if ((cin_pad | cs_pad) % 64 != 0) o.bk = 32;  // K steps must not straddle the two tensors
+  PackedConv pc;
+  choose_conv_cfg(in->H * in->W, ncols, cin_pad + cs_pad, 1, o, &pc);
+  const bool fusable = cpad % conv_tile_co(pc.tile) == 0 && !(env && env[0] == '0');
+  if (!fusable) {
+    Act* u = add_convT(up_name, in, wt, bt, cout, ConvOpts{});
+    ConvOpts so;
+    so.res_mode = RES_ADD;
+    so.res = u;
+    add_conv(skip_name, skip_in, ws, bs, cout, 1, so, u);
+    return u;
+  }
+  Act* out = new_act(up_name, cout, in->H * 2, in->W * 2);
+  const int kw = cin_pad + cs_pad;
+  std::vector<half_t> hi((size_t)pc.CoutW * kw, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
+  std::vector<float> bias(pc.CoutW, 0.0f);
+  for (int q = 0; q < 4; ++q)
+    for (int co = 0; co < cout; ++co) {
+      const int n = q * cpad + co;
+      bias[n] = bt[co] + bs[co];
+      for (int k = 0; k < cin + cs; ++k) {
+        const float v = k < cin ? wt[((size_t)k * cout + co) * 4 + q] : ws[(size_t)co * cs + (k - cin)];
+        const size_t col = k < cin ? k : cin_pad + (k - cin);
+        half_t h, l;
+        split_half(v, &h, &l);
+        hi[(size_t)n * kw + col] = h;
+        if (split()) lo[(size_t)n * kw + col] = l;
+      }
+    }
+  pc.w_hi = dupload(hi);
+  pc.w_lo = split() ? dupload(lo) : nullptr;
+  pc.bias = dupload(bias);
+  push_conv_op(up_name + "+" + skip_name.substr(skip_name.rfind('.') == std::string::npos ? 0 : skip_name.rfind('.') + 1), in, pc, 1, ncols, o,
+               out, STORE_SHUFFLE2, cout);
   return out;
 }
 
@@ -672,12 +735,9 @@ Act* Engine::build_neck(const WeightBlob& blob, const std::string& p, const Act*
   const Act* x = ctx;
   for (int blk = 0; blk < 3; ++blk) {
     const std::string up = p + "upsample_layer_" + std::to_string(blk), sk = p + "skip_link_layer_" + std::to_string(blk);
-    Act* u = add_convT(up, x, blob.get(up + ".weight").data, blob.get(up + ".bias").data, up_c[blk], ConvOpts{});
-    ConvOpts so;  // d = upsample(x) + skip(feature): second GEMM accumulates in place on the pixel-shuffled tensor
-    so.res_mode = RES_ADD;
-    so.res = u;
-    add_conv(sk, feats[3 - blk], blob.get(sk + ".weight").data, blob.get(sk + ".bias").data, up_c[blk], 1, so, u);
-    x = u;
+    // d = upsample(x) + skip(feature): one GEMM over K = [x channels | feature channels]
+    x = add_convT_skip(up, sk, x, feats[3 - blk], blob.get(up + ".weight").data, blob.get(up + ".bias").data,
+                       blob.get(sk + ".weight").data, blob.get(sk + ".bias").data, up_c[blk]);
     for (int k = 0; k < 2; ++k) {
       const std::string dl = p + "decode_layer_" + std::to_string(2 * blk + k);
       ConvOpts o;
@@ -704,11 +764,8 @@ void Engine::build_head(const WeightBlob& blob, const std::string& p, const Act*
     c_last = 3;
   } else {  // scene_seg_head.py:21-44, scene_3d_head.py:23-47, domain_seg_head.py:21-44
     const int c9 = kind_ == 1 ? 128 : 64;
-    Act* u = add_convT(p + "upsample_layer_3", x, W("upsample_layer_3"), B("upsample_layer_3"), 256, ConvOpts{});
-    ConvOpts so;
-    so.res_mode = RES_ADD;
-    so.res = u;
-    add_conv(p + "skip_link_layer_3", feats[0], W("skip_link_layer_3"), B("skip_link_layer_3"), 256, 1, so, u);
+    const Act* u = add_convT_skip(p + "upsample_layer_3", p + "skip_link_layer_3", x, feats[0], W("upsample_layer_3"),
+                                  B("upsample_layer_3"), W("skip_link_layer_3"), B("skip_link_layer_3"), 256);
     x = add_conv(p + "decode_layer_6", u, W("decode_layer_6"), B("decode_layer_6"), 256, 3, gelu);
     x = add_conv(p + "decode_layer_7", x, W("decode_layer_7"), B("decode_layer_7"), 128, 3, gelu);
     x = add_convT(p + "upsample_layer_4", x, W("upsample_layer_4"), B("upsample_layer_4"), 128, ConvOpts{});

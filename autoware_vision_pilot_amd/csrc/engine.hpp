@@ -53,6 +53,7 @@ struct ConvOpts {
   const Act* res = nullptr;
   int tile = -1, bk = -1, nsplit = -1;
   float* logits_out = nullptr;  // STORE_NCHW_F32 target
+  const Act* in2 = nullptr;     // K-extension tensor of the fused ConvTranspose + skip-link GEMM (add_convT_skip)
 };
 
 class Engine {
@@ -101,6 +102,9 @@ class Engine {
   Act* new_act(const std::string& name, int creal, int h, int w);
   Act* add_conv(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout, int ks,
                 const ConvOpts& o, Act* out_override = nullptr);
+  Act* add_convT_skip(const std::string& up_name, const std::string& skip_name, const Act* in, const Act* skip_in,
+                      const std::vector<float>& wt, const std::vector<float>& bt, const std::vector<float>& ws,
+                      const std::vector<float>& bs, int cout);
   Act* add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
                  const ConvOpts& o);
   void run_eager();

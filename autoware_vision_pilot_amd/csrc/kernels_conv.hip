@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int wco = wave / WPX, wpx = wave % WPX;
   const int M = p.H * p.W;
   const int m0 = blockIdx.x * PX_TILE, co0 = blockIdx.y * CO_TILE;
-  const int KC = p.Cin / BK;
+  const int Kw = p.Cin + p.Cin2;  // weight row length; Cin2 > 0 only for the fused ConvTranspose + skip-link GEMM (ks == 1)
+  const int KC = Kw / BK;
   const int S = p.ks * p.ks * KC;
   const int s_begin = (int)(((long long)S * blockIdx.z) / p.nsplit);
   const int s_end = (int)(((long long)S * (blockIdx.z + 1)) / p.nsplit);
@@ -54,11 +55,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
     const int idx = tid + 256 * i, row = idx / CH, ch = idx % CH;
-    a_off[i] = (size_t)(co0 + row) * p.Cin + ch * 8;
+    a_off[i] = (size_t)(co0 + row) * Kw + ch * 8;
     a_lds[i] = row * ROWB + ch * 16;
   }
   int b_y[B_ITERS], b_x[B_ITERS], b_lds[B_ITERS], b_ch[B_ITERS];
   int a_off32[A_ITERS], b_off32[B_ITERS];  // K1 fast path: element offsets of the K=0 chunk (-1 = row outside the image)
+  int b2_off32[B_ITERS];                   // same for the K extension tensor (quadrant pixel of the 2H x 2W image)
+  const int quad = p.Cin2 > 0 ? co0 / p.Cstore : 0;
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) a_off32[i] = (int)a_off[i];
 #pragma unroll
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     b_ch[i] = ch * 8;
     b_lds[i] = row * ROWB + ch * 16;
     b_off32[i] = ok ? m * p.Cin + ch * 8 : -1;
+    b2_off32[i] = ok ? ((2 * y + (quad >> 1)) * (2 * p.W) + 2 * b_x[i] + (quad & 1)) * p.Cin2 + ch * 8 : -1;
   }
 
   // Staging registers: a DEPTH-deep ring of K-step tiles, indexed by COMPILE-TIME slots (the K loop is unrolled by
@@ -105,13 +109,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + (a_off32[i] + c0_));                        \
         if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + (a_off32[i] + c0_));   \
       }                                                                                                       \
+      const bool sec_ = c0_ >= p.Cin; /* wave-uniform: this K step reads the extension tensor */              \
       _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) {                                                   \
-        const bool ok_ = b_off32[i] >= 0;                                                                     \
-        const int g_ = (ok_ ? b_off32[i] : 0) + c0_;                                                          \
-        const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in_hi + g_);                                      \
+        const int o32_ = sec_ ? b2_off32[i] : b_off32[i];                                                     \
+        const bool ok_ = o32_ >= 0;                                                                           \
+        const long long k_ = sec_ ? (long long)(c0_ - p.Cin) : (long long)c0_;                                \
+        const long long g_ = (long long)(ok_ ? o32_ : 0) + k_;                                                \
+        const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in_hi + (g_ + (sec_ ? p.in2_delta_hi : 0ll)));   \
         rb_hi[SLOT][i] = ok_ ? vh_ : zero4;                                                                   \
         if constexpr (SPLIT) {                                                                                \
-          const u32x4 vl_ = *reinterpret_cast<const u32x4*>(p.in_lo + g_);                                    \
+          const u32x4 vl_ = *reinterpret_cast<const u32x4*>(p.in_lo + (g_ + (sec_ ? p.in2_delta_lo : 0ll)));  \
           rb_lo[SLOT][i] = ok_ ? vl_ : zero4;                                                                 \
         }                                                                                                     \
       }                                                                                                       \
