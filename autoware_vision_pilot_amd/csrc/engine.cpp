@@ -96,14 +96,23 @@ void split_half(float v, half_t* hi, half_t* lo) {
 }  // namespace
 
 // ==================================================================================================== Engine
-Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id) : kind_(kind), precision_(precision), gpu_(gpu_id) {
+Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base)
+    : kind_(kind), precision_(precision), gpu_(gpu_id), base_(base) {
   if (precision != 0 && precision != 1) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     throw std::runtime_error("libvp_hip: no HIP device visible (this library has no CPU fallback)");
   if (gpu_id < 0 || gpu_id >= ndev) throw std::invalid_argument("gpu_id out of range");
   VP_HIP_CHECK(hipSetDevice(gpu_id));
-  VP_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  if (base) {
+    if (kind < 0 || base->kind_ < 0) throw std::invalid_argument("shared engines need model kinds on both sides");
+    if (base->base_) throw std::invalid_argument("the base of a shared engine must own its whole network");
+    if (base->precision_ != precision || base->gpu_ != gpu_id)
+      throw std::invalid_argument("shared engine: precision and gpu_id must equal the base engine's");
+    stream_ = base->stream_;  // same stream: this engine's launches are ordered after the base engine's
+  } else {
+    VP_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  }
   VP_HIP_CHECK(hipEventCreate(&ev0_));
   VP_HIP_CHECK(hipEventCreate(&ev1_));
   if (kind >= 0) {
@@ -123,7 +132,27 @@ Engine::~Engine() {
   if (h_mask_) hipHostFree(h_mask_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
-  if (stream_) hipStreamDestroy(stream_);
+  if (stream_ && !base_) hipStreamDestroy(stream_);
+}
+
+unsigned long long WeightBlob::group_hash(const std::string& prefix) const {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](const void* d, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(d);
+    for (size_t i = 0; i < n; ++i) {
+      h ^= b[i];
+      h *= 1099511628211ull;
+    }
+  };
+  size_t n = 0;
+  for (auto it = t_.lower_bound(prefix); it != t_.end() && it->first.compare(0, prefix.size(), prefix) == 0; ++it, ++n) {
+    const std::string suffix = it->first.substr(prefix.size());
+    mix(suffix.data(), suffix.size());
+    mix(it->second.shape.data(), it->second.shape.size() * sizeof(int));
+    mix(it->second.data.data(), it->second.data.size() * sizeof(float));
+  }
+  mix(&n, sizeof(n));
+  return h;
 }
 
 void* Engine::dalloc(size_t bytes, bool zero) {
@@ -793,6 +822,19 @@ void Engine::build_model(const WeightBlob& blob) {
        "DomainSegHead."},
       {"BEVBackbone.encoder.", "AutoSteerContext.", "EgopathNeck.", "EgoLanesHead."}};
   if (kind_ < 0 || kind_ > 3) throw std::invalid_argument("unknown model kind");
+  const Prefix& pf = P[kind_];
+  hash_bb_ = blob.group_hash(pf.bb);
+  hash_ctx_ = blob.group_hash(pf.ctx);
+  hash_neck_ = blob.group_hash(pf.neck);
+  if (base_) {
+    // Which prefix of the network is the base engine's?  Scene3D / DomainSeg are built on a pre-trained SceneSeg
+    // (scene_3d_network.py:13, domain_seg_network.py:11): same backbone parameters, DomainSeg also the same context
+    // and neck.  EgoLanes fuses all five taps before its context (ego_lanes_network.py:30-36): backbone only.
+    if (hash_bb_ != base_->hash_bb_) throw std::invalid_argument("shared engine: backbone parameters differ from the base engine's");
+    shared_level_ = 1;
+    if (kind_ != 3 && base_->kind_ != 3 && hash_ctx_ == base_->hash_ctx_ && hash_neck_ == base_->hash_neck_) shared_level_ = 2;
+  }
+  if (!base_) {
   d_input_ = static_cast<float*>(dalloc((size_t)3 * net_h() * net_w() * sizeof(float)));
   // op 0: preprocess (parameters are patched per frame geometry in ensure_tables)
   {
@@ -820,8 +862,9 @@ void Engine::build_model(const WeightBlob& blob) {
     ops_.push_back(std::move(op));
     first_net_op_ = 1;
   }
-  const Prefix& pf = P[kind_];
-  std::vector<Act*> feats = build_backbone(blob, pf.bb);
+  }  // !base_
+  std::vector<Act*> feats = base_ ? base_->feats_ : build_backbone(blob, pf.bb);
+  feats_ = feats;
   const int cctx = kind_ == 3 ? 1456 : 1280;
   const Act* deep = feats[4];
   if (kind_ == 3) {  // backbone_feature_fusion.py:13-38
@@ -841,8 +884,14 @@ void Engine::build_model(const WeightBlob& blob) {
     ops_.push_back(std::move(op));
     deep = fused;
   }
-  Act* ctx = build_context(blob, pf.ctx, deep, cctx);
-  Act* neck = build_neck(blob, pf.neck, ctx, feats, cctx);
+  Act* neck;
+  if (shared_level_ == 2) {
+    neck = base_->neck_out_;
+  } else {
+    Act* ctx = build_context(blob, pf.ctx, deep, cctx);
+    neck = build_neck(blob, pf.neck, ctx, feats, cctx);
+  }
+  neck_out_ = neck;
   build_head(blob, pf.head, neck, feats);
   decode_mode_ = kind_ == 3 ? 1 : 0;
 }
@@ -933,6 +982,7 @@ void Engine::ensure_tables(int h, int w) {
 }
 
 void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride) {
+  if (base_) throw std::invalid_argument("shared engine: frames go to the base engine (vp_infer on the base, then vp_infer_shared)");
   if (!frame || h < 2 || w < 2 || stride < 3 * w) throw std::invalid_argument("bad frame geometry");
   VP_HIP_CHECK(hipSetDevice(gpu_));
   const size_t need = (size_t)h * stride;
@@ -953,6 +1003,7 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride) {
 }
 
 void Engine::upload_tensor(const float* nchw) {
+  if (base_) throw std::invalid_argument("shared engine: tensors go to the base engine");
   if (!nchw) throw std::invalid_argument("null tensor");
   VP_HIP_CHECK(hipSetDevice(gpu_));
   VP_HIP_CHECK(hipMemcpyAsync(d_input_, nchw, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyHostToDevice, stream_));
@@ -992,7 +1043,11 @@ void Engine::capture_graph() {
 
 void Engine::enqueue() {
   VP_HIP_CHECK(hipSetDevice(gpu_));
-  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
+  if (base_) {
+    if (!base_->have_outputs_) throw std::runtime_error("shared engine: run the base engine on a frame first");
+  } else if (!input_is_tensor_ && !d_frame_) {
+    throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
+  }
   if (!warmed_) {  // first pass is eager: sets kernel attributes and surfaces launch errors with layer names
     run_eager();
     VP_HIP_CHECK(hipStreamSynchronize(stream_));

@@ -26,6 +26,9 @@ class WeightBlob {
   const HostTensor& get(const std::string& key) const;
   bool has(const std::string& key) const { return t_.count(key) != 0; }
   size_t size() const { return t_.size(); }
+  // FNV-1a over (key suffix, shape, fp32 bytes) of every tensor whose key starts with `prefix`, in key order:
+  // equal hashes <=> the sub-network under that prefix carries the same parameters (shared-prefix engines).
+  unsigned long long group_hash(const std::string& prefix) const;
 
  private:
   std::map<std::string, HostTensor> t_;
@@ -58,7 +61,10 @@ struct ConvOpts {
 
 class Engine {
  public:
-  Engine(int kind, const WeightBlob* blob, int precision, int gpu_id);
+  // base != nullptr builds a SHARED-PREFIX engine (vp_create_shared): sub-networks whose parameters equal the base
+  // engine's (backbone; backbone + context + neck) are not rebuilt -- this engine's plan starts from the base
+  // engine's feature tensors and runs on the base engine's stream, after it, on the frame the base last processed.
+  Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base = nullptr);
   ~Engine();
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -111,6 +117,7 @@ class Engine {
   void upload_act(Act* a, const float* chw);
   hipStream_t stream() const { return stream_; }
   bool split() const { return precision_ == 1; }
+  int shared_level() const { return shared_level_; }  // 0 own network, 1 backbone shared, 2 backbone + context + neck shared
 
   std::string last_error;
 
@@ -139,6 +146,11 @@ class Engine {
 
   int kind_, precision_, gpu_;
   hipStream_t stream_ = nullptr;
+  Engine* base_ = nullptr;
+  int shared_level_ = 0;
+  unsigned long long hash_bb_ = 0, hash_ctx_ = 0, hash_neck_ = 0;
+  std::vector<Act*> feats_;   // backbone taps f0..f4 (kept for shared-prefix engines)
+  Act* neck_out_ = nullptr;
   std::vector<void*> allocs_;
   std::vector<std::unique_ptr<Act>> acts_;
   std::vector<Op> ops_;

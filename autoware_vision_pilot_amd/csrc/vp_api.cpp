@@ -34,7 +34,8 @@ int guarded(vp_engine* e, F&& f) {
   }
 }
 
-int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int precision, int gpu_id, char* err, size_t err_len) {
+int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int precision, int gpu_id, char* err, size_t err_len,
+                vp::Engine* base = nullptr) {
   if (!out) return VP_ERR_ARG;
   *out = nullptr;
   try {
@@ -47,7 +48,7 @@ int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int p
     }
     auto h = std::make_unique<vp_engine>();
     try {
-      h->impl = std::make_unique<vp::Engine>(kind, &wb, precision, gpu_id);
+      h->impl = std::make_unique<vp::Engine>(kind, &wb, precision, gpu_id, base);
     } catch (const std::invalid_argument& ex) {
       set_err(err, err_len, ex.what());
       return VP_ERR_ARG;
@@ -96,6 +97,46 @@ int vp_create(vp_engine** out, int model_kind, const char* weights_path, int pre
     return VP_ERR_WEIGHTS;
   }
   return create_impl(out, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
+}
+
+int vp_create_shared_from_memory(vp_engine** out, vp_engine* base, int model_kind, const void* blob, size_t blob_bytes, int precision,
+                                 int gpu_id, char* err, size_t err_len) {
+  if (!blob || !base || !base->impl) {
+    set_err(err, err_len, !blob ? "null weight blob" : "null base engine");
+    return VP_ERR_ARG;
+  }
+  return create_impl(out, model_kind, blob, blob_bytes, precision, gpu_id, err, err_len, base->impl.get());
+}
+
+int vp_create_shared(vp_engine** out, vp_engine* base, int model_kind, const char* weights_path, int precision, int gpu_id, char* err,
+                     size_t err_len) {
+  if (!weights_path || !*weights_path) {
+    set_err(err, err_len, "No path to weight file provided");
+    return VP_ERR_ARG;
+  }
+  std::ifstream f(weights_path, std::ios::binary | std::ios::ate);
+  if (!f) {
+    set_err(err, err_len, std::string("cannot open weight file: ") + weights_path);
+    return VP_ERR_WEIGHTS;
+  }
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  std::vector<char> buf((size_t)n);
+  if (!f.read(buf.data(), n)) {
+    set_err(err, err_len, "short read on weight file");
+    return VP_ERR_WEIGHTS;
+  }
+  return vp_create_shared_from_memory(out, base, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
+}
+
+int vp_shared_level(const vp_engine* e) { return (e && e->impl) ? e->impl->shared_level() : -1; }
+
+int vp_infer_shared(vp_engine* e) {
+  return guarded(e, [&](vp::Engine& g) {
+    if (g.shared_level() == 0) throw std::invalid_argument("vp_infer_shared: not a shared-prefix engine");
+    g.enqueue();
+    g.fetch_outputs();
+  });
 }
 
 void vp_destroy(vp_engine* e) { delete e; }

@@ -28,6 +28,10 @@ _P = C.c_void_p
 _SIGS = {
     "vp_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "vp_create_from_memory": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_shared": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_shared_from_memory": (C.c_int, [C.POINTER(_P), _P, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_shared_level": (C.c_int, [_P]),
+    "vp_infer_shared": (C.c_int, [_P]),
     "vp_destroy": (None, [_P]),
     "vp_last_error": (C.c_char_p, [_P]),
     "vp_set_input_format": (C.c_int, [_P, C.c_int, C.c_int]),
@@ -92,16 +96,24 @@ def _ptr(a):
 class Engine:
     """Thin RAII wrapper over a vp_engine handle."""
 
-    def __init__(self, kind, weights, precision="fp16", gpu_id=0):
+    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None):
+        """base: another Engine -> shared-prefix engine (vp_create_shared): reuses the base engine's backbone (and
+        context + neck when their parameters are identical) on the frame the base last processed."""
         lib = load()
         self._lib = lib
         self._h = C.c_void_p()
         err = C.create_string_buffer(512)
         k = KINDS[kind] if isinstance(kind, str) else int(kind)
         pr = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        self._base = base  # keeps the base engine alive as long as this one
         if isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)):
             buf = np.frombuffer(weights, dtype=np.uint8) if not isinstance(weights, np.ndarray) else weights
-            rc = lib.vp_create_from_memory(C.byref(self._h), k, _ptr(buf), buf.nbytes, pr, gpu_id, err, len(err))
+            if base is not None:
+                rc = lib.vp_create_shared_from_memory(C.byref(self._h), base._h, k, _ptr(buf), buf.nbytes, pr, gpu_id, err, len(err))
+            else:
+                rc = lib.vp_create_from_memory(C.byref(self._h), k, _ptr(buf), buf.nbytes, pr, gpu_id, err, len(err))
+        elif base is not None:
+            rc = lib.vp_create_shared(C.byref(self._h), base._h, k, os.fsencode(weights) if weights else b"", pr, gpu_id, err, len(err))
         else:
             rc = lib.vp_create(C.byref(self._h), k, os.fsencode(weights) if weights else b"", pr, gpu_id, err, len(err))
         if rc != 0:
@@ -146,6 +158,13 @@ class Engine:
         if f.ndim != 3 or f.shape[2] != 3:
             raise ValueError("frame must be HxWx3 uint8")
         self._ck(self._lib.vp_infer(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
+
+    def infer_shared(self):
+        """Run this shared-prefix engine's own layers on the frame its base engine processed last."""
+        self._ck(self._lib.vp_infer_shared(self._h))
+
+    def shared_level(self):
+        return self._lib.vp_shared_level(self._h)
 
     def infer_tensor(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

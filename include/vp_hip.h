@@ -72,6 +72,23 @@ int vp_create_from_memory(vp_engine** out, int model_kind, const void* blob, siz
 void vp_destroy(vp_engine* e);
 const char* vp_last_error(const vp_engine* e);
 
+/* ---- shared-prefix engines (BASELINE configs[2]: SceneSeg + Scene3D + EgoLanes on one camera) -----------
+ * The reference builds Scene3D and DomainSeg ON a pre-trained SceneSeg: Scene3DNetwork wraps its backbone
+ * (Models/model_components/scene_3d_network.py:9-13, pre_trained_backbone.py), DomainSegNetwork its backbone +
+ * context + neck (domain_seg_network.py:9-12, domain_seg_upstream.py), but every ONNX/TensorRT backend instance
+ * re-runs that prefix per model.  vp_create_shared builds an engine whose plan STARTS from the base engine's feature
+ * tensors: sub-networks whose parameters are byte-identical to the base's are not rebuilt or re-run
+ * (vp_shared_level: 1 = backbone, 2 = backbone + context + neck).  It runs on the base engine's stream:
+ *     vp_infer(base, frame, ...);  vp_infer_shared(head2);  vp_infer_shared(head3);
+ * Errors: VP_ERR_ARG if the backbone parameters differ, if precision / gpu differ from the base, or if the base is
+ * itself a shared engine.  The base must outlive its shared engines; a shared engine accepts no frames of its own. */
+int vp_create_shared(vp_engine** out, vp_engine* base, int model_kind, const char* weights_path, int precision, int gpu_id,
+                     char* err, size_t err_len);
+int vp_create_shared_from_memory(vp_engine** out, vp_engine* base, int model_kind, const void* blob, size_t blob_bytes,
+                                 int precision, int gpu_id, char* err, size_t err_len);
+int vp_shared_level(const vp_engine* e);
+int vp_infer_shared(vp_engine* e);
+
 /* ---- configuration ------------------------------------------------------------------------------------- */
 int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order);
 int vp_set_decode_mode(vp_engine* e, int decode_mode);
