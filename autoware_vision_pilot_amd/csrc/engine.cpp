@@ -304,8 +304,10 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
-    op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3>" : ",x1>") +
-                (pc.nsplit > 1 ? "+splitk" : "");
+    // ",regepi": the register-GELU single-pass epilogue instantiation (same condition as launch_halo_cfg)
+    const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1;
+    op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
+                (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
   } else {
     op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
@@ -580,6 +582,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         op.name = bp + std::to_string(j);
         op.flops = 2.0 * kk * cexp * z->H * z->W;
         op.bytes = (split() ? 4.0 : 2.0) * (y->elems() + z->elems());
+        op.kernel = S.k == 3 ? "dwconv_pool<3>" : "dwconv_pool<5>";
         op.run = [dp](hipStream_t st) { return launch_dwconv(dp, st); };
         ops_.push_back(std::move(op));
         ++j;

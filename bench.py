@@ -35,6 +35,34 @@ PEAK_FP16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 FRAME_GFLOP = {"sceneseg": 367.0, "scene3d": 397.0, "domainseg": 366.6, "egolanes": 196.7}
 
 
+def pmc_traffic(tag):
+    """HBM-side bytes per launch of the kernel instantiation behind ``tag`` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
+    1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  None if not profiled."""
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
+    if m:
+        co, px, x, reg = int(m.group(1)), int(m.group(2)), m.group(3), m.group(4)
+        pat = rf"conv3x3_halo_kernel<{co}, {px // 16}, 16, \d, \d, {'true' if x == '3' else 'false'}, 0, {'true' if reg else 'false'}>"
+    else:
+        m = re.match(r"conv_gemm<bk(\d+),co(\d+),px(\d+),x(\d)>", tag)
+        if not m:
+            pat = r"vp::" + re.escape(tag.split("<")[0]) + r"_kernel" + (re.escape("<" + tag.split("<")[1]) if "<" in tag else "")
+        else:
+            pat = rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'},"
+    hit = [v for k, v in ks.items() if re.search(pat, k)]
+    n = sum(v["launches_seen"] for v in hit)
+    if not n:
+        return None
+    f = sum(v["fetch_bytes"] * v["launches_seen"] for v in hit) / n
+    w = sum(v["write_bytes"] * v["launches_seen"] for v in hit) / n
+    return {"bytes": round(f + w), "fetch_bytes": round(f), "write_bytes": round(w)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,7 +166,6 @@ def main():
         layers, kernels = eng.layers(), eng.layer_kernels()
         fam = {}
         for (name, fl, by), k, t in zip(layers, kernels, ms):
-            k = k.replace("+splitk", "")  # same kernel instantiation (= one rocprofv3 kernel name) with or without split-K
             f = fam.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, worst=("", 0.0)))
             f["ms"] += float(t)
             f["flops"] += fl
@@ -146,16 +173,21 @@ def main():
             f["n"] += 1
             if t > f["worst"][1]:
                 f["worst"] = (name, float(t))
-        dom = max(fam, key=lambda k: fam[k]["ms"])
+        # dominant = the single kernel instantiation (= one rocprofv3 kernel name) with the largest total time; "+splitk"
+        # ops are two launches (conv + finish kernel) per timing interval, so they cannot give a per-kernel duration
+        dom = max((k for k in fam if "+splitk" not in k), key=lambda k: fam[k]["ms"])
         d = fam[dom]
         frame_tflops = FRAME_GFLOP[args.kind] * (fps_total / world) / 1e3
         if dom.startswith("conv"):
             achieved, peak, unit, bound = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_FP16_TFLOPS, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = d["bytes"] / (d["ms"] * 1e-3) / 1e9, 8000.0, "GB/s", "hbm"
+        tr = pmc_traffic(dom) if args.precision == "fp16" and args.kind == "sceneseg" else None
         roofline = {
             "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": (tr or {}).get("bytes"),
+            "traffic_detail": dict(tr, source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                              "tools/pmc_conv.py, average over that instantiation's launches)") if tr else None,
             "kernel": dom, "launches_per_frame": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
             "algorithmic_mb_per_launch": round(d["bytes"] / d["n"] / 1e6, 3),
@@ -163,6 +195,9 @@ def main():
             "kernel_time_share": round(d["ms"] / float(ms.sum()), 3),
             "whole_frame": {"achieved": round(frame_tflops, 2), "frac": round(frame_tflops / PEAK_FP16_TFLOPS, 4),
                             "gflop_per_frame": FRAME_GFLOP[args.kind], "unit": "TFLOP/s"},
+            "sustained_mfma_peak": {"value": 1700.0, "unit": "TFLOP/s",
+                                    "note": "bare v_mfma_f32_32x32x16_f16 loop on this GPU: 1570-1820 TFLOP/s, shader clock drops to "
+                                            "1.55-1.85 GHz under MFMA load (tools/mfma_peak.hip, profiles/r01_mfma_peak.txt)"},
             "note": "per-launch HIP events on the engine stream (eager replay, single stream); fp16x3 issues 3 MFMAs per "
                     "algorithmic product, achieved counts algorithmic FLOPs only",
         }
