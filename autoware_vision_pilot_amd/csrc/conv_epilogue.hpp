@@ -12,6 +12,8 @@
 // loop carries no mode branches (the all-runtime version was ~1600 instructions per pass; SQ_ACTIVE_INST showed
 // waves of the memory-bound layers spending 40 % of their life issuing it).
 #pragma once
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace vp {
@@ -20,7 +22,7 @@ namespace vp {
 // STORE / RES / ACT >= 0 fix the mode at compile time; -1 reads it from the parameter block.
 template <int STORE = -1, int RES = -1, int ACT = -1>
 __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, int m, int co, float v[8], const f32x4_t& b0,
-                                                const f32x4_t& b1) {
+                                                const f32x4_t& b1, long long o_pre = -1) {
   const int act = ACT >= 0 ? ACT : p.act;
   const int res_mode = RES >= 0 ? RES : p.res_mode;
   const int store_mode = STORE >= 0 ? STORE : p.store_mode;
@@ -36,7 +38,9 @@ __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, 
     return;
   }
   size_t o;
-  if (store_mode == STORE_SHUFFLE2) {
+  if (o_pre >= 0) {
+    o = (size_t)o_pre;  // caller tracked the output element offset incrementally (no divisions in the row loop)
+  } else if (store_mode == STORE_SHUFFLE2) {
     const int q = co / p.Cstore, c = co - q * p.Cstore;
     const int y = m / p.W, x = m - y * p.W;
     o = ((size_t)(2 * y + (q >> 1)) * (2 * p.W) + (2 * x + (q & 1))) * p.Cstore + c;
@@ -105,14 +109,38 @@ template <int STORE, int RES, int ACT, int PXT, int RPI, int PITCH, class PixMap
 __device__ __forceinline__ void epilogue_rows(const ConvGemmParams& p, const char* stage, int r0, int c8, int co, const PixMap& pix,
                                               int M) {
   const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+  if constexpr (STORE == STORE_SHUFFLE2 && std::is_same<PixMap, PixLinear>::value) {
+    // Pixel-shuffle store over a linear pixel tile: the two integer divisions (quadrant of the channel, row of the
+    // pixel) are done ONCE per thread; the row loop then advances (y, x) and the output offset incrementally.  The
+    // division-per-row version cost ~110 VALU instructions per 16-byte store and made the up-sampling GEMMs
+    // VALU-bound (37 us for 65 MB of traffic).
+    const int q = co / p.Cstore, c = co - q * p.Cstore;
+    int m = pix.m0 + r0;
+    int y = m / p.W, x = m - y * p.W;
+    const int W2 = 2 * p.W;
+    for (int r = r0; r < PXT && m < pix.M; r += RPI) {
+      const long long o = ((long long)(2 * y + (q >> 1)) * W2 + (2 * x + (q & 1))) * p.Cstore + c;
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
+      float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1, o);
+      m += RPI;
+      x += RPI;
+      while (x >= p.W) {
+        x -= p.W;
+        ++y;
+      }
+    }
+  } else {
 #pragma unroll 2
-  for (int r = r0; r < PXT; r += RPI) {
-    const int m = pix(r);
-    if (m < 0) continue;
-    const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
-    const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
-    float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-    epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1);
+    for (int r = r0; r < PXT; r += RPI) {
+      const int m = pix(r);
+      if (m < 0) continue;
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
+      float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1);
+    }
   }
 }
 
@@ -177,13 +205,16 @@ constexpr int epilogue_stage_bytes() {
   return PXT * (32 * WCO * 4 + 16);
 }
 
-// Single-pass epilogue for the hot case (fp16 tensors, bias + GELU, no residual, NHWC store) of the 3x3 kernels:
-// bias + GELU + fp16 conversion happen in REGISTERS on the whole accumulator set (straight-line code: MT*NT*16
-// independent chains per lane, so the ~16-op GELU chains interleave instead of serialising in a 2-pass row loop),
-// the fp16 tile is staged once in LDS as [pixel][CO channels] and leaves as 16-byte rows (256 B contiguous per pixel).
-// Measured on decode_layer_8 the generic 2-pass fp32-staged epilogue + prologue was 32 K of the workgroup's 77 K cycles.
-template <int PXT, int CO, int WCO, int MT, int NT, class PixMap>
-__device__ __forceinline__ void epilogue_gelu_fp16(const ConvGemmParams& p, char* stage, f32x16_t (&acc)[MT][NT], int co0, int wco,
+// Single-pass REGISTER epilogue for the VP_FP16 hot cases (one fp16 plane, bias + {none, GELU, SiLU}, no residual, no
+// split-K; NHWC or pixel-shuffle store): bias + activation + fp16 conversion happen in registers on the whole
+// accumulator set, the fp16 tile is staged ONCE in LDS as [pixel][CO channels] and leaves as 16-byte row pieces
+// (CO*2 bytes contiguous per pixel).  Versus the generic fp32-staged MT-pass epilogue: half the LDS traffic, one
+// barrier pair instead of MT, ~12 instead of ~35 instructions per 16-byte store -- the short-K GEMMs (ConvTranspose:
+// K = 128..544) spent more issue slots in the epilogue than in MFMAs, and VALU does not overlap MFMA on this part.
+// ACC_AGPR: the 3x3 kernels keep accumulators in AGPRs; reading them one group at a time (inline v_accvgpr_read)
+// stops the compiler from bursting all of them into VGPRs after the main loop (which halved occupancy).
+template <int PXT, int CO, int WCO, int MT, int NT, int ACT, int STORE, bool ACC_AGPR, class PixMap>
+__device__ __forceinline__ void epilogue_regs_fp16(const ConvGemmParams& p, char* stage, f32x16_t (&acc)[MT][NT], int co0, int wco,
                                                    int wpx, const PixMap& pix) {
   constexpr int PITCH = CO * 2 + 16;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -202,24 +233,62 @@ __device__ __forceinline__ void epilogue_gelu_fp16(const ConvGemmParams& p, char
         h4_t h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v;  // read the accumulator out of its AGPR here, not in one 128-register burst after the main loop
-          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));
-          h[r] = (half_t)gelu_f16(v + b[g][r]);
+          float v;
+          if constexpr (ACC_AGPR) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));
+          } else {
+            v = acc[i][j][4 * g + r];
+          }
+          h[r] = (half_t)apply_act(v + b[g][r], ACT);
         }
         *reinterpret_cast<h4_t*>(row + g * 16) = h;
-        __builtin_amdgcn_sched_barrier(0);  // keep the GELU chains from interleaving across groups (VGPR pressure -> occupancy)
+        if constexpr (ACT != ACT_NONE) __builtin_amdgcn_sched_barrier(0);  // keep activation chains from interleaving (VGPR pressure)
       }
     }
   }
   __syncthreads();
-  constexpr int CPR = CO / 8;
-  for (int idx = tid; idx < PXT * CPR; idx += 256) {
-    const int r = idx / CPR, c8 = idx - r * CPR;
-    const int m = pix(r);
-    const int co = co0 + c8 * 8;
-    if (m < 0 || co >= p.Ncols) continue;
-    *reinterpret_cast<h8_t*>(p.out_hi + (size_t)m * p.Cstore + co) = *reinterpret_cast<const h8_t*>(stage + r * PITCH + c8 * 16);
+  constexpr int CPR = CO / 8, RPI = 256 / CPR;
+  static_assert(256 % CPR == 0 && PXT % RPI == 0, "row loop shape");
+  const int c8 = tid % CPR, r0 = tid / CPR;
+  const int co = co0 + c8 * 8;
+  if (co >= p.Ncols) return;
+  if constexpr (STORE == STORE_SHUFFLE2 && std::is_same<PixMap, PixLinear>::value) {
+    // pixel-shuffle store: quadrant and pixel row divided ONCE, then (y, x) advance incrementally
+    const int q = co0 / p.Cstore, c = co - q * p.Cstore;  // the CO tile lies inside one quadrant (launcher checks)
+    int m = pix.m0 + r0;
+    int y = m / p.W, x = m - y * p.W;
+    const int W2 = 2 * p.W;
+    for (int r = r0; r < PXT && m < pix.M; r += RPI) {
+      const size_t o = ((size_t)(2 * y + (q >> 1)) * W2 + (2 * x + (q & 1))) * p.Cstore + c;
+      *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(stage + r * PITCH + c8 * 16);
+      m += RPI;
+      x += RPI;
+      while (x >= p.W) {
+        x -= p.W;
+        ++y;
+      }
+    }
+  } else {
+    static_assert(STORE == STORE_NHWC, "register epilogue stores NHWC or pixel-shuffled NHWC");
+#pragma unroll 4
+    for (int r = r0; r < PXT; r += RPI) {
+      const int m = pix(r);
+      if (m < 0) continue;
+      *reinterpret_cast<h8_t*>(p.out_hi + (size_t)m * p.Cstore + co) = *reinterpret_cast<const h8_t*>(stage + r * PITCH + c8 * 16);
+    }
   }
+}
+// which (activation, store) combinations have a register-epilogue instantiation; 0 = none, else a small case id
+__host__ __device__ inline int regepi_case(const ConvGemmParams& p, int co_tile, bool split) {
+  if (split || p.out_lo || p.res_mode != RES_NONE || p.nsplit != 1) return 0;
+  if (p.store_mode == STORE_NHWC) {
+    if (p.act == ACT_GELU_F16) return 1;
+    if (p.act == ACT_SILU_F16) return 2;
+    if (p.act == ACT_NONE) return 3;
+    return 0;
+  }
+  if (p.store_mode == STORE_SHUFFLE2 && p.act == ACT_NONE && p.Cstore % co_tile == 0) return 4;
+  return 0;
 }
 template <int PXT, int CO>
 constexpr int epilogue_fp16_stage_bytes() {

@@ -1,5 +1,7 @@
 #include "engine.hpp"
 
+#include "conv_epilogue.hpp"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -310,8 +312,10 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
                 (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
   } else {
+    const int epi = (ks == 1 && !sp) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
     op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
-                std::to_string(conv_tile_px(tile)) + (sp ? ",x3>" : ",x1>") + (pc.nsplit > 1 ? "+splitk" : "");
+                std::to_string(conv_tile_px(tile)) + (sp ? ",x3" : ",x1") + (epi ? ",regepi" + std::to_string(epi) + ">" : ">") +
+                (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
   }
   ops_.push_back(std::move(op));
@@ -411,7 +415,10 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
   const int cpad = out->C;
   const int ncols = 4 * cpad;
   PackedConv pc;
-  choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, o, &pc);
+  ConvOpts oo = o;
+  if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
+  if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
+  choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, oo, &pc);
   std::vector<half_t> hi((size_t)pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
   std::vector<float> bias(pc.CoutW, 0.0f);
   for (int q = 0; q < 4; ++q)
@@ -451,6 +458,7 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
   ConvOpts o;
   o.in2 = skip_in;
   if ((cin_pad | cs_pad) % 64 != 0) o.bk = 32;  // K steps must not straddle the two tensors
+  if (const char* e = std::getenv("VP_CONVT_TILE")) o.tile = std::atoi(e);
   PackedConv pc;
   choose_conv_cfg(in->H * in->W, ncols, cin_pad + cs_pad, 1, o, &pc);
   const bool fusable = cpad % conv_tile_co(pc.tile) == 0 && !(env && env[0] == '0');

@@ -24,7 +24,8 @@ namespace vp {
 
 // K1: kernel size 1 (1x1 conv / ConvTranspose-as-GEMM) -- the tap/bounds arithmetic of the general path cost ~190
 // instructions per K step against 8 MFMAs; the K1 path is one 32-bit add per load.
-template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH, bool K1>
+// EPI: 0 = generic fp32-staged epilogue; 1..4 = register epilogue case (conv_epilogue.hpp regepi_case)
+template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH, bool K1, int EPI = 0>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves per workgroup");
   constexpr int ROWB = BK * 2 + 16;   // LDS row pitch in bytes
@@ -41,12 +42,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave / WPX, wpx = wave % WPX;
   const int M = p.H * p.W;
-  const int m0 = blockIdx.x * PX_TILE, co0 = blockIdx.y * CO_TILE;
+  // XCD-aware workgroup -> tile map (see kernels_conv3x3.hip): every XCD gets a contiguous range of virtual ids.
+  // Within a range the tiles that share the LARGER operand are adjacent in time: channel tile fastest when the pixel
+  // operand is the big one (up-sampling GEMMs: the 4 quadrant tiles of a pixel tile re-read it from that XCD's L2
+  // instead of the Infinity Cache), pixel tile fastest when the weights are (20x40 layers with 1280-wide K).
+  int vid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int n_px_tiles = (M + PX_TILE - 1) / PX_TILE, n_co_tiles = p.CoutW / CO_TILE;
+  int tile_px, tile_co, zsplit;
+  if (p.CoutW > M) {  // weights larger than the pixel operand: pixel tile fastest
+    tile_px = vid % n_px_tiles;
+    const int rest = vid / n_px_tiles;
+    tile_co = rest % n_co_tiles;
+    zsplit = rest / n_co_tiles;
+  } else {
+    tile_co = vid % n_co_tiles;
+    const int rest = vid / n_co_tiles;
+    tile_px = rest % n_px_tiles;
+    zsplit = rest / n_px_tiles;
+  }
+  const int m0 = tile_px * PX_TILE, co0 = tile_co * CO_TILE;
   const int Kw = p.Cin + p.Cin2;  // weight row length; Cin2 > 0 only for the fused ConvTranspose + skip-link GEMM (ks == 1)
   const int KC = Kw / BK;
   const int S = p.ks * p.ks * KC;
-  const int s_begin = (int)(((long long)S * blockIdx.z) / p.nsplit);
-  const int s_end = (int)(((long long)S * (blockIdx.z + 1)) / p.nsplit);
+  const int s_begin = (int)(((long long)S * zsplit) / p.nsplit);
+  const int s_end = (int)(((long long)S * (zsplit + 1)) / p.nsplit);
   const int half_k = p.ks >> 1;
 
   // ---- per-thread staging assignment
@@ -222,8 +245,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 
   // ---- epilogue through LDS (conv_epilogue.hpp); the main loop's last barrier has retired every LDS read
   const PixLinear pix{m0, M};
+  if constexpr (EPI == 1) {
+    epilogue_regs_fp16<PX_TILE, CO_TILE, WCO, MT, NT, ACT_GELU_F16, STORE_NHWC, false>(p, smem, acc, co0, wco, wpx, pix);
+  } else if constexpr (EPI == 2) {
+    epilogue_regs_fp16<PX_TILE, CO_TILE, WCO, MT, NT, ACT_SILU_F16, STORE_NHWC, false>(p, smem, acc, co0, wco, wpx, pix);
+  } else if constexpr (EPI == 3) {
+    epilogue_regs_fp16<PX_TILE, CO_TILE, WCO, MT, NT, ACT_NONE, STORE_NHWC, false>(p, smem, acc, co0, wco, wpx, pix);
+  } else if constexpr (EPI == 4) {
+    epilogue_regs_fp16<PX_TILE, CO_TILE, WCO, MT, NT, ACT_NONE, STORE_SHUFFLE2, false>(p, smem, acc, co0, wco, wpx, pix);
+  } else {
 #pragma unroll
-  for (int i = 0; i < MT; ++i) epilogue_pass<PX_TILE, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, blockIdx.z);
+    for (int i = 0; i < MT; ++i) epilogue_pass<PX_TILE, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, zsplit);
+  }
 }
 
 // Sums the split-K partial slabs in a fixed order (deterministic) and runs the shared epilogue.
@@ -258,20 +291,29 @@ template <int BK, int CO, int PX, int WCO, int WPX, bool SPLIT>
 static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int ROWB = BK * 2 + 16;
   constexpr int lds_main = 2 * (CO + PX) * ROWB * (SPLIT ? 2 : 1);
-  constexpr int lds = lds_main > epilogue_stage_bytes<PX, WCO>() ? lds_main : epilogue_stage_bytes<PX, WCO>();
+  constexpr int lds_a = lds_main > epilogue_stage_bytes<PX, WCO>() ? lds_main : epilogue_stage_bytes<PX, WCO>();
+  constexpr int lds = lds_a > epilogue_fp16_stage_bytes<PX, CO>() ? lds_a : epilogue_fp16_stage_bytes<PX, CO>();
   // prefetch depth: as deep as the register budget allows (staging = DEPTH * (A+B chunks) * 16 B per lane)
   constexpr int chunks = ((CO + PX) * (BK / 8) + 255) / 256 * (SPLIT ? 2 : 1);
   constexpr int DEPTH = chunks <= 4 ? 4 : (chunks <= 8 ? 3 : 2);
   const bool k1 = p.ks == 1;
-  auto k = k1 ? conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, true> : conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, false>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[k1]) {
+  // register epilogue (fp16 engines, K1 GEMMs only: that is where the epilogue dominates); see regepi_case
+  const int epi = (k1 && !SPLIT) ? regepi_case(p, CO, SPLIT) : 0;
+  void (*k)(const ConvGemmParams) = k1 ? conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, true, 0> : conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, false, 0>;
+  if constexpr (!SPLIT) {
+    if (epi == 1) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 1>;
+    if (epi == 2) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 2>;
+    if (epi == 3) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 3>;
+    if (epi == 4) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 4>;
+  }
+  static bool attr_done[2][5] = {};
+  if (!attr_done[k1][epi]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_done[k1] = true;
+    attr_done[k1][epi] = true;
   }
   const int M = p.H * p.W;
-  dim3 grid((M + PX - 1) / PX, p.CoutW / CO, p.nsplit);
+  dim3 grid(((M + PX - 1) / PX) * (p.CoutW / CO) * p.nsplit);  // decoded in the kernel (XCD-aware)
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -20,7 +20,7 @@ namespace vp {
 
 // ABL: ablation bits for tools/halo_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA,
 // 4 = no LDS fragment reads, 8 = no barrier); always 0 in the library.
-// FASTEPI: single-pass register GELU + fp16-staged epilogue (conv_epilogue.hpp epilogue_gelu_fp16); the launcher
+// FASTEPI: single-pass register GELU + fp16-staged epilogue (conv_epilogue.hpp epilogue_regs_fp16); the launcher
 // selects it when the layer is bias + ACT_GELU_F16 (VP_FP16 engines), no residual, NHWC, no split-K.
 template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0, bool FASTEPI = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams p) {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
   // ---- epilogue through LDS (conv_epilogue.hpp): accumulators -> stage[pixel][channel] -> coalesced 16-byte stores
   const PixPatch<TW> pix{y0, x0, p.H, p.W};
   if constexpr (FASTEPI) {
-    epilogue_gelu_fp16<PX, CO_TILE, WCO, MT, NT>(p, smem, acc, co0, wco, wpx, pix);
+    epilogue_regs_fp16<PX, CO_TILE, WCO, MT, NT, ACT_GELU_F16, STORE_NHWC, true>(p, smem, acc, co0, wco, wpx, pix);
   } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) epilogue_pass<PX, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, zsplit);

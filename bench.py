@@ -49,11 +49,12 @@ def pmc_traffic(tag):
         co, px, x, reg = int(m.group(1)), int(m.group(2)), m.group(3), m.group(4)
         pat = rf"conv3x3_halo_kernel<{co}, {px // 16}, 16, \d, \d, {'true' if x == '3' else 'false'}, 0, {'true' if reg else 'false'}>"
     else:
-        m = re.match(r"conv_gemm<bk(\d+),co(\d+),px(\d+),x(\d)>", tag)
+        m = re.match(r"conv_gemm<bk(\d+),co(\d+),px(\d+),x(\d)(?:,regepi(\d))?>", tag)
         if not m:
             pat = r"vp::" + re.escape(tag.split("<")[0]) + r"_kernel" + (re.escape("<" + tag.split("<")[1]) if "<" in tag else "")
         else:
-            pat = rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'},"
+            pat = (rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'}, "
+                   rf"\d, (true|false), {m.group(5) or 0}>")
     hit = [v for k, v in ks.items() if re.search(pat, k)]
     n = sum(v["launches_seen"] for v in hit)
     if not n:
