@@ -341,7 +341,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
       const long long t256 = cdiv(in->H, 16) * cdiv(in->W, 16), t128 = cdiv(in->H, 8) * cdiv(in->W, 16);
       if (ncols <= 32) {
-        halo = 4;
+        halo = (std::getenv("VP_HEAD_TILE5") && t256 >= 400) ? 5 : 4;
       } else if (ncols % 128 != 0) {
         halo = (!split() && t256 * cdiv(ncols, 64) >= 400) ? 2 : 3;
       } else {

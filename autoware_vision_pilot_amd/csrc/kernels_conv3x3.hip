@@ -275,20 +275,22 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
   return e;
 }
 
-// halo tile ids: 0 = 128co x (16x16)px, 1 = 128co x (8x16)px, 2 = 64co x (16x16)px, 3 = 64co x (8x16)px, 4 = 32co x (8x16)px
+// halo tile ids: 0 = 128co x (16x16)px, 1 = 128co x (8x16)px, 2 = 64co x (16x16)px, 3 = 64co x (8x16)px, 4 = 32co x (8x16)px,
+//                5 = 32co x (16x16)px
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st) {
 #define VP_HCASE(T, CO, TH, TW, WCO, WPX) \
   if (tile == T) return split ? launch_halo_cfg<CO, TH, TW, WCO, WPX, true>(p, st) : launch_halo_cfg<CO, TH, TW, WCO, WPX, false>(p, st);
   VP_HCASE(1, 128, 8, 16, 2, 2)
   VP_HCASE(3, 64, 8, 16, 2, 2)
   VP_HCASE(4, 32, 8, 16, 1, 4)
+  VP_HCASE(5, 32, 16, 16, 1, 4)
 #undef VP_HCASE
   if (tile == 0) return split ? hipErrorInvalidValue : launch_halo_cfg<128, 16, 16, 2, 2, false>(p, st);
   if (tile == 2) return split ? hipErrorInvalidValue : launch_halo_cfg<64, 16, 16, 2, 2, false>(p, st);
   return hipErrorInvalidValue;
 }
 int halo_tile_co(int tile) { return tile <= 1 ? 128 : (tile <= 3 ? 64 : 32); }
-int halo_tile_px(int tile) { return (tile == 0 || tile == 2) ? 256 : 128; }
-int halo_tile_th(int tile) { return (tile == 0 || tile == 2) ? 16 : 8; }
+int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5) ? 256 : 128; }
+int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5) ? 16 : 8; }
 
 }  // namespace vp
