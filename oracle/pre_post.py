@@ -78,9 +78,9 @@ def normalize_planes(img_u8, input_is_bgr, planes_rgb):
     return np.ascontiguousarray(out.transpose(2, 0, 1)).astype(np.float32)
 
 
-def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False):
-    """Any-size u8 frame -> 1x3x320x640 fp32 network input."""
-    return normalize_planes(resize_bilinear_u8(frame_u8), input_is_bgr, planes_rgb)[None]
+def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False, out_h=NET_H, out_w=NET_W):
+    """Any-size u8 frame -> 1x3xout_hxout_w fp32 network input (320x640 for the scene networks, 512x1024 for AutoDrive)."""
+    return normalize_planes(resize_bilinear_u8(frame_u8, out_h, out_w), input_is_bgr, planes_rgb)[None]
 
 
 # ------------------------------------------------------------------------------------------ decode
