@@ -26,7 +26,8 @@ struct ActView {
 // activation may trade fp32-class accuracy for VALU instructions (measured on gfx950: VALU work does NOT hide behind
 // another wave's MFMAs, tools/mfma_valu_overlap.hip, so epilogue instructions are paid in full).  VP_FP16X3 (the
 // parity mode) always uses the base codes.
-enum ActFn { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_F16 = 4, ACT_GELU_F16 = 5, ACT_SILU_F16 = 6, ACT_SIGMOID_F16 = 7 };
+enum ActFn { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_F16 = 4, ACT_GELU_F16 = 5, ACT_SILU_F16 = 6, ACT_SIGMOID_F16 = 7,
+             ACT_RELU = 8, ACT_TANH = 9, ACT_SILU2 = 10 /* SiLU(SiLU(x)): common_layers.py:211-213 */ };
 enum ResMode { RES_NONE = 0, RES_ADD = 1, RES_MULADD = 2 };  // MULADD: out = v*res + res  (scene_context.py:56)
 enum StoreMode { STORE_NHWC = 0, STORE_SHUFFLE2 = 1, STORE_NCHW_F32 = 2 };
 
@@ -56,6 +57,11 @@ struct ConvGemmParams {
   // distance from in_hi/in_lo to that tensor's planes (one base pointer keeps the loads plain global loads).
   int Cin2;
   long long in2_delta_hi, in2_delta_lo;
+  // strided 3x3 (AutoDrive Conv k3 s2, common_layers.py:5-14): H, W stay the OUTPUT size; the taps read the
+  // Hin x Win input at (y*stride + dy, x*stride + dx).  stride <= 1 means 1 and Hin = H, Win = W.
+  int stride, Hin, Win;
+  // activation applied AFTER the residual (CTX: SiLU(c4*x + x), common_layers.py:222-224); 0 = none
+  int post_act;
   float* partial;      // [nsplit][M][CoutW] fp32 scratch
 };
 
@@ -98,6 +104,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == ACT_GELU_F16) return gelu_f16(v);
   if (act == ACT_SILU_F16) return silu_f16(v);
   if (act == ACT_SIGMOID_F16) return sigmoid_f16(v);
+  if (act == ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_SILU2) return silu_f(silu_f(v));
   return v;
 }
 

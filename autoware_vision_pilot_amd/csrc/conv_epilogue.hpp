@@ -60,6 +60,10 @@ __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, 
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = (res_mode == RES_ADD) ? (v[r] + r8[r]) : (v[r] * r8[r] + r8[r]);
   }
+  if (STORE < 0 && p.post_act != ACT_NONE) {  // only the all-runtime instantiation carries it (the engine routes such ops there)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = apply_act(v[r], p.post_act);
+  }
   h8_t hi;
 #pragma unroll
   for (int r = 0; r < 8; ++r) hi[r] = (half_t)v[r];
@@ -181,7 +185,7 @@ __device__ __forceinline__ void epilogue_pass(const ConvGemmParams& p, char* sta
         *reinterpret_cast<f32x4_t*>(dst + 4) = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
       }
     } else {
-      const int key = p.store_mode * 100 + p.res_mode * 10 + p.act;
+      const int key = p.post_act != ACT_NONE ? -1 : p.store_mode * 100 + p.res_mode * 10 + p.act;
 #define VP_ROWS(S, R, A) epilogue_rows<S, R, A, PXT, RPI, PITCH>(p, stage, r0, c8, co, pix, M)
       switch (key) {
         case STORE_NHWC * 100 + RES_NONE * 10 + ACT_GELU: VP_ROWS(STORE_NHWC, RES_NONE, ACT_GELU); break;   // decoder 3x3
@@ -280,7 +284,7 @@ __device__ __forceinline__ void epilogue_regs_fp16(const ConvGemmParams& p, char
 }
 // which (activation, store) combinations have a register-epilogue instantiation; 0 = none, else a small case id
 __host__ __device__ inline int regepi_case(const ConvGemmParams& p, int co_tile, bool split) {
-  if (split || p.out_lo || p.res_mode != RES_NONE || p.nsplit != 1) return 0;
+  if (split || p.out_lo || p.res_mode != RES_NONE || p.nsplit != 1 || p.post_act != ACT_NONE) return 0;
   if (p.store_mode == STORE_NHWC) {
     if (p.act == ACT_GELU_F16) return 1;
     if (p.act == ACT_SILU_F16) return 2;

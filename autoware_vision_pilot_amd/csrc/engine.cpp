@@ -89,6 +89,29 @@ Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) {
   return f;
 }
 
+// common_layers.py:5-14 Conv: `conv` (no bias) + `norm` (BatchNorm2d eps 1e-3)
+Folded fold_conv_norm(const WeightBlob& blob, const std::string& p) {
+  const HostTensor& w = blob.get(p + ".conv.weight");
+  const HostTensor& g = blob.get(p + ".norm.weight");
+  const HostTensor& beta = blob.get(p + ".norm.bias");
+  const HostTensor& mean = blob.get(p + ".norm.running_mean");
+  const HostTensor& var = blob.get(p + ".norm.running_var");
+  if (w.shape.size() != 4) throw std::runtime_error("conv weight rank != 4: " + p);
+  Folded f;
+  f.cout = w.shape[0];
+  f.cin = w.shape[1];
+  f.k = w.shape[2];
+  const size_t per = (size_t)f.cin * f.k * f.k;
+  f.w.resize(w.data.size());
+  f.b.resize(f.cout);
+  for (int co = 0; co < f.cout; ++co) {
+    const float s = g.data[co] / std::sqrt(var.data[co] + 1e-3f);
+    for (size_t i = 0; i < per; ++i) f.w[co * per + i] = w.data[co * per + i] * s;
+    f.b[co] = beta.data[co] - mean.data[co] * s;
+  }
+  return f;
+}
+
 void split_half(float v, half_t* hi, half_t* lo) {
   const half_t h = (half_t)v;
   *hi = h;
@@ -100,7 +123,7 @@ void split_half(float v, half_t* hi, half_t* lo) {
 // ==================================================================================================== Engine
 Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base)
     : kind_(kind), precision_(precision), gpu_(gpu_id), base_(base) {
-  if (precision != 0 && precision != 1) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3");
+  if ((precision & 15) > 1 || (precision & ~17) != 0) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3 (optionally | VP_WEIGHTS_FP8)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     throw std::runtime_error("libvp_hip: no HIP device visible (this library has no CPU fallback)");
@@ -119,7 +142,13 @@ Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engi
   VP_HIP_CHECK(hipEventCreate(&ev1_));
   if (kind >= 0) {
     if (!blob) throw std::invalid_argument("weights required");
-    build_model(*blob);
+    if (fp8_weights()) {
+      WeightBlob q = *blob;
+      q.quantize_fp8_e4m3();
+      build_model(q);
+    } else {
+      build_model(*blob);
+    }
     finish_plan();
   }
 }
@@ -155,6 +184,29 @@ unsigned long long WeightBlob::group_hash(const std::string& prefix) const {
   }
   mix(&n, sizeof(n));
   return h;
+}
+
+void WeightBlob::quantize_fp8_e4m3() {
+  for (auto& kv : t_) {
+    HostTensor& t = kv.second;
+    const std::string& k = kv.first;
+    if (t.shape.size() < 2 || k.size() < 7 || k.compare(k.size() - 7, 7, ".weight") != 0) continue;
+    const size_t rows = (size_t)t.shape[0], per = t.data.size() / rows;
+    for (size_t r = 0; r < rows; ++r) {
+      float* v = t.data.data() + r * per;
+      double amax = 0.0;
+      for (size_t i = 0; i < per; ++i) amax = std::max(amax, std::fabs((double)v[i]));
+      const double scale = std::max(amax, 1e-30) / 448.0;
+      for (size_t i = 0; i < per; ++i) {
+        const double x = (double)v[i] / scale, mag = std::fabs(x);
+        double e = std::floor(std::log2(std::max(mag, std::ldexp(1.0, -9))));
+        e = std::min(std::max(e, -6.0), 8.0);
+        const double step = std::ldexp(1.0, (int)e - 3);
+        const double q = std::min(std::nearbyint(mag / step) * step, 448.0) * (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0));
+        v[i] = (float)(q * scale);
+      }
+    }
+  }
 }
 
 void* Engine::dalloc(size_t bytes, bool zero) {
@@ -225,10 +277,15 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
 void Engine::push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
                           int store_mode, int cout_real) {
   ConvGemmParams p{};
+  const int cstride = std::max(1, o.stride);
   p.in_hi = in->hi;
   p.in_lo = in->lo;
-  p.H = in->H;
-  p.W = in->W;
+  p.H = in->H / cstride;  // output size (== input size for stride 1)
+  p.W = in->W / cstride;
+  p.stride = cstride;
+  p.Hin = in->H;
+  p.Win = in->W;
+  p.post_act = o.post_act;
   p.Cin = in->C;
   p.w_hi = pc.w_hi;
   p.w_lo = pc.w_lo;
@@ -236,7 +293,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.ks = ks;
   p.Ncols = ncols;
   p.CoutW = pc.CoutW;
-  p.act = (o.act != ACT_NONE && !split()) ? (o.act | ACT_F16) : o.act;  // VP_FP16: reduced-instruction activations (common.hpp)
+  p.act = (o.act >= ACT_GELU && o.act <= ACT_SIGMOID && !split()) ? (o.act | ACT_F16) : o.act;  // VP_FP16: reduced-instruction activations (common.hpp)
   p.res_mode = o.res_mode;
   p.res_hi = o.res ? o.res->hi : nullptr;
   p.res_lo = o.res ? o.res->lo : nullptr;
@@ -252,7 +309,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     p.in2_delta_hi = o.in2->hi - in->hi;
     p.in2_delta_lo = (in->lo && o.in2->lo) ? o.in2->lo - in->lo : 0;
   }
-  const int M = in->H * in->W;
+  const int M = p.H * p.W;
   p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
   const int tile = pc.tile, bk = pc.bk;
   const bool sp = split();
@@ -326,13 +383,15 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
                       const ConvOpts& o, Act* out_override) {
   const int cin = in->Creal, cin_pad = in->C;
   if (w.size() != (size_t)cout * cin * ks * ks) throw std::runtime_error("conv weight size mismatch: " + name);
-  const int M = in->H * in->W;
+  const int cstride = std::max(1, o.stride);
+  if (cstride > 1 && (ks != 3 || in->H % cstride || in->W % cstride)) throw std::invalid_argument("strided conv: 3x3 on even maps only: " + name);
+  const int M = (in->H / cstride) * (in->W / cstride);
   const int ncols = round_up(cout, 32);
   PackedConv pc;
   const int taps = ks * ks;
   // ---- 3x3: LDS-resident halo kernel (kernels_conv3x3.hip) unless overridden (tile >= 100 selects a halo tile)
   int halo = -1;
-  if (ks == 3 && in->H >= 8 && in->W >= 16) {
+  if (ks == 3 && cstride == 1 && in->H >= 8 && in->W >= 16) {
     static const char* env = std::getenv("VP_CONV3X3");
     const bool force_v1 = (env && std::strcmp(env, "v1") == 0) || (o.tile >= 0 && o.tile < 100);
     if (o.tile >= 100) {
@@ -400,7 +459,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   if (o.logits_out) {
     store = STORE_NCHW_F32;
   } else {
-    out = out_override ? out_override : new_act(name, cout, in->H, in->W);
+    out = out_override ? out_override : new_act(name, cout, in->H / cstride, in->W / cstride);
   }
   push_conv_op(name, in, pc, ks, ncols, o, out, store, cout);
   return out;
@@ -741,6 +800,7 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
       bk[co] = b.data[co];
     }
     CtxConv1Params cp{};
+    cp.act = ACT_GELU;
     cp.map = x;
     cp.H = deep->H;
     cp.W = deep->W;
@@ -832,6 +892,11 @@ void Engine::build_model(const WeightBlob& blob) {
       {"DomainSegUpstream.pretrainedBackBone.encoder.", "DomainSegUpstream.pretrainedContext.", "DomainSegUpstream.pretrainedNeck.",
        "DomainSegHead."},
       {"BEVBackbone.encoder.", "AutoSteerContext.", "EgopathNeck.", "EgoLanesHead."}};
+  if (kind_ == 4) {
+    if (base_) throw std::invalid_argument("AutoDrive engines cannot be shared-prefix engines");
+    build_autodrive(blob);
+    return;
+  }
   if (kind_ < 0 || kind_ > 3) throw std::invalid_argument("unknown model kind");
   const Prefix& pf = P[kind_];
   hash_bb_ = blob.group_hash(pf.bb);
@@ -907,16 +972,286 @@ void Engine::build_model(const WeightBlob& blob) {
   decode_mode_ = kind_ == 3 ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------ AutoDrive
+// autodrive_network.py:32-36, autodrive_backbone.py:8-48, autodrive_head.py:70-87, common_layers.py (Conv, CTX, SPPF,
+// C2PSA, PSABlock, Attention).  One plan: preprocess -> backbone (P5 256x16x32) -> [shift: previous frame's P5 to the
+// first half of the 512-channel head input] -> [place: this frame's P5 to the second half] -> head -> 3 scalars.
+void Engine::build_autodrive(const WeightBlob& blob) {
+  auto T = [&](const std::string& k) -> const HostTensor& { return blob.get(k); };
+  auto push = [&](const std::string& name, const char* kernel, std::function<hipError_t(hipStream_t)> fn, double flops = 0, double bytes = 0) {
+    Op op;
+    op.name = name;
+    op.kernel = kernel;
+    op.flops = flops;
+    op.bytes = bytes;
+    op.run = std::move(fn);
+    ops_.push_back(std::move(op));
+  };
+  d_input_ = static_cast<float*>(dalloc((size_t)3 * net_h() * net_w() * sizeof(float)));
+  plane_order_ = 1;  // RGB planes, ImageNet constants (visualizations/AutoDrive/video_visualization.py:29-33)
+  push("preprocess", "preprocess", [this](hipStream_t st) {
+    PreprocessParams pp{};
+    pp.frame = d_frame_;
+    pp.stride = frame_stride_;
+    pp.xtab = d_xtab_;
+    pp.ytab = d_ytab_;
+    pp.out_h = net_h();
+    pp.out_w = net_w();
+    static const float mean_rgb[3] = {0.485f, 0.456f, 0.406f}, std_rgb[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c) {
+      const int colour = plane_order_ == 1 ? c : 2 - c;
+      pp.src_c[c] = pixel_format_ == 1 ? colour : 2 - colour;
+      pp.mean[c] = mean_rgb[colour];
+      pp.stdv[c] = std_rgb[colour];
+    }
+    pp.out = d_input_;
+    return launch_preprocess(pp, st);
+  });
+  first_net_op_ = 1;
+
+  // ---- p1: Conv 3->16 k3 s2 + BN + SiLU on the fp32 planes (the stem kernel computes 32 output channels: 16 are padding)
+  Act* x;
+  {
+    Folded f = fold_conv_norm(blob, "backbone.p1");
+    if (f.cout > 32 || f.cin != 3 || f.k != 3) throw std::runtime_error("backbone.p1 shape mismatch");
+    std::vector<float> wk(27 * 32, 0.0f), bk(32, 0.0f);
+    for (int co = 0; co < f.cout; ++co) {
+      for (int k = 0; k < 27; ++k) wk[k * 32 + co] = f.w[co * 27 + k];
+      bk[co] = f.b[co];
+    }
+    StemParams sp{};
+    sp.in = d_input_;
+    sp.H = net_h();
+    sp.W = net_w();
+    sp.w = dupload(wk);
+    sp.b = dupload(bk);
+    x = new_act("backbone.p1", f.cout, net_h() / 2, net_w() / 2);
+    sp.out = x->view();
+    push("backbone.p1", "stem", [sp](hipStream_t st) { return launch_stem(sp, st); }, 2.0 * 27 * f.cout * x->H * x->W,
+         4.0 * 3 * net_h() * net_w() + 2.0 * x->elems());
+  }
+  auto conv_bn = [&](const std::string& name, const Act* in, int ks, int stride, int act) -> Act* {
+    Folded f = fold_conv_norm(blob, name);
+    ConvOpts o;
+    o.act = act;
+    o.stride = stride;
+    return add_conv(name, in, f.w, f.b, f.cout, ks, o);
+  };
+  // ---- p2..p5: strided conv + CTX (common_layers.py:183-227)
+  const char* stage_names[4] = {"backbone.p2", "backbone.p3", "backbone.p4", "backbone.p5"};
+  for (int si = 0; si < 4; ++si) {
+    const std::string sn = stage_names[si];
+    Act* a = conv_bn(sn + ".0", x, 3, 2, ACT_SILU);
+    const std::string cp = sn + ".1";
+    const int HW = a->H * a->W, C = a->Creal;
+    // mean over H, W (:206) as slab partial sums
+    const int nslab = std::max(1, std::min(64, HW / 512));
+    float* partial = static_cast<float*>(dalloc((size_t)nslab * a->C * sizeof(float)));
+    {
+      PoolParams pp{a->view(), partial, nslab};
+      push(cp + ".mean", "pool_partial", [pp](hipStream_t st) { return launch_pool_partial(pp, st); });
+    }
+    // exp0: Conv1d(C -> H*W, k3, pad 1) on a length-1 sequence == the centre tap as a [H*W][C] matrix (:210), SiLU twice (:211-213)
+    const HostTensor& ew = T(cp + ".exp0.weight");
+    const HostTensor& eb = T(cp + ".exp0.bias");
+    if (ew.shape.size() != 3 || ew.shape[0] != HW || ew.shape[1] != C || ew.shape[2] != 3) throw std::runtime_error("exp0 shape mismatch: " + cp);
+    std::vector<float> wm((size_t)HW * a->C, 0.0f);
+    for (int n = 0; n < HW; ++n)
+      for (int c = 0; c < C; ++c) wm[(size_t)n * a->C + c] = ew.data[((size_t)n * C + c) * 3 + 1];
+    FcParams fp{};
+    fp.w = dupload(wm);
+    fp.b = dupload(eb.data);
+    fp.N = HW;
+    fp.K = a->C;
+    fp.act = ACT_SILU2;
+    fp.out = static_cast<float*>(dalloc((size_t)HW * sizeof(float)));
+    fp.partial = partial;
+    fp.nslab = nslab;
+    fp.Kstride = a->C;
+    fp.inv_hw = 1.0f / (float)HW;
+    push(cp + ".exp0", "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, 4.0 * HW * C);
+    // ctx0: conv3x3 1 -> C/2 + SiLU (:216-217)
+    const HostTensor& w0 = T(cp + ".ctx0.weight");
+    const HostTensor& b0 = T(cp + ".ctx0.bias");
+    const int c0n = w0.shape[0];
+    Act* c2 = new_act(cp + ".ctx0", c0n, a->H, a->W);
+    {
+      std::vector<float> wk((size_t)9 * c2->C, 0.0f), bk(c2->C, 0.0f);
+      for (int co = 0; co < c0n; ++co) {
+        for (int t = 0; t < 9; ++t) wk[(size_t)t * c2->C + co] = w0.data[(size_t)co * 9 + t];
+        bk[co] = b0.data[co];
+      }
+      CtxConv1Params cpp{};
+      cpp.map = fp.out;
+      cpp.H = a->H;
+      cpp.W = a->W;
+      cpp.w = dupload(wk);
+      cpp.b = dupload(bk);
+      cpp.out = c2->view();
+      cpp.act = ACT_SILU;
+      push(cp + ".ctx0", "ctx_conv1", [cpp](hipStream_t st) { return launch_ctx_conv1(cpp, st); }, 2.0 * 9 * c0n * HW);
+    }
+    // ctx1: conv3x3 C/2 -> C + SiLU, gate: c4*x + x, SiLU (:218-224)
+    ConvOpts o1;
+    o1.act = ACT_SILU;
+    o1.res_mode = RES_MULADD;
+    o1.res = a;
+    o1.post_act = ACT_SILU;
+    Act* g = add_conv(cp + ".ctx1", c2, T(cp + ".ctx1.weight").data, T(cp + ".ctx1.bias").data, C, 3, o1);
+    // ctx2: conv3x3 C -> Cout, no activation (:225)
+    x = add_conv(cp + ".ctx2", g, T(cp + ".ctx2.weight").data, T(cp + ".ctx2.bias").data, T(cp + ".ctx2.weight").shape[0], 3, ConvOpts{});
+  }
+  // ---- SPPF (common_layers.py:230-243): cv1, three chained 5x5 max-pools, concat, cv2
+  {
+    const std::string sp = "backbone.p5.2";
+    Act* c1 = conv_bn(sp + ".cv1", x, 1, 1, ACT_SILU);
+    const int c_ = c1->Creal;
+    Act* cat = new_act(sp + ".cat", 4 * c_, x->H, x->W);
+    const ActView cv = cat->view(), c1v = c1->view();
+    push(sp + ".cat0", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(c1v, 0, cv, 0, c_, st); });
+    for (int i = 0; i < 3; ++i)
+      push(sp + ".maxpool" + std::to_string(i), "maxpool5", [=](hipStream_t st) { return launch_maxpool5(cv, i * c_, cv, (i + 1) * c_, c_, st); });
+    x = conv_bn(sp + ".cv2", cat, 1, 1, ACT_SILU);
+  }
+  // ---- C2PSA (common_layers.py:246-257) with one PSABlock (:107-118) and its Attention (:78-104)
+  {
+    const std::string cp = "backbone.p5.3", mb = cp + ".middle_block";
+    Act* t = conv_bn(cp + ".cv1", x, 1, 1, ACT_SILU);       // 2*c_ channels: [a | y]
+    const int c_ = t->Creal / 2;
+    Act* y = new_act(cp + ".y", c_, t->H, t->W);
+    const ActView tv = t->view(), yv = y->view();
+    push(cp + ".split", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(tv, c_, yv, 0, c_, st); });
+    const int heads = c_ / 64, dv = c_ / heads, dk = dv / 2;
+    Act* qkv = conv_bn(mb + ".conv1.qkv", y, 1, 1, ACT_NONE);
+    if (qkv->Creal != heads * (2 * dk + dv)) throw std::runtime_error("attention qkv width mismatch");
+    Act* att = new_act(mb + ".conv1.attn", c_, t->H, t->W);
+    Act* vv = new_act(mb + ".conv1.v", c_, t->H, t->W);
+    AttnParams ap{};
+    ap.qkv = qkv->view();
+    ap.out = att->view();
+    ap.vout = vv->view();
+    ap.heads = heads;
+    ap.dk = dk;
+    ap.dv = dv;
+    ap.scale = 1.0f / std::sqrt((float)dk);
+    const int Tn = t->H * t->W;
+    push(mb + ".conv1.attention", "attention", [ap](hipStream_t st) { return launch_attention(ap, st); }, 2.0 * heads * Tn * (double)Tn * (dk + dv));
+    // + depthwise 3x3 positional conv of v (BN folded, identity activation)
+    Act* pe = new_act(mb + ".conv1.pe", c_, t->H, t->W);
+    {
+      Folded f = fold_conv_norm(blob, mb + ".conv1.conv1");
+      std::vector<float> wk((size_t)9 * vv->C, 0.0f), bk(vv->C, 0.0f);
+      for (int c = 0; c < c_; ++c) {
+        for (int k = 0; k < 9; ++k) wk[(size_t)k * vv->C + c] = f.w[(size_t)c * 9 + k];
+        bk[c] = f.b[c];
+      }
+      DwPlainParams dp{};
+      dp.in = vv->view();
+      dp.add = att->view();
+      dp.out = pe->view();
+      dp.w = dupload(wk);
+      dp.b = dupload(bk);
+      push(mb + ".conv1.conv1", "dwconv_plain", [dp](hipStream_t st) { return launch_dwconv_plain(dp, st); }, 2.0 * 9 * c_ * Tn);
+    }
+    // x = y + conv2(attn + pe)
+    Act* y1;
+    {
+      Folded f = fold_conv_norm(blob, mb + ".conv1.conv2");
+      ConvOpts o;
+      o.res_mode = RES_ADD;
+      o.res = y;
+      y1 = add_conv(mb + ".conv1.conv2", pe, f.w, f.b, f.cout, 1, o);
+    }
+    // x = x + ffn(x)
+    Act* h = conv_bn(mb + ".conv2.0", y1, 1, 1, ACT_SILU);
+    Act* y2;
+    {
+      Folded f = fold_conv_norm(blob, mb + ".conv2.1");
+      ConvOpts o;
+      o.res_mode = RES_ADD;
+      o.res = y1;
+      y2 = add_conv(mb + ".conv2.1", h, f.w, f.b, f.cout, 1, o);
+    }
+    const ActView y2v = y2->view();
+    push(cp + ".cat", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(y2v, 0, tv, c_, c_, st); });  // cat((a, y), 1) in place
+    x = conv_bn(cp + ".cv2", t, 1, 1, ACT_SILU);
+  }
+  // ---- head (autodrive_head.py:70-87): cat([prev, curr]) -> 3 x (conv3x3 + SiLU) -> flatten (C-major) -> MLP
+  const int c5 = x->Creal;
+  Act* cat = new_act("head.cat", 2 * c5, x->H, x->W);
+  {
+    const ActView cv = cat->view(), xv = x->view();
+    ad_shift_op_ = ops_.size();
+    push("head.shift_prev", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(cv, c5, cv, 0, c5, st); });
+    ad_place_op_ = ops_.size();
+    push("head.place_curr", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(xv, 0, cv, c5, c5, st); });
+  }
+  ConvOpts so;
+  so.act = ACT_SILU;
+  Act* h1 = add_conv("head.conv_1", cat, T("head.conv_1.weight").data, T("head.conv_1.bias").data, T("head.conv_1.weight").shape[0], 3, so);
+  Act* h2 = add_conv("head.conv_2", h1, T("head.conv_2.weight").data, T("head.conv_2.bias").data, T("head.conv_2.weight").shape[0], 3, so);
+  Act* h3 = add_conv("head.conv_3", h2, T("head.conv_3.weight").data, T("head.conv_3.bias").data, T("head.conv_3.weight").shape[0], 3, so);
+  const int flat = h3->Creal * h3->H * h3->W;
+  float* v0 = static_cast<float*>(dalloc((size_t)flat * sizeof(float)));
+  {
+    const ActView hv = h3->view();
+    const int cr = h3->Creal;
+    push("head.flatten", "act_to_nchw", [=](hipStream_t st) { return launch_act_to_nchw(hv, cr, v0, st); });
+  }
+  out_c_ = 3;
+  out_h_ = 1;
+  out_w_ = 1;
+  d_logits_ = static_cast<float*>(dalloc(3 * sizeof(float)));
+  d_mask_ = static_cast<uint8_t*>(dalloc(1));
+  auto fc = [&](const std::string& name, const float* in, int K, int act, float* out) -> float* {
+    const HostTensor& w = T(name + ".weight");
+    const HostTensor& b = T(name + ".bias");
+    if (w.shape[1] != K) throw std::runtime_error("linear shape mismatch: " + name);
+    FcParams fp{};
+    fp.x = in;
+    fp.w = dupload(w.data);
+    fp.b = dupload(b.data);
+    fp.N = w.shape[0];
+    fp.K = K;
+    fp.act = act;
+    fp.out = out ? out : static_cast<float*>(dalloc((size_t)w.shape[0] * sizeof(float)));
+    push(name, "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * fp.N * K, 4.0 * fp.N * K);
+    return fp.out;
+  };
+  const float* f1 = fc("head.fc1.0", v0, flat, ACT_SILU, nullptr);
+  const float* f2 = fc("head.fc2.0", f1, 768, ACT_SILU, nullptr);
+  fc("head.distance_head.0", f2, 512, ACT_RELU, d_logits_ + 0);
+  fc("head.curvature_head.0", f2, 512, ACT_TANH, d_logits_ + 1);
+  fc("head.flag_head", f2, 512, ACT_NONE, d_logits_ + 2);
+  decode_mode_ = 0;
+}
+
+// Runs preprocess + backbone on the resident frame and parks its P5 features in the "current" slot, WITHOUT the head:
+// the next enqueue() shifts them to "previous".  Eager launches (twice per stream at most: vp_infer_pair / first frame).
+void Engine::prime_previous() {
+  if (kind_ != 4) throw std::invalid_argument("prime_previous: AutoDrive engines only");
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident");
+  for (size_t i = input_is_tensor_ ? first_net_op_ : 0; i <= ad_place_op_; ++i) {
+    if (i == ad_shift_op_) continue;
+    hipError_t e = ops_[i].run(stream_);
+    if (e != hipSuccess) throw std::runtime_error("launch failed in layer '" + ops_[i].name + "': " + hipGetErrorString(e));
+  }
+  ad_primed_ = true;
+}
+
 void Engine::finish_plan() {
   if (d_logits_ && !h_logits_) {
     VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_logits_), (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipHostMallocDefault));
     VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_mask_), (size_t)out_h_ * out_w_, hipHostMallocDefault));
+    if (kind_ == 4) goto tags;  // AutoDrive returns three scalars: no mask to decode
     Op op;
     op.name = "decode";
     op.bytes = 4.0 * out_c_ * out_h_ * out_w_ + out_h_ * out_w_;
     op.run = [this](hipStream_t st) { return launch_decode_mask(d_logits_, out_c_, out_h_ * out_w_, decode_mode_, d_mask_, st); };
     ops_.push_back(std::move(op));
   }
+tags:
   // kernel tags of the non-GEMM launches (the conv ops set theirs in push_conv_op)
   auto ends_with = [](const std::string& s, const char* suf) {
     const size_t n = std::strlen(suf);
@@ -1059,12 +1394,13 @@ void Engine::enqueue() {
   } else if (!input_is_tensor_ && !d_frame_) {
     throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
   }
+  if (kind_ == 4 && !ad_primed_) prime_previous();  // first frame of a stream: previous := current
   if (!warmed_) {  // first pass is eager: sets kernel attributes and surfaces launch errors with layer names
     run_eager();
     VP_HIP_CHECK(hipStreamSynchronize(stream_));
     warmed_ = true;
     have_outputs_ = true;
-    if (!use_graph_) return;
+    if (!use_graph_ || kind_ == 4) return;  // AutoDrive carries state (feature shift): a frame must run exactly once
   }
   if (use_graph_) {
     if (!graph_valid_) capture_graph();

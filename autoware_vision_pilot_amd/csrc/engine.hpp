@@ -29,6 +29,9 @@ class WeightBlob {
   // FNV-1a over (key suffix, shape, fp32 bytes) of every tensor whose key starts with `prefix`, in key order:
   // equal hashes <=> the sub-network under that prefix carries the same parameters (shared-prefix engines).
   unsigned long long group_hash(const std::string& prefix) const;
+  // BASELINE configs[4] "fp8 weights": every conv / linear weight -> per-output-channel symmetric OCP e4m3 (max 448,
+  // 3 mantissa bits, subnormals), stored back DE-quantised (oracle/autodrive.py quantize_fp8_e4m3, same arithmetic).
+  void quantize_fp8_e4m3();
 
  private:
   std::map<std::string, HostTensor> t_;
@@ -57,6 +60,8 @@ struct ConvOpts {
   int tile = -1, bk = -1, nsplit = -1;
   float* logits_out = nullptr;  // STORE_NCHW_F32 target
   const Act* in2 = nullptr;     // K-extension tensor of the fused ConvTranspose + skip-link GEMM (add_convT_skip)
+  int stride = 1;               // 3x3 stride-2 convs of AutoDrive (generic GEMM kernel only)
+  int post_act = ACT_NONE;      // activation after the residual (CTX: SiLU(c4*x + x))
 };
 
 class Engine {
@@ -72,8 +77,11 @@ class Engine {
   // configuration
   void set_input_format(int pixel_format, int plane_order);
   void set_decode_mode(int mode);
-  int net_h() const { return 320; }
-  int net_w() const { return 640; }
+  int net_h() const { return kind_ == 4 ? 512 : 320; }   // AutoDrive: autodrive_network.py:8-9
+  int net_w() const { return kind_ == 4 ? 1024 : 640; }
+  // AutoDrive (kind 4) pairs every frame with the previous one: infer_pair() runs the backbone on `prev` first
+  // (features only), enqueue() then shifts the feature slots and runs backbone + head on the resident frame.
+  void prime_previous();
 
   // frame path
   void upload_frame(const uint8_t* frame, int h, int w, int stride);
@@ -116,7 +124,8 @@ class Engine {
   void run_eager();
   void upload_act(Act* a, const float* chw);
   hipStream_t stream() const { return stream_; }
-  bool split() const { return precision_ == 1; }
+  bool split() const { return (precision_ & 15) == 1; }
+  bool fp8_weights() const { return (precision_ & 16) != 0; }
   int shared_level() const { return shared_level_; }  // 0 own network, 1 backbone shared, 2 backbone + context + neck shared
 
   std::string last_error;
@@ -136,6 +145,7 @@ class Engine {
                     int store_mode, int cout_real);
 
   void build_model(const WeightBlob& blob);
+  void build_autodrive(const WeightBlob& blob);
   std::vector<Act*> build_backbone(const WeightBlob& blob, const std::string& prefix);
   Act* build_context(const WeightBlob& blob, const std::string& p, const Act* deep, int cctx);
   Act* build_neck(const WeightBlob& blob, const std::string& p, const Act* ctx, const std::vector<Act*>& feats, int cctx);
@@ -151,6 +161,8 @@ class Engine {
   unsigned long long hash_bb_ = 0, hash_ctx_ = 0, hash_neck_ = 0;
   std::vector<Act*> feats_;   // backbone taps f0..f4 (kept for shared-prefix engines)
   Act* neck_out_ = nullptr;
+  size_t ad_shift_op_ = 0, ad_place_op_ = 0;  // AutoDrive: ops_[shift] moves curr->prev features, ops_[place] stores the new ones
+  bool ad_primed_ = false;
   std::vector<void*> allocs_;
   std::vector<std::unique_ptr<Act>> acts_;
   std::vector<Op> ops_;

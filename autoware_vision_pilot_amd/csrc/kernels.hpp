@@ -84,6 +84,7 @@ struct CtxConv1Params {
   const float* w;    // [9][C]
   const float* b;    // [C]
   ActView out;
+  int act;           // ACT_GELU (scene_context.py:46-47) or ACT_SILU (CTX.ctx0, common_layers.py:216-217)
 };
 
 struct FusionParams {
@@ -125,5 +126,26 @@ hipError_t launch_resize_bilinear_f32(const float* src, int sw, const int* yi, c
                                       int oh, int ow, float* dst, hipStream_t st);
 hipError_t launch_nchw_to_act(const float* src, int Creal, const ActView& a, hipStream_t st);
 hipError_t launch_act_to_nchw(const ActView& a, int Creal, float* dst, hipStream_t st);
+
+// ---- AutoDrive blocks (kernels_autodrive.hip)
+// channel-slice copy: dst[pix][dst_off + c] = src[pix][src_off + c], c < nch (torch.cat / split / chunk along C)
+hipError_t launch_chan_copy(const ActView& src, int src_off, const ActView& dst, int dst_off, int nch, hipStream_t st);
+// MaxPool2d(5, stride 1, pad 2) on a channel slice (SPPF, common_layers.py:236-243)
+hipError_t launch_maxpool5(const ActView& src, int src_off, const ActView& dst, int dst_off, int nch, hipStream_t st);
+struct AttnParams {
+  ActView qkv;   // [HW][heads * (2*dk + dv)]: per head q(dk) | k(dk) | v(dv)   (Attention.forward, common_layers.py:95-99)
+  ActView out;   // [HW][heads * dv] = v @ softmax(q^T k * scale)^T
+  ActView vout;  // [HW][heads * dv] copy of v (input of the depthwise positional conv)
+  int heads, dk, dv;
+  float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t st);
+struct DwPlainParams {
+  ActView in, out;   // out = add + dwconv3x3(in) (BN folded, no activation), common_layers.py:103
+  ActView add;
+  const float* w;    // [9][C]
+  const float* b;    // [C]
+};
+hipError_t launch_dwconv_plain(const DwPlainParams& p, hipStream_t st);
 
 }  // namespace vp

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   const int s_begin = (int)(((long long)S * zsplit) / p.nsplit);
   const int s_end = (int)(((long long)S * (zsplit + 1)) / p.nsplit);
   const int half_k = p.ks >> 1;
+  const int cstride = p.stride > 1 ? p.stride : 1, Hin = p.stride > 1 ? p.Hin : p.H, Win = p.stride > 1 ? p.Win : p.W;
 
   // ---- per-thread staging assignment
   size_t a_off[A_ITERS];
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + wbase_ + a_off[i]);      \
     }                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) {                                                     \
-      const int yy_ = b_y[i] + dy_, xx_ = b_x[i] + dx_;                                                       \
-      const bool ok_ = ((unsigned)yy_ < (unsigned)p.H) && ((unsigned)xx_ < (unsigned)p.W);                    \
-      const size_t g_ = ok_ ? ((size_t)yy_ * p.W + xx_) * p.Cin + c0_ + b_ch[i] : 0; /* 0 is always valid */  \
+      const int yy_ = b_y[i] * cstride + dy_, xx_ = b_x[i] * cstride + dx_;                                   \
+      const bool ok_ = ((unsigned)yy_ < (unsigned)Hin) && ((unsigned)xx_ < (unsigned)Win);                    \
+      const size_t g_ = ok_ ? ((size_t)yy_ * Win + xx_) * p.Cin + c0_ + b_ch[i] : 0; /* 0 is always valid */  \
       const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in_hi + g_);                                        \
       rb_hi[SLOT][i] = ok_ ? vh_ : zero4;                                                                     \
       if constexpr (SPLIT) {                                                                                  \

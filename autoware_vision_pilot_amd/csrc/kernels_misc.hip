@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ctx_conv1_kernel(const CtxConv1Params p) 
       for (int i = 0; i < 8; ++i) acc[i] = fmaf(v, p.w[(ky * 3 + kx) * p.out.C + cg * 8 + i], acc[i]);
     }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = gelu_exact(acc[i]);
+  for (int i = 0; i < 8; ++i) acc[i] = p.act == ACT_GELU ? gelu_exact(acc[i]) : apply_act(acc[i], p.act);
   store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
 }
 

@@ -163,6 +163,15 @@ int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes)
     g.fetch_outputs();
   });
 }
+int vp_infer_pair(vp_engine* e, const uint8_t* prev, const uint8_t* curr, int h, int w, int stride_bytes) {
+  return guarded(e, [&](vp::Engine& g) {
+    g.upload_frame(prev, h, w, stride_bytes);
+    g.prime_previous();
+    g.upload_frame(curr, h, w, stride_bytes);
+    g.enqueue();
+    g.fetch_outputs();
+  });
+}
 int vp_infer_tensor(vp_engine* e, const float* nchw) {
   return guarded(e, [&](vp::Engine& g) {
     g.upload_tensor(nchw);

@@ -15,12 +15,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvp_hip.so")
 
-VP_SCENESEG, VP_SCENE3D, VP_DOMAINSEG, VP_EGOLANES = 0, 1, 2, 3
+VP_SCENESEG, VP_SCENE3D, VP_DOMAINSEG, VP_EGOLANES, VP_AUTODRIVE = 0, 1, 2, 3, 4
+VP_WEIGHTS_FP8 = 16
 VP_FP16, VP_FP16X3 = 0, 1
 VP_BGR8, VP_RGB8 = 0, 1
 VP_PLANES_BGR, VP_PLANES_RGB = 0, 1
 VP_DECODE_SEG_MASK, VP_DECODE_LANE_LABEL, VP_DECODE_CLASS_INDEX = 0, 1, 2
-KINDS = {"sceneseg": VP_SCENESEG, "scene3d": VP_SCENE3D, "domainseg": VP_DOMAINSEG, "egolanes": VP_EGOLANES}
+KINDS = {"sceneseg": VP_SCENESEG, "scene3d": VP_SCENE3D, "domainseg": VP_DOMAINSEG, "egolanes": VP_EGOLANES, "autodrive": VP_AUTODRIVE}
 PRECISIONS = {"fp16": VP_FP16, "fp16x3": VP_FP16X3, "fp32": VP_FP16X3}
 
 # every symbol include/vp_hip.h declares: name -> (restype, argtypes)
@@ -39,6 +40,7 @@ _SIGS = {
     "vp_input_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "vp_infer_tensor": (C.c_int, [_P, _P]),
+    "vp_infer_pair": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "vp_logits": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]),
     "vp_mask_u8": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_mask_resized_u8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
@@ -96,7 +98,7 @@ def _ptr(a):
 class Engine:
     """Thin RAII wrapper over a vp_engine handle."""
 
-    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None):
+    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None, weights_fp8=False):
         """base: another Engine -> shared-prefix engine (vp_create_shared): reuses the base engine's backbone (and
         context + neck when their parameters are identical) on the frame the base last processed."""
         lib = load()
@@ -105,6 +107,8 @@ class Engine:
         err = C.create_string_buffer(512)
         k = KINDS[kind] if isinstance(kind, str) else int(kind)
         pr = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        if weights_fp8:
+            pr |= VP_WEIGHTS_FP8
         self._base = base  # keeps the base engine alive as long as this one
         if isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)):
             buf = np.frombuffer(weights, dtype=np.uint8) if not isinstance(weights, np.ndarray) else weights
@@ -159,6 +163,14 @@ class Engine:
             raise ValueError("frame must be HxWx3 uint8")
         self._ck(self._lib.vp_infer(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
 
+    def infer_pair(self, prev_u8, curr_u8):
+        """AutoDrive.forward(image_prev, image_curr): both HxWx3 uint8 frames of the same geometry."""
+        a = np.ascontiguousarray(prev_u8, dtype=np.uint8)
+        b = np.ascontiguousarray(curr_u8, dtype=np.uint8)
+        if a.shape != b.shape or a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("frames must be two HxWx3 uint8 arrays of the same shape")
+        self._ck(self._lib.vp_infer_pair(self._h, _ptr(a), _ptr(b), a.shape[0], a.shape[1], a.strides[0]))
+
     def infer_shared(self):
         """Run this shared-prefix engine's own layers on the frame its base engine processed last."""
         self._ck(self._lib.vp_infer_shared(self._h))
@@ -168,8 +180,9 @@ class Engine:
 
     def infer_tensor(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)
-        if x.size != 3 * 320 * 640:
-            raise ValueError("tensor must be 1x3x320x640")
+        h, w = self.input_hw()
+        if x.size != 3 * h * w:
+            raise ValueError(f"tensor must be 1x3x{h}x{w}")
         self._ck(self._lib.vp_infer_tensor(self._h, _ptr(x)))
 
     def logits(self):
@@ -196,7 +209,8 @@ class Engine:
         return out
 
     def input_tensor(self):
-        out = np.empty((1, 3, 320, 640), dtype=np.float32)
+        h, w = self.input_hw()
+        out = np.empty((1, 3, h, w), dtype=np.float32)
         self._ck(self._lib.vp_input_tensor(self._h, _ptr(out)))
         return out
 

@@ -47,12 +47,19 @@ typedef struct vp_engine vp_engine;
 
 enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_WEIGHTS = -2, VP_ERR_HIP = -3, VP_ERR_STATE = -4 };
 
-enum vp_model_kind { VP_SCENESEG = 0, VP_SCENE3D = 1, VP_DOMAINSEG = 2, VP_EGOLANES = 3 };
+/* VP_AUTODRIVE (BASELINE configs[4]): Models/model_components/autodrive/autodrive_network.py:32-36 --
+ * shared backbone on the previous and the current frame (network input 1x3x512x1024, RGB planes), head -> three scalars
+ * returned through vp_logits as shape {1,3,1,1} = (d_norm, curvature, flag_logit); no mask. */
+enum vp_model_kind { VP_SCENESEG = 0, VP_SCENE3D = 1, VP_DOMAINSEG = 2, VP_EGOLANES = 3, VP_AUTODRIVE = 4 };
 
 /* VP_FP16  : fp16 tensors, fp16 MFMA, fp32 accumulate (the reference's "fp16" configuration).
  * VP_FP16X3: fp32-class accuracy on the fp16 matrix pipe: every tensor is a (hi, lo) fp16 pair and every
  *            product is three MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate -- the parity mode (1e-3). */
-enum vp_precision { VP_FP16 = 0, VP_FP16X3 = 1 };
+enum vp_precision { VP_FP16 = 0, VP_FP16X3 = 1,
+                    /* OR-able flag: every conv / linear weight is quantised at load to per-output-channel OCP e4m3 (fp8) and
+                     * de-quantised for the fp16 / fp16x3 matrix pipe (BASELINE configs[4] "fp8 weights"; the reference's
+                     * PTQ flow: Models/exports/quantization/PTQ/AutoDrive) */
+                    VP_WEIGHTS_FP8 = 16 };
 
 enum vp_pixel_format { VP_BGR8 = 0, VP_RGB8 = 1 };
 /* Plane order of the network input: BGR planes = middleware "common" backends (onnx_runtime_backend.cpp:47-57),
@@ -97,6 +104,10 @@ int vp_input_hw(const vp_engine* e, int* h, int* w);
 /* ---- synchronous per-frame path (host buffers in, host buffers out) -------------------------------------- */
 int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes);
 int vp_infer_tensor(vp_engine* e, const float* nchw_1x3x320x640);
+/* AutoDrive.forward(image_prev, image_curr) (autodrive_network.py:32-36): backbone on `prev`, then backbone + head on `curr`.
+ * Plain vp_infer on a VP_AUTODRIVE engine is the streaming form: the previous call's frame is `prev` (the first frame of
+ * a stream pairs with itself).  Both frames share h, w, stride. */
+int vp_infer_pair(vp_engine* e, const uint8_t* prev, const uint8_t* curr, int h, int w, int stride_bytes);
 int vp_logits(const vp_engine* e, const float** data, int64_t shape[4]);       /* host pointer, valid until next infer */
 int vp_mask_u8(const vp_engine* e, const uint8_t** data, int* h, int* w);      /* host pointer, network resolution */
 int vp_mask_resized_u8(vp_engine* e, uint8_t* dst, int h, int w);              /* nearest, to frame size */

@@ -1,0 +1,97 @@
+"""AutoDrive (BASELINE configs[4]) on the engine vs the pinned oracle.
+
+Same seeded weights and frames as tests/golden/autodrive.npz (oracle/pin_autodrive.py ran the reference's own
+nn.Module on them).  Parity bar: the three outputs within 1e-3 of the fp32 oracle in the fp16x3 mode -- with fp32
+weights and with the fp8(e4m3)-dequantised weights of configs[4]; intermediate feature maps within 1e-3 * max(1,|ref|)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import autodrive, pre_post
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "autodrive.npz")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from autoware_vision_pilot_amd import weights as vw
+
+    g = np.load(GOLDEN)
+    frames = [pre_post.synthetic_frame(1080, 1920, int(s)) for s in g["frame_seeds"]]
+    sd = autodrive.make_state_dict(int(g["weight_seed"]))
+    return g, frames, sd, vw.pack_state_dict(sd)
+
+
+def _tensor(eng, name):
+    for i, (n, c, h, w) in enumerate(eng.tensors()):
+        if n == name:
+            return eng.tensor_read(i)
+    raise KeyError(name)
+
+
+def test_preprocess_1024x512_bit_exact(setup):
+    from autoware_vision_pilot_amd import lib
+
+    _, frames, _, blob = setup
+    eng = lib.Engine("autodrive", blob, precision="fp16")
+    try:
+        assert eng.input_hw() == (512, 1024)
+        eng.infer(frames[1])
+        want = pre_post.preprocess(frames[1], input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024)
+        assert np.array_equal(eng.input_tensor(), want)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_autodrive_parity_fp16x3(setup, fp8):
+    from autoware_vision_pilot_amd import lib
+
+    g, frames, sd, blob = setup
+    tag = "fp8" if fp8 else "fp32"
+    sdt = {k: torch.from_numpy(v) for k, v in (autodrive.quantize_fp8_e4m3(sd) if fp8 else sd).items()}
+    xs = [torch.from_numpy(pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024)) for f in frames]
+    with torch.no_grad():
+        p5, inter = autodrive.backbone(sdt, xs[1], return_intermediates=True)
+        ref = np.array([float(v) for v in autodrive.forward(sdt, xs[0], xs[1])], dtype=np.float32)
+    assert np.abs(ref - g[f"{tag}_out"]).max() <= 1e-5  # the oracle itself is pinned to the reference module
+    eng = lib.Engine("autodrive", blob, precision="fp16x3", weights_fp8=fp8)
+    try:
+        eng.infer_pair(frames[0], frames[1])
+        got = eng.logits().reshape(3)
+        for name, r in (("backbone.p1", inter["p1"]), ("backbone.p2.1.ctx2", inter["p2_ctx"]), ("backbone.p3.1.ctx2", inter["p3_ctx"]),
+                        ("backbone.p4.1.ctx2", inter["p4_ctx"]), ("backbone.p5.1.ctx2", inter["p5_ctx"]), ("backbone.p5.2.cv2", inter["sppf"]),
+                        ("backbone.p5.3.cv2", p5)):
+            t = _tensor(eng, name)
+            r = r[0].numpy()
+            err = float((np.abs(t - r) / np.maximum(1.0, np.abs(r))).max())
+            assert err <= 1e-3, f"{tag} {name}: err {err:.3e}"
+        assert np.abs(got - ref).max() <= 1e-3, f"{tag}: got {got}, oracle {ref}"
+        # streaming form: frame 0 then frame 1 through plain infer() pairs (f0,f0) then (f0,f1)
+        eng2 = lib.Engine("autodrive", blob, precision="fp16x3", weights_fp8=fp8)
+        try:
+            eng2.infer(frames[0])
+            eng2.infer(frames[1])
+            assert np.array_equal(eng2.logits().reshape(3), got)
+        finally:
+            eng2.close()
+    finally:
+        eng.close()
+
+
+def test_autodrive_fp16_close(setup):
+    from autoware_vision_pilot_amd import lib
+
+    g, frames, _, blob = setup
+    eng = lib.Engine("autodrive", blob, precision="fp16")
+    try:
+        eng.infer_pair(frames[0], frames[1])
+        got = eng.logits().reshape(3)
+        assert np.abs(got - g["fp32_out"]).max() <= 3e-2, (got, g["fp32_out"])
+        eng.infer_pair(frames[0], frames[1])
+        assert np.array_equal(got, eng.logits().reshape(3))  # graph replay is deterministic
+    finally:
+        eng.close()
