@@ -78,3 +78,35 @@ class EgoLanesNetworkInfer(_NetworkInfer):
 
     def inference(self, image):
         return self._forward(image, check_size=False)  # ego_lanes_infer.py:50-62 has no size check
+
+
+class AutoDriveInfer:
+    """Models/model_components/autodrive/autodrive_network.py:15-36 behind the engine: ``forward(prev, curr)`` on two
+    HxWx3 uint8 frames (any size; the engine does the visualisation script's preprocess -- bilinear resize to
+    1024x512, RGB planes, ImageNet normalisation, video_visualization.py:29-33) -> (d_norm, curvature, flag_logit);
+    ``step(frame)`` is the streaming form (pairs each frame with the previous one).  ``frames_are_bgr`` matches
+    OpenCV captures.  ``weights_fp8`` selects the per-channel e4m3 weight format of BASELINE configs[4]."""
+
+    D_MAX_M = 150.0
+
+    def __init__(self, checkpoint_path="", precision="fp16", gpu_id=0, weights_fp8=False, frames_are_bgr=True):
+        if checkpoint_path is None or len(checkpoint_path) == 0:
+            raise ValueError("No path to checkpiont file provided in class initialization")
+        self.model = _lib.Engine("autodrive", checkpoint_path, precision=precision, gpu_id=gpu_id, weights_fp8=weights_fp8)
+        self.model.set_input_format(_lib.VP_BGR8 if frames_are_bgr else _lib.VP_RGB8, _lib.VP_PLANES_RGB)
+
+    def forward(self, image_prev, image_curr):
+        self.model.infer_pair(np.asarray(image_prev), np.asarray(image_curr))
+        d, c, f = self.model.logits().reshape(3)
+        return float(d), float(c), float(f)
+
+    def step(self, image):
+        self.model.infer(np.asarray(image))
+        d, c, f = self.model.logits().reshape(3)
+        return float(d), float(c), float(f)
+
+    @staticmethod
+    def to_distance_meters(d_norm):
+        """autodrive_head.py:89-92."""
+        return AutoDriveInfer.D_MAX_M * (1.0 - d_norm)
+

@@ -37,6 +37,9 @@ def export_checkpoint(pth_path, out_path):
     import torch  # only needed for reading the pickle
 
     sd = torch.load(pth_path, weights_only=True, map_location="cpu")
+    if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict):
+        sd = sd["model"]  # AutoDrive checkpoints wrap the state_dict (visualizations/AutoDrive/video_visualization.py:43-44)
+    sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")}
     with open(out_path, "wb") as f:
         f.write(pack_state_dict(sd))
     return out_path
