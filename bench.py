@@ -176,8 +176,24 @@ def main():
                 f["worst"] = (name, float(t))
         # dominant = the single kernel instantiation (= one rocprofv3 kernel name) with the largest total time; "+splitk"
         # ops are two launches (conv + finish kernel) per timing interval, so they cannot give a per-kernel duration
-        dom = max((k for k in fam if "+splitk" not in k), key=lambda k: fam[k]["ms"])
+        # The path is a dense contraction (bound = MFMA): the roofline kernel is the instantiation with the
+        # largest total time among those carrying >= 5 % of the frame's FLOPs; `by_time` lists the top kernels of ANY kind
+        # (the latency-bound depthwise launches are within a few us of it in eager timing) with their own bound and fraction.
+        single = [k for k in fam if "+splitk" not in k]
+        tot_fl = sum(f["flops"] for f in fam.values())
+        heavy = [k for k in single if fam[k]["flops"] >= 0.05 * tot_fl]
+        dom = max(heavy or single, key=lambda k: fam[k]["ms"])
         d = fam[dom]
+
+        def frac_of(k):
+            f = fam[k]
+            if k.startswith("conv"):
+                return "mfma", f["flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS
+            return "hbm", f["bytes"] / (f["ms"] * 1e-3) / 1e9 / 8000.0
+
+        by_time = [{"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / float(ms.sum()), 3),
+                    "bound": frac_of(k)[0], "frac": round(frac_of(k)[1], 4)}
+                   for k in sorted(single, key=lambda k: -fam[k]["ms"])[:4]]
         frame_tflops = FRAME_GFLOP[args.kind] * (fps_total / world) / 1e3
         if dom.startswith("conv"):
             achieved, peak, unit, bound = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_FP16_TFLOPS, "TFLOP/s", "mfma"
@@ -193,7 +209,7 @@ def main():
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
             "algorithmic_mb_per_launch": round(d["bytes"] / d["n"] / 1e6, 3),
             "slowest_layer": d["worst"][0], "slowest_layer_us": round(1e3 * d["worst"][1], 1),
-            "kernel_time_share": round(d["ms"] / float(ms.sum()), 3),
+            "kernel_time_share": round(d["ms"] / float(ms.sum()), 3), "by_time": by_time,
             "whole_frame": {"achieved": round(frame_tflops, 2), "frac": round(frame_tflops / PEAK_FP16_TFLOPS, 4),
                             "gflop_per_frame": FRAME_GFLOP[args.kind], "unit": "TFLOP/s"},
             "sustained_mfma_peak": {"value": 1700.0, "unit": "TFLOP/s",
