@@ -1478,6 +1478,43 @@ void Engine::mask_resized(uint8_t* dst, int h, int w) {
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+// MasksVisualizationEngine::visualize on the device: the mask of the LAST inference, coloured, nearest-resized to the frame
+// that produced it and blended 50/50 with that (still resident) frame; BGR8 out, frame size.
+void Engine::visualize_mask(int viz_type, uint8_t* dst) {
+  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
+  if (!dst || viz_type < 0 || viz_type > 2) throw std::invalid_argument("bad visualisation request");
+  if (!d_frame_ || input_is_tensor_ || base_) throw std::runtime_error("visualize_mask needs the frame path (vp_infer) on a base engine");
+  const int h = frame_h_, w = frame_w_;
+  if (!d_viz_lut_) {
+    // createColorMask (masks_visualization_engine.cpp:41-58), BGR
+    std::vector<uint8_t> lut(3 * 256 * 3, 0);
+    for (int v = 1; v < 256; ++v) { lut[(0 * 256 + v) * 3 + 2] = 255; }                          // "scene": 1..255 -> (0,0,255)
+    const uint8_t dom0[3] = {255, 93, 61}, dom255[3] = {145, 28, 255};                            // "domain"
+    for (int c = 0; c < 3; ++c) { lut[(1 * 256 + 0) * 3 + c] = dom0[c]; lut[(1 * 256 + 255) * 3 + c] = dom255[c]; }
+    const uint8_t ego[3][3] = {{255, 0, 0}, {255, 0, 200}, {0, 153, 0}};                          // "egolanes": labels 0,1,2
+    for (int v = 0; v < 3; ++v)
+      for (int c = 0; c < 3; ++c) lut[(2 * 256 + v) * 3 + c] = ego[v][c];
+    d_viz_lut_ = dupload(lut);
+  }
+  const size_t need = (size_t)3 * h * w, tabn = (size_t)(h + w);
+  if (need > resize_cap_) {
+    d_resize_out_ = dalloc(std::max(need, (size_t)4 * h * w), false);
+    resize_cap_ = std::max(need, (size_t)4 * h * w);
+  }
+  if (tabn * 4 > rs_tab_cap_) {
+    d_rs_tab_ = static_cast<int*>(dalloc(tabn * 4 * sizeof(int), false));
+    rs_tab_cap_ = tabn * 4;
+  }
+  std::vector<int> tab(h + w);
+  nearest_tab(out_h_, h, tab.data());
+  nearest_tab(out_w_, w, tab.data() + h);
+  VP_HIP_CHECK(hipMemcpyAsync(d_rs_tab_, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+  VP_HIP_CHECK(launch_viz_blend(d_mask_, out_w_, d_rs_tab_, d_rs_tab_ + h, d_frame_, frame_stride_, h, w, d_viz_lut_ + (size_t)viz_type * 768,
+                                pixel_format_ == 1, static_cast<uint8_t*>(d_resize_out_), stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, need, hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
 void Engine::depth_resized(float* dst, int h, int w) {
   if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
   if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");

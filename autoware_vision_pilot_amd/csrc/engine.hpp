@@ -92,6 +92,7 @@ class Engine {
   void copy_outputs_device(void* logits_dst, void* mask_dst);
   void mask_resized(uint8_t* dst, int h, int w);
   void depth_resized(float* dst, int h, int w);
+  void visualize_mask(int viz_type, uint8_t* dst_bgr);
   void read_input_tensor(float* dst);
 
   const float* host_logits() const { return h_logits_; }
@@ -196,6 +197,7 @@ class Engine {
   void* d_resize_out_ = nullptr;
   size_t resize_cap_ = 0;
   int* d_rs_tab_ = nullptr;
+  uint8_t* d_viz_lut_ = nullptr;  // [3 viz types][256][3]
   size_t rs_tab_cap_ = 0;
 
   // graph

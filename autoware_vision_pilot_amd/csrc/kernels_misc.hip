@@ -105,6 +105,26 @@ __global__ __launch_bounds__(256) void decode_mask_kernel(const float* logits, i
   out[i] = r;
 }
 
+// MasksVisualizationEngine::visualize (common/visualizers/masks_visualization_engine.cpp:11-58): colour LUT on the mask
+// (createColorMask :41-58; label values not listed stay black), cv::resize INTER_NEAREST to the frame size (:21-25),
+// cv::addWeighted(color, 0.5, frame, 0.5, 0) (:29) = saturate_cast<uchar>(cvRound(0.5*a + 0.5*b)): both halves are exact
+// in float, cvRound rounds half to even -> (a+b)>>1, plus 1 when the sum is odd and that half is odd.
+__global__ __launch_bounds__(256) void viz_blend_kernel(const uint8_t* mask, int mw, const int* ytab, const int* xtab, const uint8_t* frame,
+                                                        int stride, int oh, int ow, const uint8_t* lut /* [256][3] BGR */, int frame_is_rgb,
+                                                        uint8_t* dst) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= ow) return;
+  const uint8_t label = mask[(size_t)ytab[y] * mw + xtab[x]];
+  const uint8_t* f = frame + (size_t)y * stride + 3 * x;
+  uint8_t* d = dst + ((size_t)y * ow + x) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int a = lut[label * 3 + c], b = f[frame_is_rgb ? 2 - c : c];
+    const int s2 = a + b, h = s2 >> 1;
+    d[c] = (uint8_t)((s2 & 1) ? h + (h & 1) : h);
+  }
+}
+
 // cv::resize INTER_NEAREST (run_model_node.cpp:176-177); index tables from the host.
 __global__ __launch_bounds__(256) void resize_nearest_kernel(const uint8_t* src, int sw, const int* ytab, const int* xtab,
                                                              int oh, int ow, uint8_t* dst) {
@@ -170,6 +190,10 @@ hipError_t launch_decode_mask(const float* logits, int C, int HW, int mode, uint
 hipError_t launch_resize_nearest(const uint8_t* src, int sw, const int* ytab, const int* xtab, int oh, int ow, uint8_t* dst,
                                  hipStream_t st) {
   VP_LAUNCH(resize_nearest_kernel, dim3(nblk(ow), oh), dim3(256), 0, st, src, sw, ytab, xtab, oh, ow, dst);
+}
+hipError_t launch_viz_blend(const uint8_t* mask, int mw, const int* ytab, const int* xtab, const uint8_t* frame, int stride, int oh, int ow,
+                            const uint8_t* lut, int frame_is_rgb, uint8_t* dst, hipStream_t st) {
+  VP_LAUNCH(viz_blend_kernel, dim3(nblk(ow), oh), dim3(256), 0, st, mask, mw, ytab, xtab, frame, stride, oh, ow, lut, frame_is_rgb, dst);
 }
 hipError_t launch_resize_bilinear_f32(const float* src, int sw, const int* yi, const float* yf, const int* xi, const float* xf,
                                       int oh, int ow, float* dst, hipStream_t st) {

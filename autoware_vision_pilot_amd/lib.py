@@ -45,6 +45,7 @@ _SIGS = {
     "vp_mask_u8": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_mask_resized_u8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_depth_resized_f32": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "vp_visualize_mask_bgr8": (C.c_int, [_P, C.c_int, _P]),
     "vp_input_tensor": (C.c_int, [_P, _P]),
     "vp_upload_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "vp_enqueue": (C.c_int, [_P]),
@@ -206,6 +207,12 @@ class Engine:
     def depth_resized(self, h, w):
         out = np.empty((h, w), dtype=np.float32)
         self._ck(self._lib.vp_depth_resized_f32(self._h, _ptr(out), h, w))
+        return out
+
+    def visualize_mask(self, viz_type, frame_hw):
+        """Blended BGR visualisation (masks_visualization_engine.cpp) of the last inference at the last frame's size."""
+        out = np.empty((frame_hw[0], frame_hw[1], 3), dtype=np.uint8)
+        self._ck(self._lib.vp_visualize_mask_bgr8(self._h, int(viz_type), _ptr(out)))
         return out
 
     def input_tensor(self):

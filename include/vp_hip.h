@@ -112,6 +112,11 @@ int vp_logits(const vp_engine* e, const float** data, int64_t shape[4]);       /
 int vp_mask_u8(const vp_engine* e, const uint8_t** data, int* h, int* w);      /* host pointer, network resolution */
 int vp_mask_resized_u8(vp_engine* e, uint8_t* dst, int h, int w);              /* nearest, to frame size */
 int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w);              /* bilinear, plane 0 of the logits */
+/* MasksVisualizationEngine::visualize (middleware_recipes/common/visualizers/masks_visualization_engine.cpp:11-58, SURVEY.md
+ * 8f N4): colour LUT on the last mask (viz_type: 0 "scene", 1 "domain", 2 "egolanes" -- use VP_DECODE_LANE_LABEL for it),
+ * nearest resize to the frame of the last vp_infer, 50/50 blend with that frame.  dst: BGR8 [frame_h][frame_w][3], packed. */
+enum vp_viz_type { VP_VIZ_SCENE = 0, VP_VIZ_DOMAIN = 1, VP_VIZ_EGOLANES = 2 };
+int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst_bgr8);
 int vp_input_tensor(vp_engine* e, float* dst_1x3x320x640);                     /* the post-resize network input */
 
 /* ---- asynchronous / device-resident path (bench, multi-GPU) ---------------------------------------------- */

@@ -167,3 +167,30 @@ def synthetic_frame(h, w, seed, smooth=True):
         img[..., c] = 127.5 + 90.0 * np.sin(2 * np.pi * (fy * yy / h + fx * xx / w) + ph)
     img += rng.normal(0.0, 12.0, size=img.shape).astype(np.float32)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------ visualisation
+_VIZ_LUT = None
+
+
+def viz_lut():
+    """createColorMask colour tables, BGR (masks_visualization_engine.cpp:41-58): [viz_type][label] -> 3 bytes."""
+    global _VIZ_LUT
+    if _VIZ_LUT is None:
+        lut = np.zeros((3, 256, 3), dtype=np.uint8)
+        lut[0, 1:] = (0, 0, 255)                                    # "scene": inRange(1, 255) -> red
+        lut[1, 0], lut[1, 255] = (255, 93, 61), (145, 28, 255)      # "domain"
+        lut[2, 0], lut[2, 1], lut[2, 2] = (255, 0, 0), (255, 0, 200), (0, 153, 0)   # "egolanes"
+        _VIZ_LUT = lut
+    return _VIZ_LUT
+
+
+def visualize_mask(mask_u8, frame_bgr, viz_type):
+    """MasksVisualizationEngine::visualize (:11-38): colour mask -> INTER_NEAREST resize to the frame -> addWeighted(0.5, 0.5).
+    cv::addWeighted on u8 is saturate_cast<uchar>(cvRound(float)): round half to even."""
+    h, w = frame_bgr.shape[:2]
+    color = viz_lut()[viz_type][resize_nearest_u8(mask_u8, h, w)]
+    s = color.astype(np.int32) + frame_bgr.astype(np.int32)
+    half = s >> 1
+    return np.where(s & 1, half + (half & 1), half).astype(np.uint8)
+

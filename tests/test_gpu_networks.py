@@ -241,3 +241,24 @@ def test_no_state_leaks_between_frames(engines, frame720):
         a2 = eng.logits()
         assert np.array_equal(a1, a2), f"{kind}/{prec}: state leaked between frames"
         assert not np.array_equal(a1, b)
+
+
+def test_visualize_mask_bit_exact(engines, frame720):
+    """colour LUT + nearest resize + 50/50 blend (masks_visualization_engine.cpp:11-58), bit-exact."""
+    from autoware_vision_pilot_amd import lib
+    from oracle import pre_post
+
+    eng = engines("sceneseg", "fp16x3")
+    eng.set_decode_mode(lib.VP_DECODE_SEG_MASK)
+    eng.infer(frame720)
+    got = eng.visualize_mask(0, frame720.shape[:2])
+    want = pre_post.visualize_mask(eng.mask(), frame720, 0)
+    assert got.shape == frame720.shape and np.array_equal(got, want)
+    assert (got != frame720 // 2 + 0).any()  # some pixels carry the red overlay
+    ego = engines("egolanes", "fp16x3")
+    ego.set_decode_mode(lib.VP_DECODE_LANE_LABEL)
+    ego.infer(frame720)
+    assert np.array_equal(ego.visualize_mask(2, frame720.shape[:2]), pre_post.visualize_mask(ego.mask(), frame720, 2))
+    dom = engines("domainseg", "fp16x3")
+    dom.infer(frame720)
+    assert np.array_equal(dom.visualize_mask(1, frame720.shape[:2]), pre_post.visualize_mask(dom.mask(), frame720, 1))
