@@ -1244,14 +1244,14 @@ void Engine::finish_plan() {
   if (d_logits_ && !h_logits_) {
     VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_logits_), (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipHostMallocDefault));
     VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_mask_), (size_t)out_h_ * out_w_, hipHostMallocDefault));
-    if (kind_ == 4) goto tags;  // AutoDrive returns three scalars: no mask to decode
-    Op op;
-    op.name = "decode";
-    op.bytes = 4.0 * out_c_ * out_h_ * out_w_ + out_h_ * out_w_;
-    op.run = [this](hipStream_t st) { return launch_decode_mask(d_logits_, out_c_, out_h_ * out_w_, decode_mode_, d_mask_, st); };
-    ops_.push_back(std::move(op));
+    if (kind_ != 4) {  // AutoDrive returns three scalars: no mask to decode
+      Op op;
+      op.name = "decode";
+      op.bytes = 4.0 * out_c_ * out_h_ * out_w_ + out_h_ * out_w_;
+      op.run = [this](hipStream_t st) { return launch_decode_mask(d_logits_, out_c_, out_h_ * out_w_, decode_mode_, d_mask_, st); };
+      ops_.push_back(std::move(op));
+    }
   }
-tags:
   // kernel tags of the non-GEMM launches (the conv ops set theirs in push_conv_op)
   auto ends_with = [](const std::string& s, const char* suf) {
     const size_t n = std::strlen(suf);

@@ -138,7 +138,49 @@ static int run_split(const char* name, int H, int W, int Cin, int Cout, int nspl
   return 0;
 }
 
+// 64 -> 3 head conv (co32 tile, 1x4 waves): where does its time go?
+template <int ABL>
+static float time_head(const ConvGemmParams& p, int iters) {
+  constexpr int CO = 32, TH = 8, TW = 16;
+  constexpr int lds_main = 2 * ((TH + 2) * (TW + 2) * 80 + CO * 64);
+  constexpr int lds = lds_main > epilogue_stage_bytes<TH * TW, 1>() ? lds_main : epilogue_stage_bytes<TH * TW, 1>();
+  auto k = conv3x3_halo_kernel<CO, TH, TW, 1, 4, false, ABL, false>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW) * (p.CoutW / CO));
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(256), lds, 0, p);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(256), lds, 0, p);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  return ms * 1000.0f / iters;
+}
+static int run_head() {
+  const int H = 320, W = 640, Cin = 64, Cout = 32;
+  half_t *in, *w;
+  float *bias, *outf;
+  CK(hipMalloc(&in, (size_t)H * W * Cin * 2));
+  CK(hipMalloc(&w, (size_t)9 * Cout * Cin * 2));
+  CK(hipMalloc(&bias, Cout * 4));
+  CK(hipMalloc(&outf, (size_t)3 * H * W * 4));
+  CK(hipMemset(in, 0, (size_t)H * W * Cin * 2));
+  CK(hipMemset(w, 0, (size_t)9 * Cout * Cin * 2));
+  CK(hipMemset(bias, 0, Cout * 4));
+  ConvGemmParams p{};
+  p.in_hi = in; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.act = ACT_NONE; p.store_mode = STORE_NCHW_F32; p.out_f32 = outf; p.Creal = 3; p.nsplit = 1;
+  const int it = 20;
+  std::printf("head 64->3 320x640: full %6.1f us | noGlobal %6.1f | noMFMA %6.1f | noLdsRead %6.1f | noBarrier %6.1f | nothing-but-loop %6.1f | nothing, no barrier %6.1f\n",
+              time_head<0>(p, it), time_head<1>(p, it), time_head<2>(p, it), time_head<4>(p, it), time_head<8>(p, it), time_head<7>(p, it), time_head<15>(p, it));
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'h') return run_head();
   if (argc > 1) {
     for (int ns : {1, 2, 4, 8, 15}) run_split<128, 8, 16>("dec0 1920->512 20x40 t8x16", 20, 40, 1920, 512, ns);
     for (int ns : {1, 2, 4, 8, 15}) run_split<64, 8, 16>("dec0 1920->512 20x40 co64 t8x16", 20, 40, 1920, 512, ns);
