@@ -10,6 +10,7 @@ Integer/byte stages (preprocess, decode, nearest resize) are compared bit-exactl
 """
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -262,3 +263,29 @@ def test_visualize_mask_bit_exact(engines, frame720):
     dom = engines("domainseg", "fp16x3")
     dom.infer(frame720)
     assert np.array_equal(dom.visualize_mask(1, frame720.shape[:2]), pre_post.visualize_mask(dom.mask(), frame720, 1))
+
+
+def test_config1_640x360_rgb_class_map(engines, state_dicts):
+    """BASELINE configs[0] / SURVEY.md 8(d) row 1: SceneSeg on a 640x360 RGB frame (rng(0) integers), the reference's own
+    CPU-runnable case: logits within 1e-3 and the int64 class map equal to the oracle's except inside the tolerance band."""
+    from autoware_vision_pilot_amd import lib
+    from oracle import nets, pre_post
+
+    frame = np.random.default_rng(0).integers(0, 256, size=(360, 640, 3), dtype=np.uint8)
+    x = torch.from_numpy(pre_post.preprocess(frame, input_is_bgr=False, planes_rgb=True))
+    ref = nets.forward("sceneseg", nets.to_torch(state_dicts("sceneseg")), x)[0].numpy()
+    eng = engines("sceneseg", "fp16x3")
+    eng.set_input_format(lib.VP_RGB8, lib.VP_PLANES_RGB)
+    eng.set_decode_mode(lib.VP_DECODE_CLASS_INDEX)
+    try:
+        eng.infer(frame)
+        assert np.array_equal(eng.input_tensor(), x.numpy())
+        got = eng.logits()[0] if eng.logits().ndim == 4 else eng.logits()
+        assert _rel(got, ref) <= 1e-3
+        cls, ref_cls = eng.mask().astype(np.int64), pre_post.argmax_classes(ref)
+        srt = np.sort(ref, axis=0)
+        flips = cls != ref_cls
+        assert flips.mean() <= 5e-4 and ((srt[-1] - srt[-2])[flips] < 2e-3).all()
+    finally:
+        eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
+        eng.set_decode_mode(lib.VP_DECODE_SEG_MASK)
