@@ -323,7 +323,11 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     op.flops += 2.0 * M * 4.0 * cout_real * o.in2->Creal;
     op.bytes += esz * ((double)M * 4.0 * o.in2->Creal + (double)cout_real * o.in2->Creal);
   }
-  if (tile >= 100) {
+  if (tile >= 200) {
+    const int shape = tile - 200;
+    op.kernel = std::string("conv3x3_region<") + (shape == 0 ? "10x40" : "16x32") + ",co" + std::to_string(region_co(shape, pc.CoutW)) + ">" + (pc.nsplit > 1 ? "+splitk" : "");
+    op.run = [p, shape, sp](hipStream_t st) { return launch_conv3x3_region(p, shape, sp, st); };
+  } else if (tile >= 100) {
     int ht = tile - 100;
     // ---- optional per-layer tile autotune (VP_AUTOTUNE=1 enables; measured +-1 % on the frames-in-flight bench, so
     // the static heuristic is the default): time the tile shapes that share this weight packing and keep the fastest.  The K order per output is identical for every tile, so the choice never changes a result bit.
@@ -394,7 +398,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   if (ks == 3 && cstride == 1 && in->H >= 8 && in->W >= 16) {
     static const char* env = std::getenv("VP_CONV3X3");
     const bool force_v1 = (env && std::strcmp(env, "v1") == 0) || (o.tile >= 0 && o.tile < 100);
-    if (o.tile >= 100) {
+    if (o.tile >= 200) {
+      halo = -1;  // region kernel, selected below
+    } else if (o.tile >= 100) {
       halo = o.tile - 100;
     } else if (!force_v1) {
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
@@ -412,7 +418,43 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     }
     if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
   }
-  if (halo >= 0) {
+  // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
+  // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
+  int region = -1;
+  if (o.tile >= 200 && (split() || ks != 3 || cstride != 1)) throw std::invalid_argument("region kernel: 3x3 stride 1, VP_FP16 only: " + name);
+  if (ks == 3 && cstride == 1 && !split() && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !o.logits_out) {
+    static const char* renv = std::getenv("VP_REGION");
+    if (o.tile >= 200) {
+      region = o.tile - 200;
+      if (region > 1 || !region_shape_fits(region, in->H, in->W)) throw std::invalid_argument("region kernel: map does not tile into regions: " + name);
+    } else if (o.tile < 0 && renv && renv[0] == '1' && cin_pad >= 256 && M <= 3200) {
+      // opt-in (VP_REGION=1): measured 161 -> 142 us on the four neck layers alone (single-stream latency -1 %), but its
+      // 117 KiB of LDS per workgroup keeps other streams' kernels off the CU: 1278 -> 1230 frames/s with 3 frames in
+      // flight.  These layers are bound by ~120 MB of L2 / Infinity-Cache traffic each (weights x regions + fp32 split-K
+      // partials written and re-read), whatever the tiling.
+      if (region_shape_fits(0, in->H, in->W)) region = 0;
+      else if (region_shape_fits(1, in->H, in->W)) region = 1;
+    }
+  }
+  if (region >= 0) {
+    halo = 0;  // same weight packing as the patch kernel: [cin/32][tap][CoutW][32]
+    pc.tile = 200 + region;
+    pc.bk = 32;
+    pc.CoutW = round_up(ncols, 32);
+    const int KC = cin_pad / 32;
+    const long long blocks = (long long)region_count(region, in->H, in->W) * (pc.CoutW / region_co(region, pc.CoutW));
+    // one workgroup per CU: split K until the machine is covered once, at least two chunks per slice, partials <= 24 MB
+    int ns = 1;
+    if (o.nsplit > 0) {
+      ns = o.nsplit;
+    } else {
+      ns = (int)std::max<long long>(1, 256 / std::max<long long>(1, blocks));
+      ns = std::min(ns, std::max(1, KC / 2));
+      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
+      while (ns > 1 && ns * slice_mb > 24.0) --ns;
+    }
+    pc.nsplit = std::max(1, std::min(ns, KC));
+  } else if (halo >= 0) {
     pc.tile = 100 + halo;
     pc.bk = 32;
     pc.CoutW = round_up(ncols, halo_tile_co(halo));

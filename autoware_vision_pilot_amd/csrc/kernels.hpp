@@ -106,6 +106,11 @@ int halo_tile_co(int tile);
 int halo_tile_px(int tile);
 int halo_tile_th(int tile);
 
+// small-map / long-K 3x3 (kernels_conv3x3_region.hip): shape 0 = 10x40 regions, 1 = 16x32 regions
+hipError_t launch_conv3x3_region(const ConvGemmParams& p, int shape, bool split, hipStream_t st);
+bool region_shape_fits(int shape, int H, int W);
+int region_count(int shape, int H, int W);
+int region_co(int shape, int CoutW);
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);

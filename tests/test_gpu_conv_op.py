@@ -42,6 +42,10 @@ CASES = [
     (64, 48, 10, 12, 2, 1, 0, 0),      # ConvTranspose2d k2 s2 -> pixel shuffle
     (64, 3, 24, 40, 3, 0, 0, 0),       # final-layer-like, 3 output channels
     (3, 32, 8, 8, 3, 0, 0, 0),         # fewer input channels than one K block
+    (96, 72, 20, 40, 3, 0, 1, 0),      # region kernel shapes (kernels_conv3x3_region.hip): two 10x40 regions
+    (64, 40, 40, 80, 3, 0, 0, 0),      # eight 10x40 regions, ragged channel tile
+    (160, 33, 16, 32, 3, 0, 1, 0),     # one 16x32 region (AutoDrive P5 maps)
+    (64, 32, 32, 64, 3, 0, 0, 0),      # four 16x32 regions
 ]
 
 
@@ -64,6 +68,11 @@ def test_conv_op_matches_torch(case, precision):
     cfgs = [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 32, 3), (3, 32, 1), (0, 64, 1), (2, 64, 2)]
     if ks == 3 and mode == 0 and h >= 8 and w >= 16:  # LDS-halo 3x3 kernel tiles (kernels_conv3x3.hip)
         cfgs += [(100, -1, 1), (101, -1, 2), (102, -1, 1), (103, -1, 3), (104, -1, 1)]
+    if ks == 3 and mode == 0 and res_mode == 0 and precision == 0:  # region kernel: fp16 engines, maps that tile into regions
+        if h % 10 == 0 and w % 40 == 0:
+            cfgs += [(200, -1, 1), (200, -1, 2)]
+        if h % 16 == 0 and w % 32 == 0:
+            cfgs += [(201, -1, 1), (201, -1, 3)]
     for tile, bk, nsplit in cfgs:
         got = lib.op_conv2d(x, wt, b, ks=ks, mode=mode, act=act, res=res, res_mode=res_mode, precision=precision, tile=tile, bk=bk,
                             nsplit=nsplit)
