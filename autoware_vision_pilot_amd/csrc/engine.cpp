@@ -411,9 +411,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         halo = (!split() && t256 * cdiv(ncols, 64) >= 400) ? 2 : 3;
       } else {
         halo = (!split() && t256 * (ncols / 128) >= 400) ? 0 : 1;
-        // between half and one full machine of 128-channel tiles: 64-channel tiles double the workgroup count with
-        // no split-K partial traffic (decode_layer_5: 46 us vs 57 us with a 3-way split, profiles/r01_splitk_ablation.txt)
-        if (halo == 1 && t128 * (ncols / 128) < 256 && t128 * (ncols / 64) >= 256) halo = 3;
+        // fewer 128-channel tiles than CUs: 64-channel tiles double the workgroup count, so the layer needs no split-K
+        // (decode_layer_5: 46 us vs 57 us with a 3-way split) or half the split factor and half the fp32 partial
+        // traffic (neck layers at 20x40 / 40x80: -1..-5 us each; profiles/r01_splitk_ablation.txt)
+        if (halo == 1 && t128 * (ncols / 128) < 256) halo = 3;
       }
     }
     if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;

@@ -189,6 +189,12 @@ int main(int argc, char** argv) {
     for (int ns : {1, 2, 3, 6}) run_split<128, 8, 16>("dec3 512->512 40x80 t8x16", 40, 80, 512, 512, ns);
     for (int ns : {1, 2, 3}) run_split<128, 8, 16>("dec5 512->256 80x160 t8x16", 80, 160, 512, 256, ns);
     for (int ns : {1, 2, 3}) run_split<64, 8, 16>("dec5 512->256 80x160 co64 t8x16", 80, 160, 512, 256, ns);
+    for (int ns : {1, 2, 3}) run_split<64, 8, 16>("dec2 768->512 40x80 co64 t8x16", 40, 80, 768, 512, ns);
+    for (int ns : {1, 2, 3}) run_split<64, 8, 16>("dec3 512->512 40x80 co64 t8x16", 40, 80, 512, 512, ns);
+    for (int ns : {2, 4, 6, 10}) run_split<64, 8, 16>("dec0 1280->768 20x40 co64 t8x16", 20, 40, 1280, 768, ns);
+    for (int ns : {2, 4, 6, 10}) run_split<128, 8, 16>("dec0 1280->768 20x40 co128 t8x16", 20, 40, 1280, 768, ns);
+    for (int ns : {2, 4, 6}) run_split<64, 8, 16>("dec1 768->768 20x40 co64 t8x16", 20, 40, 768, 768, ns);
+    for (int ns : {2, 4, 6}) run_split<128, 8, 16>("dec1 768->768 20x40 co128 t8x16", 20, 40, 768, 768, ns);
     return 0;
   }
   run_shape<128, 16, 16>("dec8 128->128 320x640 t16x16", 320, 640, 128, 128);
