@@ -115,6 +115,18 @@ public:
     return vp_depth_resized_f32(engine_, reinterpret_cast<float *>(output_depth.data), frame_size.height, frame_size.width) == VP_OK;
   }
 
+  // MasksVisualizationEngine::visualize (common/visualizers/masks_visualization_engine.cpp:11-38) on the GPU: colour
+  // LUT + nearest resize + 50/50 blend with the frame of the last doInference; viz_type "scene" | "domain" | "egolanes".
+  bool visualizeMask(const std::string & viz_type, cv::Mat & blended, const cv::Size & frame_size)
+  {
+    if (!ran_) return false;
+    const int t = viz_type == "scene" ? VP_VIZ_SCENE : viz_type == "domain" ? VP_VIZ_DOMAIN : viz_type == "egolanes" ? VP_VIZ_EGOLANES : -1;
+    if (t < 0) return false;
+    blended.create(frame_size, CV_8UC3);
+    if (!blended.isContinuous()) return false;
+    return vp_visualize_mask_bgr8(engine_, t, blended.data) == VP_OK;
+  }
+
 private:
   vp_engine * engine_ = nullptr;
   int in_h_ = 0, in_w_ = 0;
