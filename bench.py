@@ -228,6 +228,10 @@ def main():
                        "frames_in_flight_per_gpu": len(engines)},
             "fps_per_gpu": round(fps_total / world, 2),
             "p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),
+            # FpsTimer-style split (common/benchmark/fps_timer.cpp:37-63) from the per-launch HIP events (eager, single stream)
+            "split_us": {"preprocess": round(1e3 * sum(float(t) for (n, _, _), t in zip(layers, ms) if n == "preprocess"), 1),
+                         "inference": round(1e3 * sum(float(t) for (n, _, _), t in zip(layers, ms) if n not in ("preprocess", "decode")), 1),
+                         "output_decode": round(1e3 * sum(float(t) for (n, _, _), t in zip(layers, ms) if n == "decode"), 1)},
             "roofline": roofline,
         }
         # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)

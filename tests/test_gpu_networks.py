@@ -31,7 +31,7 @@ def _rel(a, b):
     return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
 
 
-@pytest.mark.parametrize("size", [(720, 1280), (320, 640), (487, 651), (1080, 1920), (200, 300)])
+@pytest.mark.parametrize("size", [(720, 1280), (320, 640), (487, 651), (1080, 1920), (200, 300), (2160, 3840), (16, 16), (2, 3)])
 def test_preprocess_bit_exact(engines, size):
     from autoware_vision_pilot_amd import lib
     from oracle import pre_post
