@@ -146,3 +146,53 @@ def test_gather_world_size_2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def _pb_varint(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _pb_ld(field, payload):
+    return _pb_varint((field << 3) | 2) + _pb_varint(len(payload)) + payload
+
+
+def _onnx_tensor(name, a, raw=True):
+    dt = {np.dtype("float32"): 1, np.dtype("float16"): 10, np.dtype("int64"): 7}[a.dtype]
+    msg = b"".join(_pb_varint((1 << 3) | 0) + _pb_varint(d) for d in a.shape) + _pb_varint((2 << 3) | 0) + _pb_varint(dt)
+    msg += _pb_ld(8, name.encode())
+    msg += _pb_ld(9, a.tobytes()) if raw else _pb_ld(4, a.astype("<f4").tobytes())
+    return msg
+
+
+def test_onnx_initializer_reader_roundtrip(tmp_path):
+    """N2 (partial): the self-contained protobuf reader recovers named initializers (raw_data, packed float_data, fp16,
+    non-float tensors skipped by the packer) from an ONNX ModelProto laid out like the exporter's, and refuses fused ones."""
+    from autoware_vision_pilot_amd import weights as vw
+
+    rng = np.random.default_rng(0)
+    tensors = {"SceneNeck.decode_layer_0.weight": rng.standard_normal((4, 3, 3, 3)).astype(np.float32),
+               "SceneNeck.decode_layer_0.bias": rng.standard_normal((4,)).astype(np.float32),
+               "half.weight": rng.standard_normal((2, 5)).astype(np.float16),
+               "Backbone.encoder.0.1.num_batches_tracked": np.array([7], dtype=np.int64)}
+    graph = b"".join(_pb_ld(5, _onnx_tensor(k, v, raw=(i % 2 == 0) or v.dtype != np.float32)) for i, (k, v) in enumerate(tensors.items()))
+    graph = _pb_ld(2, b"main_graph") + graph                      # GraphProto.name = 2, .initializer = 5
+    model = _pb_varint((1 << 3) | 0) + _pb_varint(8) + _pb_ld(2, b"pytorch") + _pb_ld(7, graph)  # ir_version, producer_name, graph
+    path = tmp_path / "m.onnx"
+    path.write_bytes(model)
+    got = vw.load_onnx_initializers(str(path))
+    assert set(got) == set(tensors)
+    for k, v in tensors.items():
+        assert got[k].shape == v.shape and np.array_equal(got[k], v)
+    out = vw.export_onnx(str(path), str(tmp_path / "m.vpw"))
+    blob = open(out, "rb").read()
+    assert blob[:4] == b"VPW1" and int.from_bytes(blob[4:8], "little") == 3   # int64 counter dropped, fp16 widened
+    fused = _pb_ld(7, _pb_ld(5, _onnx_tensor("onnx::Conv_123", tensors["SceneNeck.decode_layer_0.weight"])))
+    (tmp_path / "f.onnx").write_bytes(fused)
+    with pytest.raises(ValueError, match="anonymous"):
+        vw.export_onnx(str(tmp_path / "f.onnx"), str(tmp_path / "f.vpw"))
