@@ -372,6 +372,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
                 (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
+  } else if (!(std::getenv("VP_CONVT_STREAM") && std::getenv("VP_CONVT_STREAM")[0] == '0') && convt_stream_supported(p, sp)) {
+    op.kernel = "convt_stream<k" + std::to_string(p.Cin + p.Cin2) + ">";
+    op.run = [p](hipStream_t st) { return launch_convt_stream(p, st); };
   } else {
     const int epi = (ks == 1 && !sp) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
     op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +

@@ -111,6 +111,9 @@ hipError_t launch_conv3x3_region(const ConvGemmParams& p, int shape, bool split,
 bool region_shape_fits(int shape, int H, int W);
 int region_count(int shape, int H, int W);
 int region_co(int shape, int CoutW);
+// persistent streaming ConvTranspose (+skip) for large maps with short K (kernels_convt_stream.hip)
+bool convt_stream_supported(const ConvGemmParams& p, bool split);
+hipError_t launch_convt_stream(const ConvGemmParams& p, hipStream_t st);
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
