@@ -662,12 +662,10 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
       const int sq = std::max(1, cin / 4);
       const int HWz = z->H * z->W;
-      // replica rows for the pool atomics: ~8 workgroups per row, 8..64 rows
+      // replica rows for the pool atomics: ~16 workgroups per row, 8..64 rows
       int se_rep = 8;
       {
-        const int cg8 = z->C >> 3;  // lane layout of dwconv_pool_kernel (act_io.hpp slab_cgl)
-        const int pxl = 256 / (cg8 >= 32 ? 32 : (cg8 >= 16 ? 16 : (cg8 >= 8 ? 8 : 4)));
-        const int nbx = (HWz + pxl - 1) / pxl;
+        const long long nbx = ((long long)HWz * (z->C >> 3) + 255) / 256;
         while (se_rep < kSeMaxReplicas && se_rep * 16 <= nbx) se_rep *= 2;
       }
       if (se_used + (size_t)se_rep * z->C > se_words) throw std::runtime_error("SE arena too small");

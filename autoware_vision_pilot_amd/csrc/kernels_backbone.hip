@@ -53,27 +53,28 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
 }
 
 // ------------------------------------------------------------------------- depthwise conv + SiLU + pool sums
-// Workgroup = CGL channel-octet lanes x PXL pixel lanes, ONE output pixel per thread (maximum parallelism: these
-// layers are latency-bound), all K*K taps loaded before the first FMA (branch-free: clamped address + mask).
-// The squeeze-excite average pool is fused: pixel lanes are reduced through LDS in a fixed order, then one
-// integer atomicAdd per channel per workgroup on a 2^24 fixed-point int64 accumulator.  Integer addition is
-// associative, so the result is bit-identical run to run whatever the workgroup order (fp32 atomics would not be).
+// One output pixel x 8 channels per thread, threads laid out over the FLAT (pixel, channel-octet) index: consecutive
+// threads walk the octets of one pixel, then the next pixel -- every lane is live whatever the channel count (the
+// power-of-two octet-lane layout idled 44 % of the lanes at 144 channels, 25 % at 96) and a wave's 16-byte accesses are
+// one contiguous run.  All K*K taps are loaded before the first FMA (latency-bound layers; branch-free: clamped address +
+// mask).  The squeeze-excite average pool is fused: every thread adds its 8 activations as 2^24 fixed-point int64 into
+// per-channel LDS accumulators (LDS atomics), then one global atomicAdd per channel per workgroup into one of `replicas`
+// rows.  Integer addition is associative, so the result is bit-identical run to run whatever the order (fp32 atomics
+// would not be).
 constexpr float kPoolFix = 16777216.0f;  // 2^24
 
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
-  __shared__ float red[256 * 8];
+  extern __shared__ unsigned long long red64[];  // [C]
   const int CG = p.in.C >> 3;
-  const int CGL = CG >= 32 ? 32 : (CG >= 16 ? 16 : (CG >= 8 ? 8 : 4));
-  const int PXL = 256 / CGL;
-  const int cl = threadIdx.x % CGL, pl = threadIdx.x / CGL;
-  const int cg = blockIdx.y * CGL + cl;
   const int OH = p.out.H, OW = p.out.W, HWo = OH * OW;
-  const int pix = blockIdx.x * PXL + pl;
+  for (int i = threadIdx.x; i < p.in.C; i += 256) red64[i] = 0ull;
+  __syncthreads();
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int pix = t / CG, cg = t - pix * CG;
   constexpr int pad = (K - 1) / 2;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool live = cg < CG && pix < HWo;
-  if (live) {
+  if (pix < HWo) {
+    float acc[8];
     const int oy = pix / OW, ox = pix - oy * OW;
     h8_t vh[K * K], vl[K * K];
     bool ok[K * K];
@@ -95,35 +96,27 @@ __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-      const float* wk = p.w + (size_t)t * p.in.C + cg * 8;
+    for (int tp = 0; tp < K * K; ++tp) {
+      const float* wk = p.w + (size_t)tp * p.in.C + cg * 8;
       const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wk), w1 = *reinterpret_cast<const f32x4_t*>(wk + 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float v = (float)vh[t][i];
-        if (p.in.lo) v += (float)vl[t][i];
-        v = ok[t] ? v : 0.0f;
+        float v = (float)vh[tp][i];
+        if (p.in.lo) v += (float)vl[tp][i];
+        v = ok[tp] ? v : 0.0f;
         acc[i] = fmaf(v, i < 4 ? w0[i] : w1[i - 4], acc[i]);
       }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = p.out.lo ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
     store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&red64[cg * 8 + i], (unsigned long long)(long long)__float2ll_rn(acc[i] * kPoolFix));
   }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = live ? acc[i] : 0.0f;
   __syncthreads();
-  if (pl == 0 && cg < CG) {
-    float s[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = red[cl * 8 + i];
-    for (int q = 1; q < PXL; ++q)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] += red[(q * CGL + cl) * 8 + i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * p.in.C + cg * 8 + i,
-                (unsigned long long)(long long)__float2ll_rn(s[i] * kPoolFix));
+  for (int i = threadIdx.x; i < p.in.C; i += 256) {
+    const unsigned long long v = red64[i];
+    if (v != 0ull) atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * p.in.C + i, v);
   }
 }
 
@@ -299,10 +292,11 @@ hipError_t launch_stem(const StemParams& p, hipStream_t st) {
   VP_LAUNCH(stem_kernel, dim3(nblk((long long)(p.H / 2) * (p.W / 2) * 4)), dim3(256), 0, st, p);
 }
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st) {
-  const int CG = p.in.C >> 3, CGL = slab_cgl(p.in.C), PXL = 256 / CGL;
-  const dim3 grid((p.out.H * p.out.W + PXL - 1) / PXL, (CG + CGL - 1) / CGL);
-  if (p.k == 3) VP_LAUNCH(dwconv_pool_kernel<3>, grid, dim3(256), 0, st, p);
-  if (p.k == 5) VP_LAUNCH(dwconv_pool_kernel<5>, grid, dim3(256), 0, st, p);
+  const long long threads = (long long)p.out.H * p.out.W * (p.in.C >> 3);
+  const dim3 grid(nblk(threads));
+  const size_t lds = (size_t)p.in.C * sizeof(unsigned long long);
+  if (p.k == 3) VP_LAUNCH(dwconv_pool_kernel<3>, grid, dim3(256), lds, st, p);
+  if (p.k == 5) VP_LAUNCH(dwconv_pool_kernel<5>, grid, dim3(256), lds, st, p);
   return hipErrorInvalidValue;
 }
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
