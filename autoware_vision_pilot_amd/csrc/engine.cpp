@@ -662,12 +662,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
       const int sq = std::max(1, cin / 4);
       const int HWz = z->H * z->W;
-      // replica rows for the pool atomics: ~16 workgroups per row, 8..64 rows
+      // replica rows for the pool atomics (a workgroup covers >= 32 pixels of one channel group): ~4 per row, 8..64 rows
       int se_rep = 8;
-      {
-        const long long nbx = ((long long)HWz * (z->C >> 3) + 255) / 256;
-        while (se_rep < kSeMaxReplicas && se_rep * 16 <= nbx) se_rep *= 2;
-      }
+      while (se_rep < kSeMaxReplicas && se_rep * 4 * 32 <= HWz) se_rep *= 2;
       if (se_used + (size_t)se_rep * z->C > se_words) throw std::runtime_error("SE arena too small");
       unsigned long long* sums = se_arena + se_used;
       se_used += (size_t)se_rep * z->C;

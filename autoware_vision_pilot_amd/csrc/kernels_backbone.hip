@@ -53,31 +53,43 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
 }
 
 // ------------------------------------------------------------------------- depthwise conv + SiLU + pool sums
-// One output pixel x 8 channels per thread, threads laid out over the FLAT (pixel, channel-octet) index: consecutive
-// threads walk the octets of one pixel, then the next pixel -- every lane is live whatever the channel count (the
-// power-of-two octet-lane layout idled 44 % of the lanes at 144 channels, 25 % at 96) and a wave's 16-byte accesses are
-// one contiguous run.  All K*K taps are loaded before the first FMA (latency-bound layers; branch-free: clamped address +
-// mask).  The squeeze-excite average pool is fused: every thread adds its 8 activations as 2^24 fixed-point int64 into
-// per-channel LDS accumulators (LDS atomics), then one global atomicAdd per channel per workgroup into one of `replicas`
-// rows.  Integer addition is associative, so the result is bit-identical run to run whatever the order (fp32 atomics
-// would not be).
+// One output pixel x 8 channels per thread.  A workgroup owns G channel-octets (G = the largest divisor of C/8 that
+// is <= 8, so no lane idles on a ragged channel count) x 256/G consecutive output pixels: a wave's 16-byte accesses cover
+// whole 128-byte runs, the K*K x 8G filter slice is staged ONCE per workgroup in LDS (it used to be 2*K*K dependent
+// 16-byte global loads per thread -- a serialised latency chain longer than the arithmetic), and the fused squeeze-excite
+// pool reduces 256/G pixels per channel in LDS before touching global memory.  All K*K taps are loaded before the first
+// FMA (latency-bound layers; branch-free: clamped address + mask) and overlap the filter staging.  Pool: every thread
+// adds its 8 activations as 2^24 fixed-point int64 into per-channel LDS accumulators, then one global atomicAdd per
+// channel per workgroup into one of `replicas` rows.  Integer addition is associative, so the result is bit-identical
+// run to run whatever the order (fp32 atomics would not be).
 constexpr float kPoolFix = 16777216.0f;  // 2^24
 
-template <int K>
-__global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
-  extern __shared__ unsigned long long red64[];  // [C]
-  const int CG = p.in.C >> 3;
-  const int OH = p.out.H, OW = p.out.W, HWo = OH * OW;
-  for (int i = threadIdx.x; i < p.in.C; i += 256) red64[i] = 0ull;
-  __syncthreads();
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int pix = t / CG, cg = t - pix * CG;
+static int dw_octets_per_group(int CG) {
+  for (int g = 8; g > 1; --g)
+    if (CG % g == 0) return g;
+  return 1;
+}
+
+template <int K, bool SPLIT>
+__global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p, const int G) {
+  extern __shared__ unsigned char dw_smem[];
+  const int GC = G * 8;                                            // channels of this workgroup
+  float* wl = reinterpret_cast<float*>(dw_smem);                   // [K*K][GC]
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(dw_smem + (size_t)K * K * GC * sizeof(float));  // [GC]
+  const int C = p.in.C, c0 = blockIdx.y * GC;
+  const int OW = p.out.W, HWo = p.out.H * OW;
+  const int PXB = 256 / G;
+  const int pl = threadIdx.x / G, og = threadIdx.x - pl * G;
+  const int pix = blockIdx.x * PXB + pl;
+  const bool live = pl < PXB && pix < HWo;
+  const int cc = c0 + og * 8;
   constexpr int pad = (K - 1) / 2;
-  if (pix < HWo) {
-    float acc[8];
+
+  h8_t vh[K * K], vl[SPLIT ? K * K : 1];
+  bool ok[K * K];
+  f32x4_t b0, b1;
+  if (live) {
     const int oy = pix / OW, ox = pix - oy * OW;
-    h8_t vh[K * K], vl[K * K];
-    bool ok[K * K];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * p.stride + ky - pad;
@@ -86,37 +98,47 @@ __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p) {
       for (int kx = 0; kx < K; ++kx) {
         const int ix = ox * p.stride + kx - pad;
         const bool o = yok && (unsigned)ix < (unsigned)p.in.W;
-        const size_t off = ((size_t)(o ? iy : 0) * p.in.W + (o ? ix : 0)) * p.in.C + cg * 8;
+        const size_t off = ((size_t)(o ? iy : 0) * p.in.W + (o ? ix : 0)) * C + cc;
         ok[ky * K + kx] = o;
         vh[ky * K + kx] = *reinterpret_cast<const h8_t*>(p.in.hi + off);
-        if (p.in.lo) vl[ky * K + kx] = *reinterpret_cast<const h8_t*>(p.in.lo + off);
+        if constexpr (SPLIT) vl[ky * K + kx] = *reinterpret_cast<const h8_t*>(p.in.lo + off);
       }
     }
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8), b1 = *reinterpret_cast<const f32x4_t*>(p.b + cg * 8 + 4);
+    b0 = *reinterpret_cast<const f32x4_t*>(p.b + cc);
+    b1 = *reinterpret_cast<const f32x4_t*>(p.b + cc + 4);
+  }
+  for (int i = threadIdx.x; i < K * K * G * 2; i += 256) {
+    const int tp = i / (G * 2), j = i - tp * (G * 2);
+    *reinterpret_cast<f32x4_t*>(wl + tp * GC + j * 4) = *reinterpret_cast<const f32x4_t*>(p.w + (size_t)tp * C + c0 + j * 4);
+  }
+  if (threadIdx.x < GC) red64[threadIdx.x] = 0ull;
+  __syncthreads();
+  if (live) {
+    float acc[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; }
 #pragma unroll
     for (int tp = 0; tp < K * K; ++tp) {
-      const float* wk = p.w + (size_t)tp * p.in.C + cg * 8;
+      const float* wk = wl + tp * GC + og * 8;
       const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wk), w1 = *reinterpret_cast<const f32x4_t*>(wk + 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float v = (float)vh[tp][i];
-        if (p.in.lo) v += (float)vl[tp][i];
+        if constexpr (SPLIT) v += (float)vl[tp][i];
         v = ok[tp] ? v : 0.0f;
         acc[i] = fmaf(v, i < 4 ? w0[i] : w1[i - 4], acc[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = p.out.lo ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
-    store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
+    for (int i = 0; i < 8; ++i) acc[i] = SPLIT ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
+    store8(p.out, (size_t)pix * p.out.C + cc, acc);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&red64[cg * 8 + i], (unsigned long long)(long long)__float2ll_rn(acc[i] * kPoolFix));
+    for (int i = 0; i < 8; ++i) atomicAdd(&red64[og * 8 + i], (unsigned long long)(long long)__float2ll_rn(acc[i] * kPoolFix));
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < p.in.C; i += 256) {
-    const unsigned long long v = red64[i];
-    if (v != 0ull) atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * p.in.C + i, v);
+  if (threadIdx.x < GC) {
+    const unsigned long long v = red64[threadIdx.x];
+    if (v != 0ull) atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * C + c0 + threadIdx.x, v);
   }
 }
 
@@ -167,18 +189,30 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
 // squeeze unit does a 16-byte-wide dot product (all loads of a row in flight).
 __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
   extern __shared__ __attribute__((aligned(16))) float mean[];
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    float s = 0.f;
-    if (p.sums) {
-      long long t = 0;
+  if (p.sums) {
+    // [replicas][C] int64 rows -> per-channel totals: the flat index is strided over the workgroup so that every thread's
+    // loads are independent and coalesced (a per-channel loop over 64 replica rows was a serial chain of L2 round trips);
+    // integer LDS atomics keep the total order-independent.
+    unsigned long long* tot = reinterpret_cast<unsigned long long*>(mean + p.C);
+    for (int c = threadIdx.x; c < p.C; c += 256) tot[c] = 0ull;
+    __syncthreads();
+    const int n = p.replicas * p.C;
 #pragma unroll 8
-      for (int r = 0; r < p.replicas; ++r) t += (long long)p.sums[(size_t)r * p.C + c];
-      s = (float)((double)t * (1.0 / 16777216.0));
-    } else {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const unsigned long long v = p.sums[i];
+      int c = i % p.C;
+      if (v != 0ull) atomicAdd(&tot[c], v);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256)
+      mean[c] = (float)((double)(long long)tot[c] * (1.0 / 16777216.0)) * p.inv_hw;
+  } else {
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+      float s = 0.f;
 #pragma unroll 4
       for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
+      mean[c] = s * p.inv_hw;
     }
-    mean[c] = s * p.inv_hw;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -292,11 +326,15 @@ hipError_t launch_stem(const StemParams& p, hipStream_t st) {
   VP_LAUNCH(stem_kernel, dim3(nblk((long long)(p.H / 2) * (p.W / 2) * 4)), dim3(256), 0, st, p);
 }
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st) {
-  const long long threads = (long long)p.out.H * p.out.W * (p.in.C >> 3);
-  const dim3 grid(nblk(threads));
-  const size_t lds = (size_t)p.in.C * sizeof(unsigned long long);
-  if (p.k == 3) VP_LAUNCH(dwconv_pool_kernel<3>, grid, dim3(256), lds, st, p);
-  if (p.k == 5) VP_LAUNCH(dwconv_pool_kernel<5>, grid, dim3(256), lds, st, p);
+  const int CG = p.in.C >> 3, G = dw_octets_per_group(CG), PXB = 256 / G;
+  const dim3 grid((p.out.H * p.out.W + PXB - 1) / PXB, CG / G);
+  const size_t lds = (size_t)p.k * p.k * G * 8 * sizeof(float) + (size_t)G * 8 * sizeof(unsigned long long);
+  const bool split = p.in.lo != nullptr;
+  if (split != (p.out.lo != nullptr)) return hipErrorInvalidValue;
+  if (p.k == 3 && !split) VP_LAUNCH((dwconv_pool_kernel<3, false>), grid, dim3(256), lds, st, p, G);
+  if (p.k == 5 && !split) VP_LAUNCH((dwconv_pool_kernel<5, false>), grid, dim3(256), lds, st, p, G);
+  if (p.k == 3) VP_LAUNCH((dwconv_pool_kernel<3, true>), grid, dim3(256), lds, st, p, G);
+  if (p.k == 5) VP_LAUNCH((dwconv_pool_kernel<5, true>), grid, dim3(256), lds, st, p, G);
   return hipErrorInvalidValue;
 }
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
@@ -304,7 +342,7 @@ hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
   VP_LAUNCH(pool_partial_kernel, dim3(p.nslab, (CG + CGL - 1) / CGL), dim3(256), 0, st, p);
 }
 hipError_t launch_se_fc1(const SeParams& p, hipStream_t st) {
-  VP_LAUNCH(se_fc1_kernel, dim3((p.sq + 3) / 4), dim3(256), p.C * sizeof(float), st, p);
+  VP_LAUNCH(se_fc1_kernel, dim3((p.sq + 3) / 4), dim3(256), p.C * (sizeof(float) + sizeof(unsigned long long)), st, p);
 }
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st) {
   VP_LAUNCH(se_scale_weights_kernel, dim3(p.C / 32), dim3(256), 0, st, p);
