@@ -189,30 +189,18 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
 // squeeze unit does a 16-byte-wide dot product (all loads of a row in flight).
 __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
   extern __shared__ __attribute__((aligned(16))) float mean[];
-  if (p.sums) {
-    // [replicas][C] int64 rows -> per-channel totals: the flat index is strided over the workgroup so that every thread's
-    // loads are independent and coalesced (a per-channel loop over 64 replica rows was a serial chain of L2 round trips);
-    // integer LDS atomics keep the total order-independent.
-    unsigned long long* tot = reinterpret_cast<unsigned long long*>(mean + p.C);
-    for (int c = threadIdx.x; c < p.C; c += 256) tot[c] = 0ull;
-    __syncthreads();
-    const int n = p.replicas * p.C;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float s = 0.f;
+    if (p.sums) {
+      long long t = 0;
 #pragma unroll 8
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const unsigned long long v = p.sums[i];
-      int c = i % p.C;
-      if (v != 0ull) atomicAdd(&tot[c], v);
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += 256)
-      mean[c] = (float)((double)(long long)tot[c] * (1.0 / 16777216.0)) * p.inv_hw;
-  } else {
-    for (int c = threadIdx.x; c < p.C; c += 256) {
-      float s = 0.f;
+      for (int r = 0; r < p.replicas; ++r) t += (long long)p.sums[(size_t)r * p.C + c];
+      s = (float)((double)t * (1.0 / 16777216.0));
+    } else {
 #pragma unroll 4
       for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
-      mean[c] = s * p.inv_hw;
     }
+    mean[c] = s * p.inv_hw;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -342,7 +330,7 @@ hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
   VP_LAUNCH(pool_partial_kernel, dim3(p.nslab, (CG + CGL - 1) / CGL), dim3(256), 0, st, p);
 }
 hipError_t launch_se_fc1(const SeParams& p, hipStream_t st) {
-  VP_LAUNCH(se_fc1_kernel, dim3((p.sq + 3) / 4), dim3(256), p.C * (sizeof(float) + sizeof(unsigned long long)), st, p);
+  VP_LAUNCH(se_fc1_kernel, dim3((p.sq + 3) / 4), dim3(256), p.C * sizeof(float), st, p);
 }
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st) {
   VP_LAUNCH(se_scale_weights_kernel, dim3(p.C / 32), dim3(256), 0, st, p);
