@@ -66,51 +66,44 @@ struct Folded {
   int cout = 0, cin = 0, k = 0;  // cin = per-group input channels
 };
 
-// conv(no bias) + BatchNorm(eval) -> conv with bias:  w' = w * g/sqrt(v+eps),  b' = beta - mean * g/sqrt(v+eps)
-Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) {
-  const HostTensor& w = blob.get(p + ".0.weight");
-  const HostTensor& g = blob.get(p + ".1.weight");
-  const HostTensor& beta = blob.get(p + ".1.bias");
-  const HostTensor& mean = blob.get(p + ".1.running_mean");
-  const HostTensor& var = blob.get(p + ".1.running_var");
-  if (w.shape.size() != 4) throw std::runtime_error("conv weight rank != 4: " + p);
+// conv(no bias) + BatchNorm(eval) -> conv with bias:  w' = w * g/sqrt(v+eps),  b' = beta - mean * g/sqrt(v+eps).
+// A blob converted from an ONNX file exported with do_constant_folding=True (Models/exports/convert_pytorch_to_onnx.py:
+// 144-154) carries that product already: `<conv>.weight` + `<conv>.bias` and NO norm tensors (weights.py export_onnx) --
+// taken as is.  Anything in between (norm present but incomplete, or neither) fails loudly in blob.get().
+Folded fold_conv(const WeightBlob& blob, const std::string& conv, const std::string& norm, float eps) {
+  const HostTensor& w = blob.get(conv + ".weight");
+  if (w.shape.size() != 4) throw std::runtime_error("conv weight rank != 4: " + conv);
   Folded f;
   f.cout = w.shape[0];
   f.cin = w.shape[1];
   f.k = w.shape[2];
   const size_t per = (size_t)f.cin * f.k * f.k;
+  if (!blob.has(norm + ".weight") && blob.has(conv + ".bias")) {  // exporter-folded
+    const HostTensor& b = blob.get(conv + ".bias");
+    if ((int)b.data.size() != f.cout) throw std::runtime_error("folded conv bias length != Cout: " + conv);
+    f.w = w.data;
+    f.b = b.data;
+    return f;
+  }
+  const HostTensor& g = blob.get(norm + ".weight");
+  const HostTensor& beta = blob.get(norm + ".bias");
+  const HostTensor& mean = blob.get(norm + ".running_mean");
+  const HostTensor& var = blob.get(norm + ".running_var");
   f.w.resize(w.data.size());
   f.b.resize(f.cout);
   for (int co = 0; co < f.cout; ++co) {
-    const float s = g.data[co] / std::sqrt(var.data[co] + kBnEps);
+    const float s = g.data[co] / std::sqrt(var.data[co] + eps);
     for (size_t i = 0; i < per; ++i) f.w[co * per + i] = w.data[co * per + i] * s;
     f.b[co] = beta.data[co] - mean.data[co] * s;
   }
   return f;
 }
 
+// torchvision Conv2dNormActivation: Sequential(0: conv, 1: BatchNorm2d eps 1e-5)
+Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) { return fold_conv(blob, p + ".0", p + ".1", kBnEps); }
+
 // common_layers.py:5-14 Conv: `conv` (no bias) + `norm` (BatchNorm2d eps 1e-3)
-Folded fold_conv_norm(const WeightBlob& blob, const std::string& p) {
-  const HostTensor& w = blob.get(p + ".conv.weight");
-  const HostTensor& g = blob.get(p + ".norm.weight");
-  const HostTensor& beta = blob.get(p + ".norm.bias");
-  const HostTensor& mean = blob.get(p + ".norm.running_mean");
-  const HostTensor& var = blob.get(p + ".norm.running_var");
-  if (w.shape.size() != 4) throw std::runtime_error("conv weight rank != 4: " + p);
-  Folded f;
-  f.cout = w.shape[0];
-  f.cin = w.shape[1];
-  f.k = w.shape[2];
-  const size_t per = (size_t)f.cin * f.k * f.k;
-  f.w.resize(w.data.size());
-  f.b.resize(f.cout);
-  for (int co = 0; co < f.cout; ++co) {
-    const float s = g.data[co] / std::sqrt(var.data[co] + 1e-3f);
-    for (size_t i = 0; i < per; ++i) f.w[co * per + i] = w.data[co * per + i] * s;
-    f.b[co] = beta.data[co] - mean.data[co] * s;
-  }
-  return f;
-}
+Folded fold_conv_norm(const WeightBlob& blob, const std::string& p) { return fold_conv(blob, p + ".conv", p + ".norm", 1e-3f); }
 
 void split_half(float v, half_t* hi, half_t* lo) {
   const half_t h = (half_t)v;

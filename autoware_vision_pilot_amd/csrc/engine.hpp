@@ -37,6 +37,10 @@ class WeightBlob {
   std::map<std::string, HostTensor> t_;
 };
 
+// onnx_reader.cpp: ONNX file (reference exporter settings) -> tensors in state_dict naming / the same as a VPW1 blob.
+std::map<std::string, HostTensor> load_onnx_state_dict(const std::string& path);
+std::vector<char> onnx_to_blob(const std::string& path);
+
 struct Act {
   std::string name;
   int Creal = 0, C = 0, H = 0, W = 0;

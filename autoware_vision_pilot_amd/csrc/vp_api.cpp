@@ -1,4 +1,5 @@
 // C ABI of libvp_hip.so (declarations + reference citations: include/vp_hip.h).  No exception crosses it.
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -64,6 +65,41 @@ int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int p
   }
 }
 
+// Weight file -> VPW1 bytes.  `*.onnx` (the reference's `model_path`, ROS2/models/config/autoseg.yaml:3) goes through
+// the native ONNX reader; anything else is read as a VPW1 blob.
+int read_weights(const char* path, std::vector<char>& buf, char* err, size_t err_len) {
+  const std::string p(path);
+  auto ends_with = [&](const char* suf) {
+    const size_t n = std::strlen(suf);
+    if (p.size() < n) return false;
+    for (size_t i = 0; i < n; ++i)
+      if (std::tolower((unsigned char)p[p.size() - n + i]) != suf[i]) return false;
+    return true;
+  };
+  if (ends_with(".onnx")) {
+    try {
+      buf = vp::onnx_to_blob(p);
+      return VP_OK;
+    } catch (const std::exception& ex) {
+      set_err(err, err_len, ex.what());
+      return VP_ERR_WEIGHTS;
+    }
+  }
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) {
+    set_err(err, err_len, std::string("cannot open weight file: ") + path);
+    return VP_ERR_WEIGHTS;
+  }
+  const std::streamsize n = f.tellg();
+  f.seekg(0);
+  buf.resize((size_t)n);
+  if (n && !f.read(buf.data(), n)) {
+    set_err(err, err_len, "short read on weight file");
+    return VP_ERR_WEIGHTS;
+  }
+  return VP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -84,18 +120,8 @@ int vp_create(vp_engine** out, int model_kind, const char* weights_path, int pre
     set_err(err, err_len, "No path to weight file provided");  // scene_seg_infer.py:33
     return VP_ERR_ARG;
   }
-  std::ifstream f(weights_path, std::ios::binary | std::ios::ate);
-  if (!f) {
-    set_err(err, err_len, std::string("cannot open weight file: ") + weights_path);
-    return VP_ERR_WEIGHTS;
-  }
-  const std::streamsize n = f.tellg();
-  f.seekg(0);
-  std::vector<char> buf((size_t)n);
-  if (!f.read(buf.data(), n)) {
-    set_err(err, err_len, "short read on weight file");
-    return VP_ERR_WEIGHTS;
-  }
+  std::vector<char> buf;
+  if (const int rc = read_weights(weights_path, buf, err, err_len)) return rc;
   return create_impl(out, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
 }
 
@@ -114,19 +140,28 @@ int vp_create_shared(vp_engine** out, vp_engine* base, int model_kind, const cha
     set_err(err, err_len, "No path to weight file provided");
     return VP_ERR_ARG;
   }
-  std::ifstream f(weights_path, std::ios::binary | std::ios::ate);
-  if (!f) {
-    set_err(err, err_len, std::string("cannot open weight file: ") + weights_path);
-    return VP_ERR_WEIGHTS;
-  }
-  const std::streamsize n = f.tellg();
-  f.seekg(0);
-  std::vector<char> buf((size_t)n);
-  if (!f.read(buf.data(), n)) {
-    set_err(err, err_len, "short read on weight file");
-    return VP_ERR_WEIGHTS;
-  }
+  std::vector<char> buf;
+  if (const int rc = read_weights(weights_path, buf, err, err_len)) return rc;
   return vp_create_shared_from_memory(out, base, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
+}
+
+int vp_convert_onnx(const char* onnx_path, const char* vpw_path, char* err, size_t err_len) {
+  if (!onnx_path || !*onnx_path || !vpw_path || !*vpw_path) {
+    set_err(err, err_len, "No path to weight file provided");
+    return VP_ERR_ARG;
+  }
+  try {
+    const std::vector<char> blob = vp::onnx_to_blob(onnx_path);
+    std::ofstream o(vpw_path, std::ios::binary | std::ios::trunc);
+    if (!o || !o.write(blob.data(), (std::streamsize)blob.size())) {
+      set_err(err, err_len, std::string("cannot write ") + vpw_path);
+      return VP_ERR_WEIGHTS;
+    }
+    return VP_OK;
+  } catch (const std::exception& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_WEIGHTS;
+  }
 }
 
 int vp_shared_level(const vp_engine* e) { return (e && e->impl) ? e->impl->shared_level() : -1; }

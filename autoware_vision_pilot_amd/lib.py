@@ -66,6 +66,7 @@ _SIGS = {
     "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
     "vp_version": (C.c_char_p, []),
+    "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -94,6 +95,16 @@ def load():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def convert_onnx(onnx_path, vpw_path):
+    """ONNX file (reference exporter settings) -> VPW1 blob file with the library's native reader (csrc/onnx_reader.cpp;
+    host only, no GPU needed).  `Engine(kind, "model.onnx")` does the same conversion in memory."""
+    err = C.create_string_buffer(512)
+    rc = load().vp_convert_onnx(os.fsencode(onnx_path), os.fsencode(vpw_path), err, len(err))
+    if rc != 0:
+        raise (ValueError if rc == -1 else VpError)(f"vp_convert_onnx failed ({rc}): {err.value.decode(errors='replace')}")
+    return vpw_path
 
 
 class Engine:

@@ -32,6 +32,27 @@ def pack_state_dict(sd):
     return b"".join(out)
 
 
+def unpack_blob(blob):
+    """Inverse of pack_state_dict: VPW1 bytes -> {name: float32 array}."""
+    blob = bytes(blob)
+    if blob[:4] != b"VPW1":
+        raise ValueError("not a VPW1 blob")
+    (count,), i, out = struct.unpack_from("<I", blob, 4), 8, {}
+    for _ in range(count):
+        (nl,) = struct.unpack_from("<H", blob, i)
+        name = blob[i + 2:i + 2 + nl].decode()
+        i += 2 + nl
+        nd = blob[i]
+        dims = struct.unpack_from(f"<{nd}I", blob, i + 1)
+        i += 1 + 4 * nd
+        n = int(np.prod(dims)) if nd else 1
+        out[name] = np.frombuffer(blob, dtype="<f4", count=n, offset=i).reshape(dims).copy()
+        i += 4 * n
+    if i != len(blob):
+        raise ValueError("trailing bytes after the last tensor")
+    return out
+
+
 def export_checkpoint(pth_path, out_path):
     """Convert a reference ``.pth`` state_dict (Models/inference/scene_seg_infer.py:30-31) to a blob file."""
     import torch  # only needed for reading the pickle
@@ -45,13 +66,18 @@ def export_checkpoint(pth_path, out_path):
     return out_path
 
 
-# ------------------------------------------------------------------------------------------------ ONNX initializers
-# SURVEY.md 8f N2 (partial).  The reference ships / exports its models as ONNX (Models/exports/convert_pytorch_to_onnx.py:
-# opset 18, export_params=True, external_data=False), and the ROS parameters name `model_path: *.onnx`.  This reads the
-# GRAPH INITIALIZERS of such a file with a self-contained protobuf wire-format parser (no `onnx` package) so that files
-# whose initializers keep the state_dict names -- torch.export-based exports, or do_constant_folding=False -- convert to
-# the engine's blob.  Not handled (stated, not guessed): exporter-fused Conv+BatchNorm initializers with anonymous
-# names ("onnx::Conv_123"); no exporter-made file exists in the reference tree to pin that mapping against.
+# ------------------------------------------------------------------------------------------------ ONNX files
+# SURVEY.md 8f N2.  The reference ships / exports its models as ONNX (Models/exports/convert_pytorch_to_onnx.py:144-154:
+# opset 18, export_params=True, do_constant_folding=True, external_data=False) and the ROS parameters name
+# `model_path: *.onnx`.  This reads such a file with a self-contained protobuf wire-format parser (no `onnx` package):
+#   * initializers that kept their state_dict names (plain convs, linears, stand-alone norms) pass through verbatim;
+#   * a Conv / ConvTranspose whose weight and bias are exporter-made anonymous tensors ("onnx::Conv_626": Conv+BatchNorm
+#     folded by constant folding) is named from the node's module scope ("/backbone/p3/p3.0/conv/Conv" ->
+#     "backbone.p3.0.conv"), emitted as `<conv>.weight` + `<conv>.bias` with no norm tensors -- csrc/engine.cpp fold_conv
+#     takes that form as is; a second invocation of the same module (suffix "_1", identical tensors) is dropped;
+#   * a bias-free Linear exported as MatMul with a transposed anonymous weight becomes `<module>.weight`.
+# Pinned against real exporter output: tests/golden/tiny_export.onnx (nested Sequentials, repeated module) and, where
+# /root/reference exists, the reference's own AutoDrive module (oracle/pin_autodrive_onnx.py).
 def _varint(buf, i):
     r, s = 0, 0
     while True:
@@ -143,13 +169,96 @@ def load_onnx_initializers(path):
     return out
 
 
+def _graph(path):
+    """(initializers, nodes) of the model's graph; nodes = [(op_type, name, inputs, outputs)] in file order
+    (ModelProto.graph = 7; GraphProto.node = 1, initializer = 5; NodeProto.input = 1, output = 2, name = 3, op_type = 4)."""
+    with open(path, "rb") as fh:
+        model = memoryview(fh.read())
+    inits, nodes = {}, []
+    for f, wt, v in _fields(model):
+        if f != 7 or wt != 2:
+            continue
+        for gf, gwt, gv in _fields(v):
+            if gwt != 2:
+                continue
+            if gf == 5:
+                name, a = _tensor_proto(gv)
+                if a is not None and name:
+                    inits[name] = a
+            elif gf == 1:
+                ins, outs, name, op = [], [], "", ""
+                for nf, nwt, nv in _fields(gv):
+                    if nwt != 2:
+                        continue
+                    if nf == 1:
+                        ins.append(bytes(nv).decode())
+                    elif nf == 2:
+                        outs.append(bytes(nv).decode())
+                    elif nf == 3:
+                        name = bytes(nv).decode()
+                    elif nf == 4:
+                        op = bytes(nv).decode()
+                nodes.append((op, name, ins, outs))
+    return inits, nodes
+
+
+def _is_anonymous(name):
+    return name.startswith("onnx::") or "." not in name
+
+
+def _scope_prefix(node_name):
+    """'/backbone/p5/p5.3/middle_block/conv2/conv2.0/conv/Conv' -> 'backbone.p5.3.middle_block.conv2.0.conv': the
+    TorchScript exporter writes one path segment per module level and spells a container's child as '<container>.<idx>'."""
+    comps = []
+    for seg in node_name.strip("/").split("/")[:-1]:
+        if comps and seg.startswith(comps[-1] + "."):
+            comps[-1] = seg
+        else:
+            comps.append(seg)
+    return ".".join(comps)
+
+
+def load_onnx_state_dict(path):
+    """name -> numpy array in the reference state_dict's naming (see the section comment); raises on a weight it cannot name."""
+    inits, nodes = _graph(path)
+    out = {k: v for k, v in inits.items() if not _is_anonymous(k) and v.dtype.kind == "f"}
+    unnamed = []
+    for op, name, ins, _ in nodes:
+        if op in ("Conv", "ConvTranspose") and len(ins) >= 2 and ins[1] in inits and _is_anonymous(ins[1]):
+            tensors = [("weight", inits[ins[1]])]
+            if len(ins) >= 3 and ins[2] in inits:
+                tensors.append(("bias", inits[ins[2]]))
+        elif op == "MatMul" and len(ins) == 2 and ins[1] in inits and _is_anonymous(ins[1]) and inits[ins[1]].ndim == 2:
+            tensors = [("weight", np.ascontiguousarray(inits[ins[1]].T))]
+        else:
+            continue
+        prefix = _scope_prefix(name)
+        if not prefix:
+            unnamed.append(f"{op} node '{name}' ({ins[1]})")
+            continue
+        head, _, leaf = prefix.rpartition(".")
+        base, sep, idx = leaf.rpartition("_")
+        if sep and idx.isdigit():  # 2nd, 3rd ... invocation of one module: same tensors under the un-suffixed name
+            first = (head + "." if head else "") + base
+            if first + ".weight" in out and all(
+                    first + "." + t in out and out[first + "." + t].shape == a.shape and np.array_equal(out[first + "." + t], a)
+                    for t, a in tensors):
+                continue
+        for t, a in tensors:
+            key = prefix + "." + t
+            if key in out and not np.array_equal(out[key], a):
+                raise ValueError(f"two different tensors map to '{key}' (node '{name}')")
+            out[key] = a
+    if unnamed:
+        raise ValueError("cannot name exporter-folded weights without a module scope: " + "; ".join(unnamed[:4]))
+    return out
+
+
 def export_onnx(onnx_path, out_path):
-    """ONNX file whose initializers carry the reference state_dict names -> VPW1 blob (floating-point tensors only)."""
-    sd = load_onnx_initializers(onnx_path)
-    anon = [k for k in sd if k.startswith("onnx::")]
-    if anon:
-        raise ValueError(f"{len(anon)} exporter-fused anonymous initializers (e.g. {anon[0]}): export with the torch.export-based "
-                         "exporter or do_constant_folding=False, or convert the .pth checkpoint with export_checkpoint")
+    """ONNX file made by the reference's exporter settings -> VPW1 blob (floating-point tensors only)."""
+    sd = load_onnx_state_dict(onnx_path)
+    if not sd:
+        raise ValueError(f"{onnx_path}: no floating-point weights found")
     with open(out_path, "wb") as f:
         f.write(pack_state_dict(sd))
     return out_path

@@ -72,12 +72,18 @@ enum vp_decode_mode {
   VP_DECODE_CLASS_INDEX = 2 /* raw argmax index (first maximum wins) */
 };
 
-/* ---- lifetime ------------------------------------------------------------------------------------------ */
+/* ---- lifetime ------------------------------------------------------------------------------------------
+ * weights_path: a VPW1 blob (autoware_vision_pilot_amd/weights.py) or -- as the reference's backends take
+ * (`model_path: *.onnx`, ROS2/models/config/autoseg.yaml:3; OnnxRuntimeBackend ctor onnx_runtime_backend.cpp:14-38) --
+ * an `.onnx` file made by Models/exports/convert_pytorch_to_onnx.py:144-154.  ONNX files are read by the library's own
+ * wire-format parser (csrc/onnx_reader.cpp): weights only, the graph is the engine's. */
 int vp_create(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, char* err, size_t err_len);
 int vp_create_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id,
                           char* err, size_t err_len);
 void vp_destroy(vp_engine* e);
 const char* vp_last_error(const vp_engine* e);
+/* Host only (no HIP device needed): ONNX file -> VPW1 blob file, the conversion vp_create does in memory. */
+int vp_convert_onnx(const char* onnx_path, const char* vpw_path, char* err, size_t err_len);
 
 /* ---- shared-prefix engines (BASELINE configs[2]: SceneSeg + Scene3D + EgoLanes on one camera) -----------
  * The reference builds Scene3D and DomainSeg ON a pre-trained SceneSeg: Scene3DNetwork wraps its backbone

@@ -107,6 +107,9 @@ def quantize_fp8_e4m3(sd):
 def _conv_bn_act(sd, p, x, stride=1, groups=1, act=True):
     """common_layers.py:5-14  Conv = conv(no bias, pad k//2) -> BN(eval, eps 1e-3) -> activation."""
     w = sd[p + ".conv.weight"]
+    if p + ".norm.weight" not in sd:  # exporter-folded form (weights.py load_onnx_state_dict): conv carries the bias
+        y = F.conv2d(x, w, sd[p + ".conv.bias"], stride=stride, padding=w.shape[-1] // 2, groups=groups)
+        return F.silu(y) if act else y
     y = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2, groups=groups)
     y = F.batch_norm(y, sd[p + ".norm.running_mean"], sd[p + ".norm.running_var"], sd[p + ".norm.weight"], sd[p + ".norm.bias"],
                      training=False, eps=BN_EPS)

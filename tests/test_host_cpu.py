@@ -148,31 +148,12 @@ def test_gather_world_size_2_gloo(tmp_path):
         assert "ok" in o
 
 
-def _pb_varint(n):
-    out = bytearray()
-    while True:
-        b = n & 0x7F
-        n >>= 7
-        out.append(b | (0x80 if n else 0))
-        if not n:
-            return bytes(out)
-
-
-def _pb_ld(field, payload):
-    return _pb_varint((field << 3) | 2) + _pb_varint(len(payload)) + payload
-
-
-def _onnx_tensor(name, a, raw=True):
-    dt = {np.dtype("float32"): 1, np.dtype("float16"): 10, np.dtype("int64"): 7}[a.dtype]
-    msg = b"".join(_pb_varint((1 << 3) | 0) + _pb_varint(d) for d in a.shape) + _pb_varint((2 << 3) | 0) + _pb_varint(dt)
-    msg += _pb_ld(8, name.encode())
-    msg += _pb_ld(9, a.tobytes()) if raw else _pb_ld(4, a.astype("<f4").tobytes())
-    return msg
+from pbwriter import _onnx_tensor, _pb_ld, _pb_varint  # noqa: E402  (tests/pbwriter.py)
 
 
 def test_onnx_initializer_reader_roundtrip(tmp_path):
-    """N2 (partial): the self-contained protobuf reader recovers named initializers (raw_data, packed float_data, fp16,
-    non-float tensors skipped by the packer) from an ONNX ModelProto laid out like the exporter's, and refuses fused ones."""
+    """N2: the self-contained protobuf reader recovers named initializers (raw_data, packed float_data, fp16,
+    non-float tensors skipped by the packer) from an ONNX ModelProto laid out like the exporter's."""
     from autoware_vision_pilot_amd import weights as vw
 
     rng = np.random.default_rng(0)
@@ -192,7 +173,78 @@ def test_onnx_initializer_reader_roundtrip(tmp_path):
     out = vw.export_onnx(str(path), str(tmp_path / "m.vpw"))
     blob = open(out, "rb").read()
     assert blob[:4] == b"VPW1" and int.from_bytes(blob[4:8], "little") == 3   # int64 counter dropped, fp16 widened
-    fused = _pb_ld(7, _pb_ld(5, _onnx_tensor("onnx::Conv_123", tensors["SceneNeck.decode_layer_0.weight"])))
-    (tmp_path / "f.onnx").write_bytes(fused)
-    with pytest.raises(ValueError, match="anonymous"):
+    # an exporter-folded weight can only be named from its node's module scope: a scope-less node is refused, loudly
+    anon = _pb_ld(5, _onnx_tensor("onnx::Conv_123", tensors["SceneNeck.decode_layer_0.weight"]))
+    node = _pb_ld(1, _pb_ld(1, b"x") + _pb_ld(1, b"onnx::Conv_123") + _pb_ld(2, b"y") + _pb_ld(3, b"Conv_0") + _pb_ld(4, b"Conv"))
+    (tmp_path / "f.onnx").write_bytes(_pb_ld(7, node + anon))
+    with pytest.raises(ValueError, match="cannot name"):
         vw.export_onnx(str(tmp_path / "f.onnx"), str(tmp_path / "f.vpw"))
+    (tmp_path / "g.onnx").write_bytes(_pb_ld(7, anon))           # anonymous tensor no node consumes: nothing to load
+    with pytest.raises(ValueError, match="no floating-point weights"):
+        vw.export_onnx(str(tmp_path / "g.onnx"), str(tmp_path / "g.vpw"))
+
+
+def test_onnx_reader_names_exporter_folded_convs():
+    """N2: tests/golden/tiny_export.onnx was made by torch.onnx.export with the reference's exporter settings
+    (tests/golden/make_tiny_onnx.py): Conv+BatchNorm pairs arrive folded under anonymous names.  The reader must name them
+    from the node scopes (torchvision-style `encoder.1.0.block.0.0`, reference-style `stage.conv`), keep the named tensors
+    verbatim, transpose the bias-free Linear back, and drop the second invocation of the trunk."""
+    from autoware_vision_pilot_amd import weights as vw
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = dict(np.load(os.path.join(here, "tiny_export.npz")))
+    got = vw.load_onnx_state_dict(os.path.join(here, "tiny_export.onnx"))
+    convs = {}
+    for n in {k[:-len(".running_var")] for k in ref if k.endswith(".running_var")}:
+        head, leaf = n.rsplit(".", 1)
+        convs[head + (".conv" if leaf == "norm" else ".0")] = (n, 1e-3 if leaf == "norm" else 1e-5)
+    assert len(convs) == 8
+    want = {k for k in ref if not any(k.startswith(n + ".") for n, _ in convs.values())} | {c + ".bias" for c in convs}
+    assert set(got) == want
+    for c, (n, eps) in convs.items():
+        s = ref[n + ".weight"] / np.sqrt(ref[n + ".running_var"] + np.float32(eps))
+        w = ref[c + ".weight"] * s[:, None, None, None]
+        b = ref[n + ".bias"] - ref[n + ".running_mean"] * s
+        assert np.allclose(got[c + ".weight"], w, rtol=1e-5, atol=1e-7), c
+        assert np.allclose(got[c + ".bias"], b, rtol=1e-5, atol=1e-7), c
+    for k in ("plain.weight", "plain.bias", "up.weight", "up.bias", "fc.weight", "fc.bias", "proj.weight"):
+        assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k
+    assert vw._scope_prefix("/backbone/p5/p5.3/middle_block/conv2/conv2.0/conv/Conv") == "backbone.p5.3.middle_block.conv2.0.conv"
+
+
+def test_native_onnx_reader_matches_python_reader(tmp_path):
+    """csrc/onnx_reader.cpp (what vp_create runs on a `*.onnx` model_path) against weights.load_onnx_state_dict, tensor by
+    tensor, on the exporter-made fixture; host only -- vp_convert_onnx needs no HIP device.  Also the hand-laid-out file of
+    the reader round-trip test (fp16 raw_data, packed float_data, an int64 tensor to skip) and the two refusals."""
+    from autoware_vision_pilot_amd import lib, weights as vw
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    out = lib.convert_onnx(os.path.join(here, "tiny_export.onnx"), str(tmp_path / "tiny.vpw"))
+    got = vw.unpack_blob(open(out, "rb").read())
+    want = vw.load_onnx_state_dict(os.path.join(here, "tiny_export.onnx"))
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert got[k].shape == v.shape and np.array_equal(got[k], v.astype(np.float32)), k
+    assert vw.unpack_blob(vw.pack_state_dict(want)).keys() == got.keys()
+
+    rng = np.random.default_rng(1)
+    tensors = {"a.weight": rng.standard_normal((4, 3, 3, 3)).astype(np.float32), "a.bias": rng.standard_normal((4,)).astype(np.float32),
+               "half.weight": rng.standard_normal((2, 5)).astype(np.float16), "sub.weight": np.array([6e-8, -3e-6, 65504.0], dtype=np.float16),
+               "n.num_batches_tracked": np.array([7], dtype=np.int64)}
+    graph = b"".join(_pb_ld(5, _onnx_tensor(k, v, raw=(i % 2 == 0) or v.dtype != np.float32)) for i, (k, v) in enumerate(tensors.items()))
+    (tmp_path / "m.onnx").write_bytes(_pb_ld(7, _pb_ld(2, b"main_graph") + graph))
+    got = vw.unpack_blob(open(lib.convert_onnx(str(tmp_path / "m.onnx"), str(tmp_path / "m.vpw")), "rb").read())
+    assert set(got) == {"a.weight", "a.bias", "half.weight", "sub.weight"}
+    for k in got:
+        assert np.array_equal(got[k], tensors[k].astype(np.float32)), k
+
+    anon = _pb_ld(5, _onnx_tensor("onnx::Conv_123", tensors["a.weight"]))
+    node = _pb_ld(1, _pb_ld(1, b"x") + _pb_ld(1, b"onnx::Conv_123") + _pb_ld(2, b"y") + _pb_ld(3, b"Conv_0") + _pb_ld(4, b"Conv"))
+    (tmp_path / "f.onnx").write_bytes(_pb_ld(7, node + anon))
+    with pytest.raises(lib.VpError, match="cannot name"):
+        lib.convert_onnx(str(tmp_path / "f.onnx"), str(tmp_path / "f.vpw"))
+    (tmp_path / "t.onnx").write_bytes(_pb_ld(7, graph)[:-9])      # truncated file
+    with pytest.raises(lib.VpError):
+        lib.convert_onnx(str(tmp_path / "t.onnx"), str(tmp_path / "t.vpw"))
+    with pytest.raises(lib.VpError, match="cannot open"):
+        lib.convert_onnx(str(tmp_path / "missing.onnx"), str(tmp_path / "x.vpw"))
