@@ -64,6 +64,29 @@ def pmc_traffic(tag):
     return {"bytes": round(f + w), "fetch_bytes": round(f), "write_bytes": round(w)}
 
 
+def cpu_baseline(kind, sd, frame, seconds, nthreads=0):
+    """The CPU oracle (oracle/nets.py, torch fp32) on `nthreads` host threads (0 = all, capped at 32): whole frames
+    (preprocess + forward + decode) for about `seconds`.  SURVEY.md 8(d) also asks for a per-core figure: --cpu-threads 1
+    (tools/cpu_baseline.py runs this leg alone, no GPU needed)."""
+    from oracle import nets, pre_post
+
+    nthreads = nthreads or min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(nthreads)
+    tsd = nets.to_torch(sd)
+    n_done, t_cpu = 0, 0.0
+    nets.forward(kind, tsd, torch.from_numpy(pre_post.preprocess(frame)))  # warm-up
+    while t_cpu < seconds and n_done < 50:
+        t1 = time.perf_counter()
+        x = torch.from_numpy(pre_post.preprocess(frame))
+        y = nets.forward(kind, tsd, x)[0].numpy()
+        pre_post.seg_mask_u8(y) if kind != "egolanes" else pre_post.egolanes_priority_mask(y)
+        t_cpu += time.perf_counter() - t1
+        n_done += 1
+    return {"value": round(n_done / t_cpu, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n_done} frames of the same 1280x720 workload (preprocess+forward+decode), torch "
+                      f"{torch.__version__} CPU fp32, {t_cpu:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +101,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, max 32)")
     ap.add_argument("--latency-iters", type=int, default=100)
     args = ap.parse_args()
 
@@ -236,23 +260,7 @@ def main():
         }
         # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import nets
-
-            nthreads = min(os.cpu_count() or 1, 32)
-            torch.set_num_threads(nthreads)
-            tsd = nets.to_torch(sd)
-            n_done, t_cpu = 0, 0.0
-            nets.forward(args.kind, tsd, torch.from_numpy(pre_post.preprocess(frame)))  # warm-up
-            while t_cpu < args.cpu_seconds and n_done < 50:
-                t1 = time.perf_counter()
-                x = torch.from_numpy(pre_post.preprocess(frame))
-                y = nets.forward(args.kind, tsd, x)[0].numpy()
-                pre_post.seg_mask_u8(y) if args.kind != "egolanes" else pre_post.egolanes_priority_mask(y)
-                t_cpu += time.perf_counter() - t1
-                n_done += 1
-            out["cpu_baseline"] = {"value": round(n_done / t_cpu, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
-                                   "sample": f"{n_done} frames of the same 1280x720 workload (preprocess+forward+decode), torch "
-                                             f"{torch.__version__} CPU fp32, {t_cpu:.1f} s"}
+            out["cpu_baseline"] = cpu_baseline(args.kind, sd, frame, args.cpu_seconds, args.cpu_threads)
     for e in engines:
         e.close()
     if dist is not None:
