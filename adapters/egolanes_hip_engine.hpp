@@ -21,7 +21,7 @@ class EgoLanesHipEngine
 {
 public:
   // provider / cache_dir are accepted for signature compatibility (the ONNX/TensorRT engines use them); precision:
-  // "fp16" or "fp32" (parity mode).  model_path is a VPW1 blob exported from the EgoLanes checkpoint.
+  // "fp16" or "fp32" (parity mode).  model_path: the EgoLanes `.onnx` file or a VPW1 blob exported from the checkpoint.
   EgoLanesHipEngine(const std::string & model_path, const std::string & provider = "hip", const std::string & precision = "fp16",
                     int device_id = 0, const std::string & cache_dir = "")
   {

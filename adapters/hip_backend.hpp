@@ -7,8 +7,8 @@
 //   * getRawTensorData() returns HOST fp32 NCHW logits owned by the backend, valid until the next doInference;
 //     getters throw std::runtime_error before the first inference (onnx_runtime_backend.cpp:86-91);
 //   * one instance per node / thread, not re-entrant, no global state.
-// `model_path` is a VPW1 weight blob (autoware_vision_pilot_amd/weights.py export_checkpoint converts the reference
-// .pth).  precision: "fp16" (fast) or "fp32" (fp16x3 parity mode).  Header-only; include it from the node exactly
+// `model_path` is the reference's `.onnx` file (read natively by libvp_hip, csrc/onnx_reader.cpp) or a VPW1 weight blob
+// (autoware_vision_pilot_amd/weights.py export_checkpoint converts the reference .pth).  precision: "fp16" (fast) or "fp32" (fp16x3 parity mode).  Header-only; include it from the node exactly
 // where onnx_runtime_backend.hpp is included.
 #ifndef HIP_BACKEND_HPP_
 #define HIP_BACKEND_HPP_

@@ -611,7 +611,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
     op.name = "se_pool_zero";
     op.kernel = "zero_u64";
     op.bytes = 8.0 * se_words;
-    op.run = [se_arena, se_words](hipStream_t st) { return launch_zero_u64(se_arena, se_words, st); };
+    op.run = [se_arena](hipStream_t st) { return launch_zero_u64(se_arena, se_words, st); };
     ops_.push_back(std::move(op));
   }
   // ---- features[0]: stem

@@ -193,8 +193,6 @@ class Engine {
   bool have_outputs_ = false;
 
   // split-K scratch
-  float* d_partial_ = nullptr;
-  size_t partial_need_ = 0;
   std::vector<float**> partial_slots_;
 
   // resize scratch
@@ -208,7 +206,7 @@ class Engine {
   bool use_graph_ = true;
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;
-  bool graph_valid_ = false, graph_for_tensor_ = false;
+  bool graph_valid_ = false;
   bool warmed_ = false;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
 };

@@ -20,7 +20,8 @@
 namespace vp {
 
 // ABL: ablation bits for tools/halo_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA,
-// 4 = no LDS fragment reads, 8 = no barrier); always 0 in the library.
+// 4 = no LDS fragment reads, 8 = no barrier, 16 / 32 = de-phase the workgroups sharing a CU by TG_ID parity / block index
+// with `p.ks - 3` x s_sleep(127), the tool passes the count in ks -- DESIGN.md "Tried and dropped"); always 0 in the library.
 // FASTEPI: single-pass register GELU + fp16-staged epilogue (conv_epilogue.hpp epilogue_regs_fp16); the launcher
 // selects it when the layer is bias + ACT_GELU_F16 (VP_FP16 engines), no residual, NHWC, no split-K.
 template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0, bool FASTEPI = false>
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
       if (next_chunk || ((T) < 8)) VP_STORE_W(((T) + 1) % 3, wb ^ 1)                                  \
       VP_LOAD_W(((T) + 1) % 3, c * 9 + (T) + 4)                                                       \
       if constexpr ((T) >= 2 && (T) - 2 < HP) {                                                       \
-        if (next_chunk) VP_STORE_H(((T) - 2) % 3, (T) >= 2 ? (T) - 2 : 0, hb ^ 1)                     \
+        if (next_chunk) VP_STORE_H(((T) + 1) % 3 /* == (T - 2) % 3, never negative */, (T) >= 2 ? (T) - 2 : 0, hb ^ 1)                     \
       }                                                                                               \
     }                                                                                                 \
     if constexpr (!(ABL & 8)) __syncthreads();                                                        \
