@@ -1,0 +1,261 @@
+"""Synthetic data of the reference's shapes: seeded random-init weights in the reference ``state_dict`` key layout and
+seeded camera frames.  No dataset or checkpoint is reachable from the build / benchmark boxes, so ``bench.py``, the
+profiling tools and the tests all draw their inputs from here (BASELINE.json: "synthetic data of that shape, random-init
+weights of that architecture").  Pure data generation -- no network arithmetic lives in this module; the CPU oracle
+(``oracle/``, test infrastructure) re-exports these generators so checker and engine always see identical tensors.
+
+The key layout is the reference's ``state_dict`` key layout, so the same dict can be ``load_state_dict``-ed into the
+reference's own modules (oracle/pin_against_reference.py) and exported to the engine's weight blob (weights.py).
+
+Key prefixes:
+  SceneSeg  : Backbone.encoder.* SceneContext.* SceneNeck.* SceneSegHead.*
+              (Models/model_components/scene_seg_network.py:11-21)
+  Scene3D   : PreTrainedBackbone.pretrainedBackBone.encoder.* DepthContext.* DepthNeck.* SuperDepthHead.*
+              (scene_3d_network.py:13-22, pre_trained_backbone.py:10)
+  DomainSeg : DomainSegUpstream.{pretrainedBackBone.encoder,pretrainedContext,pretrainedNeck}.* DomainSegHead.*
+              (domain_seg_network.py:11-14, domain_seg_upstream.py:10-20)
+  EgoLanes  : BEVBackbone.encoder.* AutoSteerContext.* EgopathNeck.* EgoLanesHead.*
+              (ego_lanes_network.py:14-26)
+  AutoDrive : backbone.p1..p5.* head.*  (autodrive/autodrive_network.py, autodrive_backbone.py:8-48, autodrive_head.py:70-87)
+
+Init is NOT PyTorch's default: with default init the decoder contracts the signal ~0.6x/layer and argmax collapses to
+one class (SURVEY.md 8(d) init note), which would make every parity check vacuous.  A variance-preserving init is used.
+"""
+import numpy as np
+
+# torchvision efficientnet_b0 inverted-residual setting (published architecture):
+# (expand_ratio, kernel, stride, in_ch, out_ch, num_layers)
+B0_STAGES = [
+    (1, 3, 1, 32, 16, 1),
+    (6, 3, 2, 16, 24, 2),
+    (6, 5, 2, 24, 40, 2),
+    (6, 3, 2, 40, 80, 3),
+    (6, 5, 1, 80, 112, 3),
+    (6, 5, 2, 112, 192, 4),
+    (6, 3, 1, 192, 320, 1),
+]
+B0_STEM_OUT = 32
+B0_LAST_OUT = 1280
+BN_EPS = 1e-5
+
+MODEL_KINDS = ("sceneseg", "scene3d", "domainseg", "egolanes")
+
+PREFIX = {
+    "sceneseg": dict(backbone="Backbone.encoder.", context="SceneContext.",
+                     neck="SceneNeck.", head="SceneSegHead."),
+    "scene3d": dict(backbone="PreTrainedBackbone.pretrainedBackBone.encoder.", context="DepthContext.",
+                    neck="DepthNeck.", head="SuperDepthHead."),
+    "domainseg": dict(backbone="DomainSegUpstream.pretrainedBackBone.encoder.",
+                      context="DomainSegUpstream.pretrainedContext.",
+                      neck="DomainSegUpstream.pretrainedNeck.", head="DomainSegHead."),
+    "egolanes": dict(backbone="BEVBackbone.encoder.", context="AutoSteerContext.",
+                     neck="EgopathNeck.", head="EgoLanesHead."),
+}
+
+
+def _bn(p, c):
+    return [(p + ".weight", (c,), "bn_w"), (p + ".bias", (c,), "bn_b"),
+            (p + ".running_mean", (c,), "bn_mean"), (p + ".running_var", (c,), "bn_var")]
+
+
+def backbone_spec(prefix):
+    """(key, shape, kind) for every tensor of torchvision efficientnet_b0().features."""
+    s = [(prefix + "0.0.weight", (B0_STEM_OUT, 3, 3, 3), "conv")]
+    s += _bn(prefix + "0.1", B0_STEM_OUT)
+    for si, (e, k, st, cin, cout, n) in enumerate(B0_STAGES, start=1):
+        for bi in range(n):
+            ci = cin if bi == 0 else cout
+            cexp = ci * e
+            p = f"{prefix}{si}.{bi}.block."
+            j = 0
+            if e != 1:
+                s.append((p + f"{j}.0.weight", (cexp, ci, 1, 1), "conv"))
+                s += _bn(p + f"{j}.1", cexp)
+                j += 1
+            s.append((p + f"{j}.0.weight", (cexp, 1, k, k), "conv"))  # depthwise
+            s += _bn(p + f"{j}.1", cexp)
+            j += 1
+            sq = max(1, ci // 4)
+            s += [(p + f"{j}.fc1.weight", (sq, cexp, 1, 1), "conv"), (p + f"{j}.fc1.bias", (sq,), "bias"),
+                  (p + f"{j}.fc2.weight", (cexp, sq, 1, 1), "conv"), (p + f"{j}.fc2.bias", (cexp,), "bias")]
+            j += 1
+            s.append((p + f"{j}.0.weight", (cout, cexp, 1, 1), "conv"))
+            s += _bn(p + f"{j}.1", cout)
+    s.append((prefix + "8.0.weight", (B0_LAST_OUT, 320, 1, 1), "conv"))
+    s += _bn(prefix + "8.1", B0_LAST_OUT)
+    return s
+
+
+def _conv(p, cout, cin, k):
+    return [(p + ".weight", (cout, cin, k, k), "conv"), (p + ".bias", (cout,), "bias")]
+
+
+def _convT(p, cin, cout):
+    return [(p + ".weight", (cin, cout, 2, 2), "convT"), (p + ".bias", (cout,), "bias")]
+
+
+def _lin(p, cout, cin):
+    return [(p + ".weight", (cout, cin), "linear"), (p + ".bias", (cout,), "bias")]
+
+
+def context_spec(prefix, cin):
+    """scene_context.py:14-22 / depth_context.py:14-22 (cin=1280); auto_steer_context.py:15-23 (cin=1456)."""
+    return (_lin(prefix + "context_layer_0", 800, cin) + _lin(prefix + "context_layer_1", 800, 800)
+            + _lin(prefix + "context_layer_2", 200, 800)
+            + _conv(prefix + "context_layer_3", 128, 1, 3) + _conv(prefix + "context_layer_4", 256, 128, 3)
+            + _conv(prefix + "context_layer_5", 512, 256, 3) + _conv(prefix + "context_layer_6", cin, 512, 3))
+
+
+def neck_spec(prefix, cin):
+    """scene_neck.py:11-24 / scene_3d_neck.py:11-24 (cin=1280); ego_path_neck.py:11-24 (cin=1456)."""
+    return (_convT(prefix + "upsample_layer_0", cin, cin) + _conv(prefix + "skip_link_layer_0", cin, 80, 1)
+            + _conv(prefix + "decode_layer_0", 768, cin, 3) + _conv(prefix + "decode_layer_1", 768, 768, 3)
+            + _convT(prefix + "upsample_layer_1", 768, 768) + _conv(prefix + "skip_link_layer_1", 768, 40, 1)
+            + _conv(prefix + "decode_layer_2", 512, 768, 3) + _conv(prefix + "decode_layer_3", 512, 512, 3)
+            + _convT(prefix + "upsample_layer_2", 512, 512) + _conv(prefix + "skip_link_layer_2", 512, 24, 1)
+            + _conv(prefix + "decode_layer_4", 512, 512, 3) + _conv(prefix + "decode_layer_5", 256, 512, 3))
+
+
+def head_spec(kind, prefix):
+    """scene_seg_head.py:11-19, scene_3d_head.py:13-21, domain_seg_head.py:11-19, ego_lanes_head.py:11-13."""
+    if kind == "egolanes":
+        return (_conv(prefix + "decode_layer_6", 256, 256, 3) + _conv(prefix + "decode_layer_7", 128, 256, 3)
+                + _conv(prefix + "decode_layer_8", 3, 128, 3))
+    c9, cout = {"sceneseg": (64, 3), "scene3d": (128, 1), "domainseg": (64, 1)}[kind]
+    return (_convT(prefix + "upsample_layer_3", 256, 256) + _conv(prefix + "skip_link_layer_3", 256, 32, 1)
+            + _conv(prefix + "decode_layer_6", 256, 256, 3) + _conv(prefix + "decode_layer_7", 128, 256, 3)
+            + _convT(prefix + "upsample_layer_4", 128, 128)
+            + _conv(prefix + "decode_layer_8", 128, 128, 3) + _conv(prefix + "decode_layer_9", c9, 128, 3)
+            + _conv(prefix + "decode_layer_10", cout, c9, 3))
+
+
+def context_channels(kind):
+    return 1456 if kind == "egolanes" else 1280
+
+
+def model_spec(kind):
+    p = PREFIX[kind]
+    c = context_channels(kind)
+    return (backbone_spec(p["backbone"]) + context_spec(p["context"], c)
+            + neck_spec(p["neck"], c) + head_spec(kind, p["head"]))
+
+
+def _init(rng, shape, kind):
+    f32 = np.float32
+    if kind == "conv":
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (rng.standard_normal(shape, dtype=f32) * f32(np.sqrt(2.0 / fan_in))).astype(f32)
+    if kind == "linear":
+        return (rng.standard_normal(shape, dtype=f32) * f32(np.sqrt(2.0 / shape[1]))).astype(f32)
+    if kind == "convT":  # k2 s2: each output pixel sees exactly one tap -> fan_in = Cin
+        return (rng.standard_normal(shape, dtype=f32) * f32(np.sqrt(1.0 / shape[0]))).astype(f32)
+    if kind in ("bias", "bn_b", "bn_mean"):
+        return (rng.standard_normal(shape, dtype=f32) * f32(0.1)).astype(f32)
+    if kind in ("bn_w", "bn_var"):
+        return rng.uniform(0.5, 1.5, size=shape).astype(f32)
+    raise ValueError(kind)
+
+
+def make_state_dict(kind, seed, spec=None):
+    """Deterministic name->np.float32 array dict for ``kind`` (numpy PCG64, one stream, spec order)."""
+    rng = np.random.default_rng(seed)
+    return {k: _init(rng, shape, kd) for (k, shape, kd) in (spec or model_spec(kind))}
+
+
+def share_backbone(dst_sd, dst_kind, src_sd, src_kind, also_context_neck=False):
+    """Graft ``src``'s backbone (and optionally context+neck) tensors into ``dst`` under dst's key
+    prefixes -- what Scene3DNetwork(pretrained) / DomainSegNetwork(pretrained) do by object sharing
+    (pre_trained_backbone.py:10, domain_seg_upstream.py:10-20)."""
+    parts = ["backbone"] + (["context", "neck"] if also_context_neck else [])
+    for part in parts:
+        sp, dp = PREFIX[src_kind][part], PREFIX[dst_kind][part]
+        for k, v in src_sd.items():
+            if k.startswith(sp):
+                dst_sd[dp + k[len(sp):]] = v
+    return dst_sd
+
+
+def param_count(kind):
+    return sum(int(np.prod(s)) for (_, s, kd) in model_spec(kind) if kd not in ("bn_mean", "bn_var"))
+
+
+# ------------------------------------------------------------------------------------------------ AutoDrive
+AD_BN_EPS = 1e-3                      # common_layers.py:10
+AD_NET_H, AD_NET_W = 512, 1024        # autodrive_network.py:8-9
+# (stage, cin of the strided conv, cout of the strided conv, CTX out, CTX map h, w)   autodrive_backbone.py:13-40
+AD_STAGES = [("p2", 16, 32, 64, 128, 256), ("p3", 64, 64, 128, 64, 128), ("p4", 128, 128, 128, 32, 64), ("p5", 128, 256, 256, 16, 32)]
+
+
+def _ad_conv_bn(p, cout, cin, k, groups=1):
+    return [(p + ".conv.weight", (cout, cin // groups, k, k), "conv"), (p + ".norm.weight", (cout,), "bn_w"),
+            (p + ".norm.bias", (cout,), "bn_b"), (p + ".norm.running_mean", (cout,), "bn_mean"),
+            (p + ".norm.running_var", (cout,), "bn_var")]
+
+
+def _ad_ctx(p, cin, cout, h, w, r=2):
+    return [(p + ".exp0.weight", (h * w, cin, 3), "conv1d"), (p + ".exp0.bias", (h * w,), "bias"),
+            (p + ".ctx0.weight", (cin // r, 1, 3, 3), "conv"), (p + ".ctx0.bias", (cin // r,), "bias"),
+            (p + ".ctx1.weight", (cin, cin // r, 3, 3), "conv"), (p + ".ctx1.bias", (cin,), "bias"),
+            (p + ".ctx2.weight", (cout, cin, 3, 3), "conv"), (p + ".ctx2.bias", (cout,), "bias")]
+
+
+def autodrive_spec():
+    """(key, shape, init kind) in the reference ``state_dict`` order (num_batches_tracked omitted)."""
+    s = _ad_conv_bn("backbone.p1", 16, 3, 3)
+    for name, cin, cmid, cout, h, w in AD_STAGES:
+        s += _ad_conv_bn(f"backbone.{name}.0", cmid, cin, 3)
+        s += _ad_ctx(f"backbone.{name}.1", cmid, cout, h, w)
+    s += _ad_conv_bn("backbone.p5.2.cv1", 128, 256, 1) + _ad_conv_bn("backbone.p5.2.cv2", 256, 512, 1)   # SPPF
+    s += _ad_conv_bn("backbone.p5.3.cv1", 256, 256, 1) + _ad_conv_bn("backbone.p5.3.cv2", 256, 256, 1)   # C2PSA
+    a = "backbone.p5.3.middle_block"
+    s += _ad_conv_bn(a + ".conv1.qkv", 256, 128, 1) + _ad_conv_bn(a + ".conv1.conv1", 128, 128, 3, groups=128)
+    s += _ad_conv_bn(a + ".conv1.conv2", 128, 128, 1) + _ad_conv_bn(a + ".conv2.0", 256, 128, 1) + _ad_conv_bn(a + ".conv2.1", 128, 256, 1)
+    s += [("head.conv_1.weight", (256, 512, 3, 3), "conv"), ("head.conv_1.bias", (256,), "bias"),
+          ("head.conv_2.weight", (64, 256, 3, 3), "conv"), ("head.conv_2.bias", (64,), "bias"),
+          ("head.conv_3.weight", (2, 64, 3, 3), "conv"), ("head.conv_3.bias", (2,), "bias"),
+          ("head.fc1.0.weight", (768, 1024), "linear"), ("head.fc1.0.bias", (768,), "bias"),
+          ("head.fc2.0.weight", (512, 768), "linear"), ("head.fc2.0.bias", (512,), "bias"),
+          ("head.distance_head.0.weight", (1, 512), "linear"), ("head.distance_head.0.bias", (1,), "bias"),
+          ("head.curvature_head.0.weight", (1, 512), "linear"), ("head.curvature_head.0.bias", (1,), "bias"),
+          ("head.flag_head.weight", (1, 512), "linear"), ("head.flag_head.bias", (1,), "bias")]
+    return s
+
+
+def make_autodrive_state_dict(seed):
+    """Seeded init (scheme of make_state_dict above) tuned so every stage carries O(1) signal and no output saturates:
+    CTX gates multiplicatively (c4*x + x, with c4 driven by mean(x)), so Kaiming gains square the scale per stage
+    (measured: P5 std 2e4, all three outputs clipped -> vacuous parity).  exp0 and ctx2 weights get gain 0.5 and the
+    distance head's bias +1 (pre-ReLU value ~ +0.5): per-stage std 0.9 / 0.6 / 0.4 / 0.2, P5 std ~2, outputs
+    (d, curvature, flag) ~ (0.5, 0.5, -1.1) on the fixture frames."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k, shape, kind in autodrive_spec():
+        if kind == "conv1d":  # Conv1d on a length-1 sequence: only the centre tap ever multiplies data
+            out[k] = (rng.standard_normal(shape, dtype=np.float32) * np.float32(0.5 * np.sqrt(2.0 / shape[1]))).astype(np.float32)
+        else:
+            out[k] = _init(rng, shape, kind)
+        if k.endswith("ctx2.weight"):
+            out[k] = out[k] * np.float32(0.5)
+        if k == "head.distance_head.0.bias":
+            out[k] = out[k] + np.float32(1.0)
+    return out
+
+
+def autodrive_param_count():
+    return sum(int(np.prod(s)) for _, s, _ in autodrive_spec())
+
+
+# ------------------------------------------------------------------------------------------------ frames
+def synthetic_frame(h, w, seed, smooth=True):
+    """Seeded u8 HxWx3 frame.  ``smooth`` mixes low-frequency sinusoids with noise so argmax regions are
+    non-trivial."""
+    rng = np.random.default_rng(seed)
+    if not smooth:
+        return rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.empty((h, w, 3), dtype=np.float32)
+    for c in range(3):
+        fy, fx, ph = rng.uniform(1.0, 6.0), rng.uniform(1.0, 6.0), rng.uniform(0, 6.28)
+        img[..., c] = 127.5 + 90.0 * np.sin(2 * np.pi * (fy * yy / h + fx * xx / w) + ph)
+    img += rng.normal(0.0, 12.0, size=img.shape).astype(np.float32)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -121,16 +121,15 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
 
-    from autoware_vision_pilot_amd import lib, weights as vw
-    from oracle import pre_post, weights  # input generator + seeded state-dict (test infrastructure, not measured)
+    from autoware_vision_pilot_amd import lib, synthetic, weights as vw
 
     fw, fh = (int(v) for v in args.frame.split("x"))
     seed = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}[args.kind]
-    sd = weights.make_state_dict(args.kind, seed)
+    sd = synthetic.make_state_dict(args.kind, seed)
     blob = vw.pack_state_dict(sd)
     engines = [lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank) for _ in range(max(1, args.streams))]
     eng = engines[0]
-    frame = pre_post.synthetic_frame(fh, fw, 10 + rank)  # camera r
+    frame = synthetic.synthetic_frame(fh, fw, 10 + rank)  # camera r
     for e in engines:
         e.upload_frame(frame)  # resident in HBM before the timed region
         e.enqueue()            # first pass is eager (sets kernel attributes), second captures the graph

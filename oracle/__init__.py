@@ -4,6 +4,9 @@ TEST INFRASTRUCTURE ONLY.  Nothing in ``autoware_vision_pilot_amd`` (the product
 may import, call, link or execute anything in this package.  The only legal
 callers are ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
 of ``bench.py`` -- and there only as the checker, never as the thing measured.
+(The seeded weight / frame GENERATORS are pure data and live in the product package,
+``autoware_vision_pilot_amd/synthetic.py``; this package re-exports them so that checker and
+engine see identical tensors.  The dependency points from the oracle to the package, never back.)
 
 What it is: a torch-CPU fp32 *functional* restatement (``torch.nn.functional``
 calls over a flat ``state_dict``) of the reference networks

@@ -154,19 +154,7 @@ def resize_bilinear_f32(plane, out_h, out_w):
 
 
 # ------------------------------------------------------------------------------------ synthetic data
-def synthetic_frame(h, w, seed, smooth=True):
-    """Seeded u8 HxWx3 frame.  ``smooth`` mixes low-frequency sinusoids with noise so argmax regions are
-    non-trivial."""
-    rng = np.random.default_rng(seed)
-    if not smooth:
-        return rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
-    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    img = np.empty((h, w, 3), dtype=np.float32)
-    for c in range(3):
-        fy, fx, ph = rng.uniform(1.0, 6.0), rng.uniform(1.0, 6.0), rng.uniform(0, 6.28)
-        img[..., c] = 127.5 + 90.0 * np.sin(2 * np.pi * (fy * yy / h + fx * xx / w) + ph)
-    img += rng.normal(0.0, 12.0, size=img.shape).astype(np.float32)
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+from autoware_vision_pilot_amd.synthetic import synthetic_frame  # noqa: E402,F401  (shared data generation)
 
 
 # ------------------------------------------------------------------------------------------ visualisation (SURVEY 8f N4)

@@ -6,8 +6,7 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
-from autoware_vision_pilot_amd import lib, weights as vw
-from oracle import autodrive, pre_post
+from autoware_vision_pilot_amd import lib, synthetic, weights as vw
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="fp16")
@@ -16,8 +15,8 @@ ap.add_argument("--warmup", type=int, default=50)
 ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--no-fp8", action="store_true")
 a = ap.parse_args()
-blob = vw.pack_state_dict(autodrive.make_state_dict(5))
-frame = pre_post.synthetic_frame(1080, 1920, 21)
+blob = vw.pack_state_dict(synthetic.make_autodrive_state_dict(5))
+frame = synthetic.synthetic_frame(1080, 1920, 21)
 engs = [lib.Engine("autodrive", blob, precision=a.precision, weights_fp8=not a.no_fp8) for _ in range(a.streams)]
 for e in engs:
     e.upload_frame(frame)

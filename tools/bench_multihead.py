@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 from autoware_vision_pilot_amd import lib, weights as vw
-from oracle import pre_post, weights
+from autoware_vision_pilot_amd import synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="fp16")
@@ -19,11 +19,11 @@ ap.add_argument("--streams", type=int, default=3)
 ap.add_argument("--no-share", action="store_true")
 a = ap.parse_args()
 
-sd_seg = weights.make_state_dict("sceneseg", 0)
-sd_3d = weights.share_backbone(weights.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")
-sd_ego = weights.share_backbone(weights.make_state_dict("egolanes", 2), "egolanes", sd_seg, "sceneseg")
+sd_seg = synthetic.make_state_dict("sceneseg", 0)
+sd_3d = synthetic.share_backbone(synthetic.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")
+sd_ego = synthetic.share_backbone(synthetic.make_state_dict("egolanes", 2), "egolanes", sd_seg, "sceneseg")
 blobs = {"sceneseg": vw.pack_state_dict(sd_seg), "scene3d": vw.pack_state_dict(sd_3d), "egolanes": vw.pack_state_dict(sd_ego)}
-frame = pre_post.synthetic_frame(720, 1280, 1)
+frame = synthetic.synthetic_frame(720, 1280, 1)
 groups = []
 for _ in range(a.streams):
     base = lib.Engine("sceneseg", blobs["sceneseg"], precision=a.precision)

@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 from autoware_vision_pilot_amd import lib, weights as vw
-from oracle import pre_post, weights
+from autoware_vision_pilot_amd import synthetic
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "sceneseg"
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp16"
 seed = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}[kind]
-eng = lib.Engine(kind, vw.pack_state_dict(weights.make_state_dict(kind, seed)), precision=prec)
-eng.upload_frame(pre_post.synthetic_frame(720, 1280, 1))
+eng = lib.Engine(kind, vw.pack_state_dict(synthetic.make_state_dict(kind, seed)), precision=prec)
+eng.upload_frame(synthetic.synthetic_frame(720, 1280, 1))
 ms = eng.profile_layers(20)
 print(f"# {kind} {prec}: eager sum {ms.sum()*1e3:.1f} us over {len(ms)} launches")
 fam = {}
@@ -21,7 +21,7 @@ for (n, fl, by), k, t in zip(eng.layers(), eng.layer_kernels(), ms):
 print("# per kernel family: name, launches, total us, TFLOP/s")
 for k, (t, fl, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
     print(f"# {k}\t{n}\t{t*1e3:.1f}\t{fl/(t*1e-3)/1e12:.1f}")
-eng.upload_frame(pre_post.synthetic_frame(720, 1280, 1))
+eng.upload_frame(synthetic.synthetic_frame(720, 1280, 1))
 for _ in range(10): eng.enqueue()
 eng.sync(); eng.timer_begin()
 for _ in range(50): eng.enqueue()

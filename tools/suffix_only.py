@@ -2,11 +2,11 @@ import os, sys, time, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from autoware_vision_pilot_amd import lib, weights as vw
-from oracle import pre_post, weights
-sd_seg = weights.make_state_dict("sceneseg", 0)
-sd_3d = weights.share_backbone(weights.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")
+from autoware_vision_pilot_amd import synthetic
+sd_seg = synthetic.make_state_dict("sceneseg", 0)
+sd_3d = synthetic.share_backbone(synthetic.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")
 b_seg, b_3d = vw.pack_state_dict(sd_seg), vw.pack_state_dict(sd_3d)
-frame = pre_post.synthetic_frame(720, 1280, 1)
+frame = synthetic.synthetic_frame(720, 1280, 1)
 groups = []
 for _ in range(3):
     base = lib.Engine("sceneseg", b_seg, precision="fp16")
