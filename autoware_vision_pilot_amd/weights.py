@@ -262,3 +262,23 @@ def export_onnx(onnx_path, out_path):
     with open(out_path, "wb") as f:
         f.write(pack_state_dict(sd))
     return out_path
+
+
+def main(argv=None):
+    """python -m autoware_vision_pilot_amd.weights <in.pth|in.pt|in.onnx> <out.vpw>"""
+    import argparse
+
+    ap = argparse.ArgumentParser(prog="python -m autoware_vision_pilot_amd.weights",
+                                 description="Convert a reference checkpoint (.pth / .pt state_dict) or an ONNX file made by the "
+                                             "reference's exporter to the engine's VPW1 weight blob.")
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    a = ap.parse_args(argv)
+    out = export_onnx(a.src, a.dst) if a.src.lower().endswith(".onnx") else export_checkpoint(a.src, a.dst)
+    n = len(unpack_blob(open(out, "rb").read()))
+    print(f"{out}: {n} tensors")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

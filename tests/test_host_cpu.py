@@ -248,3 +248,20 @@ def test_native_onnx_reader_matches_python_reader(tmp_path):
         lib.convert_onnx(str(tmp_path / "t.onnx"), str(tmp_path / "t.vpw"))
     with pytest.raises(lib.VpError, match="cannot open"):
         lib.convert_onnx(str(tmp_path / "missing.onnx"), str(tmp_path / "x.vpw"))
+
+
+def test_weights_cli_converts_pth_and_onnx(tmp_path):
+    """`python -m autoware_vision_pilot_amd.weights src dst`: .pth state_dict (AutoDrive-style {"model": sd} wrapper too)
+    and exporter-made .onnx both end in the same VPW1 container."""
+    from autoware_vision_pilot_amd import weights as vw
+
+    sd = {"a.weight": torch.randn(4, 3, 3, 3), "a.bias": torch.randn(4), "bn.num_batches_tracked": torch.tensor(3)}
+    torch.save({"model": sd}, tmp_path / "m.pth")
+    assert vw.main([str(tmp_path / "m.pth"), str(tmp_path / "m.vpw")]) == 0
+    got = vw.unpack_blob((tmp_path / "m.vpw").read_bytes())
+    assert set(got) == {"a.weight", "a.bias"} and np.array_equal(got["a.weight"], sd["a.weight"].numpy())
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    r = subprocess.run([sys.executable, "-m", "autoware_vision_pilot_amd.weights", os.path.join(here, "tiny_export.onnx"), str(tmp_path / "t.vpw")],
+                       capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr
+    assert set(vw.unpack_blob((tmp_path / "t.vpw").read_bytes())) == set(vw.load_onnx_state_dict(os.path.join(here, "tiny_export.onnx")))
