@@ -1549,9 +1549,7 @@ void Engine::visualize_mask(int viz_type, uint8_t* dst) {
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
-void Engine::depth_resized(float* dst, int h, int w) {
-  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
-  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
+void Engine::resize_depth_on_device(int h, int w) {
   const size_t need = (size_t)4 * h * w, tabn = (size_t)4 * (h + w);
   if (need > resize_cap_) {
     d_resize_out_ = dalloc(need, false);
@@ -1561,8 +1559,11 @@ void Engine::depth_resized(float* dst, int h, int w) {
     d_rs_tab_ = static_cast<int*>(dalloc(tabn * sizeof(int), false));
     rs_tab_cap_ = tabn;
   }
-  std::vector<int> idx(2 * (h + w));
-  std::vector<float> wgt(2 * (h + w));
+  // host tap tables are members: they must outlive the asynchronous copies (every caller syncs the stream before returning)
+  std::vector<int>& idx = rs_idx_host_;
+  std::vector<float>& wgt = rs_wgt_host_;
+  idx.assign(2 * (h + w), 0);
+  wgt.assign(2 * (h + w), 0.f);
   linear_taps_f32(out_h_, h, idx.data(), wgt.data());
   linear_taps_f32(out_w_, w, idx.data() + 2 * h, wgt.data() + 2 * h);
   int* d_idx = d_rs_tab_;
@@ -1571,7 +1572,40 @@ void Engine::depth_resized(float* dst, int h, int w) {
   VP_HIP_CHECK(hipMemcpyAsync(d_wgt, wgt.data(), wgt.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
   VP_HIP_CHECK(launch_resize_bilinear_f32(d_logits_, out_w_, d_idx, d_wgt, d_idx + 2 * h, d_wgt + 2 * h, h, w,
                                           static_cast<float*>(d_resize_out_), stream_));
-  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, need, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::depth_resized(float* dst, int h, int w) {
+  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
+  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
+  resize_depth_on_device(h, w);
+  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, (size_t)4 * h * w, hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// DepthVisualizationEngine::visualize (depth_visualization_engine.cpp:9-26) on the device: plane 0 of the logits,
+// bilinear-resized to h x w (what the depth topic carries, run_model_node.cpp:100-104), min-max normalised to u8 and
+// mapped through COLORMAP_VIRIDIS; BGR8 out.
+void Engine::visualize_depth(uint8_t* dst, int h, int w) {
+  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
+  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad visualisation target");
+  static const uint8_t kViridisBgr[256 * 3] = {
+#include "viridis_lut.inc"
+  };
+  if (!d_viridis_) {
+    d_viridis_ = dupload(std::vector<uint8_t>(kViridisBgr, kViridisBgr + sizeof(kViridisBgr)));
+    d_minmax_ = static_cast<unsigned*>(dalloc(2 * sizeof(unsigned), false));
+  }
+  const size_t n = (size_t)h * w;
+  if (3 * n > depth_viz_cap_) {
+    d_depth_viz_ = dalloc(3 * n, false);
+    depth_viz_cap_ = 3 * n;
+  }
+  resize_depth_on_device(h, w);
+  static const unsigned kInit[2] = {0xFFFFFFFFu, 0u};
+  VP_HIP_CHECK(hipMemcpyAsync(d_minmax_, kInit, sizeof(kInit), hipMemcpyHostToDevice, stream_));
+  VP_HIP_CHECK(launch_minmax_f32(static_cast<const float*>(d_resize_out_), n, d_minmax_, stream_));
+  VP_HIP_CHECK(launch_depth_colorize(static_cast<const float*>(d_resize_out_), n, d_minmax_, d_viridis_, static_cast<uint8_t*>(d_depth_viz_), stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(dst, d_depth_viz_, 3 * n, hipMemcpyDeviceToHost, stream_));
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 

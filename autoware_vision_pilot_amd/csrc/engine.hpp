@@ -97,6 +97,7 @@ class Engine {
   void mask_resized(uint8_t* dst, int h, int w);
   void depth_resized(float* dst, int h, int w);
   void visualize_mask(int viz_type, uint8_t* dst_bgr);
+  void visualize_depth(uint8_t* dst_bgr, int h, int w);
   void read_input_tensor(float* dst);
 
   const float* host_logits() const { return h_logits_; }
@@ -200,6 +201,13 @@ class Engine {
   size_t resize_cap_ = 0;
   int* d_rs_tab_ = nullptr;
   uint8_t* d_viz_lut_ = nullptr;  // [3 viz types][256][3]
+  uint8_t* d_viridis_ = nullptr;  // [256][3] BGR (viridis_lut.inc)
+  unsigned* d_minmax_ = nullptr;  // order keys of the depth plane's min / max
+  void* d_depth_viz_ = nullptr;
+  size_t depth_viz_cap_ = 0;
+  void resize_depth_on_device(int h, int w);  // fp32 h x w plane -> d_resize_out_
+  std::vector<int> rs_idx_host_;
+  std::vector<float> rs_wgt_host_;
   size_t rs_tab_cap_ = 0;
 
   // graph

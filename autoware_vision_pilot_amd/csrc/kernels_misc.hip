@@ -151,6 +151,63 @@ __global__ __launch_bounds__(256) void resize_bilinear_f32_kernel(const float* s
   dst[(size_t)y * ow + x] = q0 + q1;
 }
 
+// ------------------------------------------------------------------------------ depth visualisation
+// DepthVisualizationEngine::visualize (depth_visualization_engine.cpp:9-26): minMaxLoc -> convertTo(CV_8U, 255/(max-min),
+// -min*255/(max-min)) -> applyColorMap(VIRIDIS).  Two launches over the frame-size fp32 depth plane.
+// Order-preserving float -> unsigned key, so that min / max are integer atomics (exact, order-independent).
+__device__ inline unsigned f32_order_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ inline float f32_from_order_key(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__global__ __launch_bounds__(256) void minmax_f32_kernel(const float* src, size_t n, unsigned* mm) {  // mm[0] = min key, mm[1] = max key
+  __shared__ unsigned smin[4], smax[4];
+  unsigned lo = 0xFFFFFFFFu, hi = 0u;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned k = f32_order_key(src[i]);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = lo;
+    smax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 1; q < 4; ++q) {
+      lo = smin[q] < lo ? smin[q] : lo;
+      hi = smax[q] > hi ? smax[q] : hi;
+    }
+    atomicMin(mm, lo);
+    atomicMax(mm + 1, hi);
+  }
+}
+
+// u8 = saturate(cvRound(x * alpha + beta)) with alpha, beta formed in double and applied in float, as cv::Mat::convertTo does
+// (fused multiply-add, the AVX2 / NEON build's v_fma; cvRound = round-half-even), then the 256 x BGR table.
+__global__ __launch_bounds__(256) void depth_colorize_kernel(const float* src, size_t n, const unsigned* mm, const uint8_t* lut, uint8_t* dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float mn = f32_from_order_key(mm[0]), mx = f32_from_order_key(mm[1]);
+  int v = 0;
+  if (mx > mn) {
+    const double range = (double)mx - (double)mn;
+    const float a = (float)(255.0 / range), b = (float)(-(double)mn * 255.0 / range);
+    const int r = __float2int_rn(__builtin_fmaf(src[i], a, b));
+    v = r < 0 ? 0 : (r > 255 ? 255 : r);
+  }
+  dst[3 * i] = lut[3 * v];
+  dst[3 * i + 1] = lut[3 * v + 1];
+  dst[3 * i + 2] = lut[3 * v + 2];
+}
+
 // ----------------------------------------------------------------------------------- layout conversions
 // fp32 NCHW (host-visible test/debug format) <-> NHWC activation.
 __global__ __launch_bounds__(256) void nchw_to_act_kernel(const float* src, int Creal, ActView a) {
@@ -194,6 +251,13 @@ hipError_t launch_resize_nearest(const uint8_t* src, int sw, const int* ytab, co
 hipError_t launch_viz_blend(const uint8_t* mask, int mw, const int* ytab, const int* xtab, const uint8_t* frame, int stride, int oh, int ow,
                             const uint8_t* lut, int frame_is_rgb, uint8_t* dst, hipStream_t st) {
   VP_LAUNCH(viz_blend_kernel, dim3(nblk(ow), oh), dim3(256), 0, st, mask, mw, ytab, xtab, frame, stride, oh, ow, lut, frame_is_rgb, dst);
+}
+hipError_t launch_minmax_f32(const float* src, size_t n, unsigned* mm, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  VP_LAUNCH(minmax_f32_kernel, dim3(blocks < 1024u ? (blocks ? blocks : 1u) : 1024u), dim3(256), 0, st, src, n, mm);
+}
+hipError_t launch_depth_colorize(const float* src, size_t n, const unsigned* mm, const uint8_t* lut, uint8_t* dst, hipStream_t st) {
+  VP_LAUNCH(depth_colorize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, n, mm, lut, dst);
 }
 hipError_t launch_resize_bilinear_f32(const float* src, int sw, const int* yi, const float* yf, const int* xi, const float* xf,
                                       int oh, int ow, float* dst, hipStream_t st) {

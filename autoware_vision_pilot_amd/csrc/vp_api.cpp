@@ -244,6 +244,9 @@ int vp_mask_resized_u8(vp_engine* e, uint8_t* dst, int h, int w) {
 int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w) {
   return guarded(e, [&](vp::Engine& g) { g.depth_resized(dst, h, w); });
 }
+int vp_visualize_depth_bgr8(vp_engine* e, uint8_t* dst, int h, int w) {
+  return guarded(e, [&](vp::Engine& g) { g.visualize_depth(dst, h, w); });
+}
 int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst) {
   return guarded(e, [&](vp::Engine& g) { g.visualize_mask(viz_type, dst); });
 }

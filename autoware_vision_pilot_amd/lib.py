@@ -46,6 +46,7 @@ _SIGS = {
     "vp_mask_resized_u8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_depth_resized_f32": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_visualize_mask_bgr8": (C.c_int, [_P, C.c_int, _P]),
+    "vp_visualize_depth_bgr8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_input_tensor": (C.c_int, [_P, _P]),
     "vp_upload_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "vp_enqueue": (C.c_int, [_P]),
@@ -218,6 +219,12 @@ class Engine:
     def depth_resized(self, h, w):
         out = np.empty((h, w), dtype=np.float32)
         self._ck(self._lib.vp_depth_resized_f32(self._h, _ptr(out), h, w))
+        return out
+
+    def visualize_depth(self, h, w):
+        """Colourised depth (depth_visualization_engine.cpp): plane 0 of the logits at h x w, min-max -> u8 -> VIRIDIS; BGR8."""
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        self._ck(self._lib.vp_visualize_depth_bgr8(self._h, _ptr(out), h, w))
         return out
 
     def visualize_mask(self, viz_type, frame_hw):

@@ -123,6 +123,12 @@ int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w);              /
  * nearest resize to the frame of the last vp_infer, 50/50 blend with that frame.  dst: BGR8 [frame_h][frame_w][3], packed. */
 enum vp_viz_type { VP_VIZ_SCENE = 0, VP_VIZ_DOMAIN = 1, VP_VIZ_EGOLANES = 2 };
 int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst_bgr8);
+/* DepthVisualizationEngine::visualize (middleware_recipes/common/visualizers/depth_visualization_engine.cpp:9-26): plane 0 of
+ * the logits bilinear-resized to h x w (the map vp_depth_resized_f32 returns, run_model_node.cpp:100-104), min-max
+ * normalised to u8 (convertTo with alpha = 255/(max-min), beta = -min*alpha; all zero if max == min) and mapped through
+ * COLORMAP_VIRIDIS.  dst: BGR8 [h][w][3], packed.  Table and convertTo rounding restated from published sources, not
+ * pinned against OpenCV (absent here) -- see DESIGN.md. */
+int vp_visualize_depth_bgr8(vp_engine* e, uint8_t* dst_bgr8, int h, int w);
 int vp_input_tensor(vp_engine* e, float* dst_1x3x320x640);                     /* the post-resize network input */
 
 /* ---- asynchronous / device-resident path (bench, multi-GPU) ---------------------------------------------- */

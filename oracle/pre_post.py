@@ -182,3 +182,28 @@ def visualize_mask(mask_u8, frame_bgr, viz_type):
     half = s >> 1
     return np.where(s & 1, half + (half & 1), half).astype(np.uint8)
 
+
+def viridis_lut_bgr():
+    """cv::COLORMAP_VIRIDIS as 256 x BGR u8: OpenCV's colormap.cpp embeds matplotlib's published viridis data and converts it
+    with convertTo(CV_8U, 255); restated from matplotlib's own copy (PARITY UNPINNED against OpenCV, absent here).  The engine
+    carries the same table as csrc/viridis_lut.inc (tools/gen_viridis_lut.py); tests compare the two."""
+    from matplotlib import _cm_listed
+
+    rgb = np.asarray(_cm_listed._viridis_data, dtype=np.float32)
+    return np.rint(rgb * np.float32(255.0)).astype(np.uint8)[:, ::-1].copy()
+
+
+def visualize_depth(depth_f32):
+    """depth_visualization_engine.cpp:9-26: minMaxLoc -> convertTo(CV_8UC1, 255/(max-min), -min*255/(max-min)) ->
+    applyColorMap(VIRIDIS).  convertTo: alpha / beta formed in double, applied in float as a fused multiply-add, cvRound
+    (half-to-even), saturate.  The fma is evaluated here in float64 (product of two float32 is exact there)."""
+    d = np.ascontiguousarray(depth_f32, dtype=np.float32)
+    mn, mx = float(d.min()), float(d.max())
+    if mx > mn:
+        a = np.float32(255.0 / (mx - mn))
+        b = np.float32(-mn * 255.0 / (mx - mn))
+        t = (d.astype(np.float64) * np.float64(a) + np.float64(b)).astype(np.float32)
+        u = np.clip(np.rint(t), 0, 255).astype(np.uint8)
+    else:
+        u = np.zeros(d.shape, dtype=np.uint8)
+    return viridis_lut_bgr()[u]

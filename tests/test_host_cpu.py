@@ -265,3 +265,20 @@ def test_weights_cli_converts_pth_and_onnx(tmp_path):
                        capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr
     assert set(vw.unpack_blob((tmp_path / "t.vpw").read_bytes())) == set(vw.load_onnx_state_dict(os.path.join(here, "tiny_export.onnx")))
+
+
+def test_viridis_table_in_engine_matches_published_data():
+    """csrc/viridis_lut.inc (compiled into the engine) against matplotlib's published viridis data, the
+    source OpenCV's COLORMAP_VIRIDIS embeds; and the oracle's depth visualisation on a hand-checked ramp."""
+    pytest.importorskip("matplotlib")
+    from oracle import pre_post
+
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "autoware_vision_pilot_amd", "csrc", "viridis_lut.inc")
+    vals = [int(v) for line in open(inc) if not line.startswith("//") for v in line.replace(",", " ").split()]
+    table = np.array(vals, dtype=np.uint8).reshape(256, 3)
+    assert np.array_equal(table, pre_post.viridis_lut_bgr())
+    assert tuple(table[0]) == (84, 1, 68) and tuple(table[255]) == (37, 231, 253)
+    ramp = np.linspace(-2.0, 3.0, 256, dtype=np.float32).reshape(16, 16)
+    out = pre_post.visualize_depth(ramp)
+    assert out.shape == (16, 16, 3) and np.array_equal(out.reshape(256, 3), table)      # 256 evenly spaced values -> every entry once
+    assert np.array_equal(pre_post.visualize_depth(np.full((4, 5), 7.5, np.float32)), np.broadcast_to(table[0], (4, 5, 3)))
