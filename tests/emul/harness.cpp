@@ -1,0 +1,80 @@
+// TEST INFRASTRUCTURE (see shim/hip/hip_runtime.h): the real kernel sources compiled for the host + plain-C entry points
+// for the CPU tests (tests/test_kernels_emulated.py).  The included files are csrc/*.hip with `extern __shared__`
+// rewritten to `extern` by build.py; nothing else is changed.
+#include "kernels_misc.cpp"
+#include "kernels_backbone.cpp"
+#include "kernels_autodrive.cpp"
+
+namespace vp {  // dynamic-LDS arrays of the kernels above (one workgroup runs at a time)
+alignas(16) unsigned char dw_smem[1 << 17];
+alignas(16) float mean[1 << 15];
+alignas(16) float xs[1 << 15];
+alignas(16) float sh[1 << 15];
+}  // namespace vp
+
+using namespace vp;
+
+static ActView view(void* hi, void* lo, int H, int W, int C) { return ActView{static_cast<half_t*>(hi), static_cast<half_t*>(lo), H, W, C}; }
+
+extern "C" {
+
+int emu_preprocess(const uint8_t* frame, int stride, const int* xtab, const int* ytab, int out_h, int out_w, const int* src_c,
+                   const float* mean3, const float* std3, float* out) {
+  PreprocessParams p{};
+  p.frame = frame; p.stride = stride; p.xtab = xtab; p.ytab = ytab; p.out_h = out_h; p.out_w = out_w; p.out = out;
+  for (int c = 0; c < 3; ++c) { p.src_c[c] = src_c[c]; p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
+  return launch_preprocess(p, nullptr);
+}
+int emu_decode_mask(const float* logits, int C, int HW, int mode, uint8_t* out) { return launch_decode_mask(logits, C, HW, mode, out, nullptr); }
+int emu_resize_nearest(const uint8_t* src, int sw, const int* ytab, const int* xtab, int oh, int ow, uint8_t* dst) {
+  return launch_resize_nearest(src, sw, ytab, xtab, oh, ow, dst, nullptr);
+}
+int emu_resize_bilinear_f32(const float* src, int sw, const int* yi, const float* yf, const int* xi, const float* xf, int oh, int ow, float* dst) {
+  return launch_resize_bilinear_f32(src, sw, yi, yf, xi, xf, oh, ow, dst, nullptr);
+}
+int emu_viz_blend(const uint8_t* mask, int mw, const int* ytab, const int* xtab, const uint8_t* frame, int stride, int oh, int ow,
+                  const uint8_t* lut, int frame_is_rgb, uint8_t* dst) {
+  return launch_viz_blend(mask, mw, ytab, xtab, frame, stride, oh, ow, lut, frame_is_rgb, dst, nullptr);
+}
+int emu_depth_viz(const float* src, size_t n, const uint8_t* lut, uint8_t* dst) {
+  unsigned mm[2] = {0xFFFFFFFFu, 0u};
+  if (launch_minmax_f32(src, n, mm, nullptr)) return 1;
+  return launch_depth_colorize(src, n, mm, lut, dst, nullptr);
+}
+int emu_stem(const float* in, int H, int W, const float* w, const float* b, void* out_hi, void* out_lo) {
+  StemParams p{in, H, W, w, b, view(out_hi, out_lo, H / 2, W / 2, 32)};
+  return launch_stem(p, nullptr);
+}
+int emu_dwconv(void* in_hi, void* in_lo, int H, int W, int C, void* out_hi, void* out_lo, int OH, int OW, const float* w, const float* b, int k,
+               int stride, unsigned long long* sums, int replicas) {
+  DwParams p{view(in_hi, in_lo, H, W, C), view(out_hi, out_lo, OH, OW, C), w, b, k, stride, sums, replicas};
+  return launch_dwconv(p, nullptr);
+}
+int emu_se_fc1(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1, float* s1) {
+  SeParams p{};
+  p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.s1 = s1;
+  return launch_se_fc1(p, nullptr);
+}
+int emu_se_scale_weights(const float* w, void* out_hi, void* out_lo, int rows, int C, const float* s1, const float* w2, const float* b2, int sq,
+                         int Creal) {
+  ScaleWParams p{};
+  p.w = w; p.out_hi = static_cast<half_t*>(out_hi); p.out_lo = static_cast<half_t*>(out_lo); p.rows = rows; p.C = C; p.s1 = s1; p.w2 = w2; p.b2 = b2;
+  p.sq = sq; p.Creal = Creal;
+  return launch_se_scale_weights(p, nullptr);
+}
+int emu_fc(const float* x, const float* w, const float* b, float* out, int N, int K, int act) {
+  FcParams p{};
+  p.x = x; p.w = w; p.b = b; p.out = out; p.N = N; p.K = K; p.act = act; p.Kstride = K;
+  return launch_fc(p, nullptr);
+}
+int emu_maxpool5(void* src_hi, int H, int W, int C, int src_off, void* dst_hi, int dstC, int dst_off, int nch) {
+  return launch_maxpool5(view(src_hi, nullptr, H, W, C), src_off, view(dst_hi, nullptr, H, W, dstC), dst_off, nch, nullptr);
+}
+int emu_attention(void* qkv_hi, void* qkv_lo, int H, int W, int heads, int dk, int dv, float scale, void* out_hi, void* out_lo, void* v_hi, void* v_lo) {
+  AttnParams p{view(qkv_hi, qkv_lo, H, W, heads * (2 * dk + dv)), view(out_hi, out_lo, H, W, heads * dv), view(v_hi, v_lo, H, W, heads * dv), heads, dk, dv, scale};
+  return launch_attention(p, nullptr);
+}
+int emu_nchw_to_act(const float* src, int Creal, void* hi, void* lo, int H, int W, int C) { return launch_nchw_to_act(src, Creal, view(hi, lo, H, W, C), nullptr); }
+int emu_act_to_nchw(void* hi, void* lo, int H, int W, int C, int Creal, float* dst) { return launch_act_to_nchw(view(hi, lo, H, W, C), Creal, dst, nullptr); }
+
+}  // extern "C"
