@@ -3,7 +3,7 @@ the CPU through tests/emul (a HIP-on-CPU shim: one host thread per work-item, re
 checked against the oracle.  Runs in the CPU suite, so an indexing or arithmetic regression in these kernels shows up
 without a GPU; the MFMA convolution kernels stay GPU-only (tests/test_gpu_*.py).  Integer / byte work: bit-exact; float
 work: the tolerance the GPU parity tests use (the host compiler does not contract a*b+c, the device does)."""
-import ctypes as C
+import ctypes as ct
 import os
 import sys
 
@@ -23,11 +23,11 @@ def emu():
 
     if not os.path.exists(emul_build.CLANG):
         pytest.skip("host clang++ of the ROCm toolchain not found")
-    return C.CDLL(emul_build.build())
+    return ct.CDLL(emul_build.build())
 
 
 def ptr(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    return a.ctypes.data_as(ct.c_void_p) if a is not None else None
 
 
 def taps_u8(src, dst):
@@ -117,10 +117,156 @@ def test_visualisation_kernels_bit_exact(emu):
     depth = (rng.standard_normal((37, 53)) * 3 - 1).astype(np.float32)
     lut = pre_post.viridis_lut_bgr()
     outd = np.empty((37, 53, 3), dtype=np.uint8)
-    emu.emu_depth_viz.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    emu.emu_depth_viz.argtypes = [ct.c_void_p, ct.c_size_t, ct.c_void_p, ct.c_void_p]
     assert emu.emu_depth_viz(ptr(depth), depth.size, ptr(lut), ptr(outd)) == 0
     assert np.array_equal(outd, pre_post.visualize_depth(depth))
     flat = np.full((8, 8), -2.5, dtype=np.float32)           # max == min -> all zeros -> LUT[0]
     outf = np.empty((8, 8, 3), dtype=np.uint8)
     assert emu.emu_depth_viz(ptr(flat), flat.size, ptr(lut), ptr(outf)) == 0
     assert np.array_equal(outf, np.broadcast_to(lut[0], (8, 8, 3)))
+
+
+# ------------------------------------------------------------------------------------------------ encoder pieces
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_stem_kernel(emu, split):
+    """conv 3x3 / s2, 3 -> 32, BN folded, SiLU (EfficientNet features[0]); fp16x3 pair or single fp16 plane out."""
+    rng = np.random.default_rng(3)
+    H, W = 18, 28
+    x = rng.standard_normal((3, H, W)).astype(np.float32)
+    wt = (rng.standard_normal((32, 3, 3, 3)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(32) * 0.1).astype(np.float32)
+    want = F.silu(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(wt), torch.from_numpy(b), stride=2, padding=1))[0].numpy()
+    w27 = np.ascontiguousarray(wt.reshape(32, 27).T)          # [k = (ci*3+ky)*3+kx][co]
+    hi = np.zeros((H // 2, W // 2, 32), dtype=np.float16)
+    lo = np.zeros_like(hi) if split else None
+    assert emu.emu_stem(ptr(x), H, W, ptr(w27), ptr(b), ptr(hi), ptr(lo)) == 0
+    got = hi.astype(np.float32) + (lo.astype(np.float32) if split else 0)
+    assert _rel(got.transpose(2, 0, 1), want) <= (2e-6 if split else 2e-3)
+
+
+@pytest.mark.parametrize("C,k,stride,H,W", [(48, 3, 1, 12, 20), (144, 5, 2, 13, 21), (32, 3, 2, 16, 16), (56, 5, 1, 9, 11)])
+def test_depthwise_pool_kernel(emu, C, k, stride, H, W):
+    """Depthwise conv + SiLU with the fused squeeze-excite pool: ragged channel-octet groups (6, 18, 4, 7 octets), strides,
+    map edges; the int64 fixed-point channel sums against the sum of the kernel's own outputs."""
+    rng = np.random.default_rng(C + k)
+    x = rng.standard_normal((C, H, W)).astype(np.float32)
+    wt = (rng.standard_normal((C, 1, k, k)) * 0.4).astype(np.float32)
+    b = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    xh, xl = split16(nhwc(x, C))
+    xin = torch.from_numpy((xh.astype(np.float32) + xl.astype(np.float32)).transpose(2, 0, 1))[None]
+    want = F.silu(F.conv2d(xin, torch.from_numpy(wt), torch.from_numpy(b), stride=stride, padding=k // 2, groups=C))[0].numpy()
+    OH, OW = want.shape[1:]
+    wk = np.ascontiguousarray(wt.reshape(C, k * k).T)           # [tap][C]
+    oh, ol = np.zeros((OH, OW, C), np.float16), np.zeros((OH, OW, C), np.float16)
+    replicas = 8
+    sums = np.zeros((replicas, C), dtype=np.uint64)
+    assert emu.emu_dwconv(ptr(xh), ptr(xl), H, W, C, ptr(oh), ptr(ol), OH, OW, ptr(wk), ptr(b), k, stride, ptr(sums), replicas) == 0
+    got = (oh.astype(np.float32) + ol.astype(np.float32)).transpose(2, 0, 1)
+    assert _rel(got, want) <= 2e-6
+    pooled = sums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
+    assert np.abs(pooled - got.astype(np.float64).sum(axis=(1, 2))).max() <= 1e-4
+    # fp16 engine: single plane, SiLU variant rounded to fp16
+    o16 = np.zeros((OH, OW, C), np.float16)
+    sums2 = np.zeros((replicas, C), dtype=np.uint64)
+    assert emu.emu_dwconv(ptr(xh), None, H, W, C, ptr(o16), None, OH, OW, ptr(wk), ptr(b), k, stride, ptr(sums2), replicas) == 0
+    want16 = F.silu(F.conv2d(torch.from_numpy(xh.astype(np.float32).transpose(2, 0, 1))[None], torch.from_numpy(wt), torch.from_numpy(b), stride=stride,
+                             padding=k // 2, groups=C))[0].numpy()
+    assert _rel(o16.astype(np.float32).transpose(2, 0, 1), want16) <= 2e-3
+
+
+def test_squeeze_excite_kernels(emu):
+    """se_fc1 (means from the replica rows -> squeeze FC -> SiLU) and se_scale_weights (excite FC -> sigmoid gate folded into
+    the projection weights' K axis, pad channels gated to 0)."""
+    rng = np.random.default_rng(7)
+    C, Creal, sq, rows, hw, replicas = 160, 144, 6, 64, 35, 16
+    act = np.zeros((hw, C), dtype=np.float32)
+    act[:, :Creal] = rng.standard_normal((hw, Creal)).astype(np.float32)
+    fixed = np.rint(act.astype(np.float64) * 2.0 ** 24).astype(np.int64)
+    sums = np.zeros((replicas, C), dtype=np.int64)
+    for i in range(hw):
+        sums[i % replicas] += fixed[i]
+    w1 = np.zeros((sq, C), np.float32)
+    w1[:, :Creal] = rng.standard_normal((sq, Creal)).astype(np.float32) * 0.2
+    b1 = rng.standard_normal(sq).astype(np.float32) * 0.1
+    s1 = np.zeros(sq, np.float32)
+    emu.emu_se_fc1.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    assert emu.emu_se_fc1(ptr(sums.view(np.uint64)), replicas, C, Creal, sq, 1.0 / hw, ptr(w1), ptr(b1), ptr(s1)) == 0
+    mean = (fixed.sum(axis=0).astype(np.float64) / 2.0 ** 24 / hw).astype(np.float32)
+    z = w1 @ mean + b1
+    want_s1 = z / (1.0 + np.exp(-z))
+    assert np.abs(s1 - want_s1).max() <= 1e-5
+
+    w2 = np.zeros((C, sq), np.float32)
+    w2[:Creal] = rng.standard_normal((Creal, sq)).astype(np.float32) * 0.5
+    b2 = np.zeros(C, np.float32)
+    b2[:Creal] = rng.standard_normal(Creal).astype(np.float32) * 0.2
+    w = rng.standard_normal((rows, C)).astype(np.float32)
+    hi, lo = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
+    assert emu.emu_se_scale_weights(ptr(w), ptr(hi), ptr(lo), rows, C, ptr(s1), ptr(w2), ptr(b2), sq, Creal) == 0
+    gate = 1.0 / (1.0 + np.exp(-(w2 @ s1 + b2)))
+    gate[Creal:] = 0.0
+    want = w * gate[None, :]
+    got = hi.astype(np.float32) + lo.astype(np.float32)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    assert np.all(got[:, Creal:] == 0)
+    hi2 = np.zeros((rows, C), np.float16)
+    assert emu.emu_se_scale_weights(ptr(w), ptr(hi2), None, rows, C, ptr(s1), ptr(w2), ptr(b2), sq, Creal) == 0
+    assert np.array_equal(hi2, hi)
+
+
+def test_fc_kernel(emu):
+    rng = np.random.default_rng(9)
+    N, K = 37, 200
+    x, w, b = rng.standard_normal(K).astype(np.float32), (rng.standard_normal((N, K)) * 0.1).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    z = torch.from_numpy(w @ x + b)
+    out = np.zeros(N, np.float32)
+    for act, want in ((0, z), (1, F.gelu(z)), (3, torch.sigmoid(z)), (2, F.silu(z)), (10, F.silu(F.silu(z)))):
+        assert emu.emu_fc(ptr(x), ptr(w), ptr(b), ptr(out), N, K, act) == 0
+        assert np.abs(out - want.numpy()).max() <= 2e-5, act
+
+
+# ------------------------------------------------------------------------------------------------ AutoDrive blocks
+def test_maxpool5_and_attention_kernels(emu):
+    rng = np.random.default_rng(11)
+    H, W, C = 9, 12, 32
+    x = rng.standard_normal((C, H, W)).astype(np.float32)
+    src = np.ascontiguousarray(nhwc(x, C).astype(np.float16))
+    dst = np.zeros((H, W, 64), np.float16)
+    assert emu.emu_maxpool5(ptr(src), H, W, C, 8, ptr(dst), 64, 32, 16) == 0       # channels 8..23 -> slice 32..47 of the concat tensor
+    want = F.max_pool2d(torch.from_numpy(src.astype(np.float32).transpose(2, 0, 1))[None], 5, 1, 2)[0].numpy()
+    assert np.array_equal(dst[..., 32:48].astype(np.float32), want[8:24].transpose(1, 2, 0))
+    assert not dst[..., :32].any() and not dst[..., 48:].any()
+
+    heads, dk, dv = 2, 8, 16
+    Hq, Wq = 6, 7
+    T, per = Hq * Wq, 2 * dk + dv
+    qkv = rng.standard_normal((T, heads * per)).astype(np.float32)
+    qh, ql = split16(qkv)
+    q32 = torch.from_numpy(qh.astype(np.float32) + ql.astype(np.float32))
+    oh, ol = np.zeros((T, heads * dv), np.float16), np.zeros((T, heads * dv), np.float16)
+    vh, vl = np.zeros_like(oh), np.zeros_like(ol)
+    scale = dk ** -0.5
+    emu.emu_attention.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 4
+    assert emu.emu_attention(ptr(qh), ptr(ql), Hq, Wq, heads, dk, dv, scale, ptr(oh), ptr(ol), ptr(vh), ptr(vl)) == 0
+    got = oh.astype(np.float32) + ol.astype(np.float32)
+    for h in range(heads):
+        q, k, v = (q32[:, h * per + a:h * per + b] for a, b in ((0, dk), (dk, 2 * dk), (2 * dk, per)))
+        want = torch.softmax(q @ k.T * scale, dim=1) @ v                              # common_layers.py:95-101
+        assert np.abs(got[:, h * dv:(h + 1) * dv] - want.numpy()).max() <= 1e-5
+        assert np.abs((vh.astype(np.float32) + vl.astype(np.float32))[:, h * dv:(h + 1) * dv] - v.numpy()).max() <= 1e-6
+
+
+def test_layout_conversion_kernels_roundtrip(emu):
+    rng = np.random.default_rng(13)
+    Creal, C, H, W = 5, 32, 6, 9
+    x = rng.standard_normal((Creal, H, W)).astype(np.float32)
+    hi, lo = np.full((H, W, C), 7, np.float16), np.full((H, W, C), 7, np.float16)
+    assert emu.emu_nchw_to_act(ptr(x), Creal, ptr(hi), ptr(lo), H, W, C) == 0
+    assert not hi[..., Creal:].any() and not lo[..., Creal:].any()                # pad channels are exactly zero
+    back = np.zeros_like(x)
+    assert emu.emu_act_to_nchw(ptr(hi), ptr(lo), H, W, C, Creal, ptr(back)) == 0
+    assert np.abs(back - x).max() <= 4e-7 * np.abs(x).max()
