@@ -74,6 +74,39 @@ int emu_attention(void* qkv_hi, void* qkv_lo, int H, int W, int heads, int dk, i
   AttnParams p{view(qkv_hi, qkv_lo, H, W, heads * (2 * dk + dv)), view(out_hi, out_lo, H, W, heads * dv), view(v_hi, v_lo, H, W, heads * dv), heads, dk, dv, scale};
   return launch_attention(p, nullptr);
 }
+int emu_pool_partial(void* hi, void* lo, int H, int W, int C, float* partial, int nslab) {
+  PoolParams p{view(hi, lo, H, W, C), partial, nslab};
+  return launch_pool_partial(p, nullptr);
+}
+int emu_fc_pooled(const float* partial, int nslab, int Kstride, float inv_hw, const float* w, const float* b, float* out, int N, int K, int act) {
+  FcParams p{};
+  p.w = w; p.b = b; p.out = out; p.N = N; p.K = K; p.act = act; p.partial = partial; p.nslab = nslab; p.Kstride = Kstride; p.inv_hw = inv_hw;
+  return launch_fc(p, nullptr);
+}
+int emu_ctx_conv1(const float* map, int H, int W, const float* w, const float* b, void* hi, void* lo, int C, int act) {
+  CtxConv1Params p{map, H, W, w, b, view(hi, lo, H, W, C), act};
+  return launch_ctx_conv1(p, nullptr);
+}
+// f[i]: hi/lo planes, H, W, C of the five backbone taps; out: 10x20-style map with Cout padded channels
+int emu_fusion(void** hi, void** lo, const int* H, const int* W, const int* C, const int* creal, const int* shift, void* out_hi, void* out_lo, int OH,
+               int OW, int Cout, int Creal_out) {
+  FusionParams p{};
+  for (int i = 0; i < 5; ++i) {
+    p.f[i] = view(hi[i], lo ? lo[i] : nullptr, H[i], W[i], C[i]);
+    p.creal[i] = creal[i];
+    p.shift[i] = shift[i];
+  }
+  p.out = view(out_hi, out_lo, OH, OW, Cout);
+  p.Creal_out = Creal_out;
+  return launch_fusion(p, nullptr);
+}
+int emu_chan_copy(void* shi, void* slo, int H, int W, int C, int src_off, void* dhi, void* dlo, int dC, int dst_off, int nch) {
+  return launch_chan_copy(view(shi, slo, H, W, C), src_off, view(dhi, dlo, H, W, dC), dst_off, nch, nullptr);
+}
+int emu_dwconv_plain(void* ihi, void* ilo, void* ahi, void* alo, void* ohi, void* olo, int H, int W, int C, const float* w, const float* b) {
+  DwPlainParams p{view(ihi, ilo, H, W, C), view(ohi, olo, H, W, C), view(ahi, alo, H, W, C), w, b};
+  return launch_dwconv_plain(p, nullptr);
+}
 int emu_nchw_to_act(const float* src, int Creal, void* hi, void* lo, int H, int W, int C) { return launch_nchw_to_act(src, Creal, view(hi, lo, H, W, C), nullptr); }
 int emu_act_to_nchw(void* hi, void* lo, int H, int W, int C, int Creal, float* dst) { return launch_act_to_nchw(view(hi, lo, H, W, C), Creal, dst, nullptr); }
 

@@ -270,3 +270,85 @@ def test_layout_conversion_kernels_roundtrip(emu):
     back = np.zeros_like(x)
     assert emu.emu_act_to_nchw(ptr(hi), ptr(lo), H, W, C, Creal, ptr(back)) == 0
     assert np.abs(back - x).max() <= 4e-7 * np.abs(x).max()
+
+
+# ------------------------------------------------------------------------------------------------ context / fusion
+def test_context_path_kernels(emu):
+    """scene_context.py:25-47 pieces: global average pool as slab partial sums -> first FC reading the partials (GELU),
+    and context_layer_3 (conv 3x3 1 -> C on the 10x20 sigmoid map, GELU)."""
+    rng = np.random.default_rng(17)
+    H, W, Creal, Cp, nslab = 10, 20, 72, 96, 4
+    x = np.zeros((H, W, Cp), np.float32)
+    x[..., :Creal] = rng.standard_normal((H, W, Creal)).astype(np.float32)
+    hi, lo = split16(x)
+    partial = np.zeros((nslab, Cp), np.float32)
+    assert emu.emu_pool_partial(ptr(hi), ptr(lo), H, W, Cp, ptr(partial), nslab) == 0
+    val = hi.astype(np.float32) + lo.astype(np.float32)
+    assert np.abs(partial.sum(axis=0) - val.reshape(-1, Cp).sum(axis=0)).max() <= 1e-4
+    N = 24
+    w = (rng.standard_normal((N, Creal)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32) * 0.1
+    out = np.zeros(N, np.float32)
+    emu.emu_fc_pooled.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int]
+    assert emu.emu_fc_pooled(ptr(partial), nslab, Cp, 1.0 / (H * W), ptr(w), ptr(b), ptr(out), N, Creal, 1) == 0
+    mean = val.reshape(-1, Cp).mean(axis=0)[:Creal]
+    assert np.abs(out - F.gelu(torch.from_numpy(w @ mean + b)).numpy()).max() <= 2e-5
+
+    C = 32
+    m = rng.uniform(0, 1, size=(H, W)).astype(np.float32)
+    wt = (rng.standard_normal((C, 1, 3, 3)) * 0.5).astype(np.float32)
+    bc = rng.standard_normal(C).astype(np.float32) * 0.1
+    w9 = np.ascontiguousarray(wt.reshape(C, 9).T)
+    ohi, olo = np.zeros((H, W, C), np.float16), np.zeros((H, W, C), np.float16)
+    assert emu.emu_ctx_conv1(ptr(m), H, W, ptr(w9), ptr(bc), ptr(ohi), ptr(olo), C, 1) == 0
+    want = F.gelu(F.conv2d(torch.from_numpy(m)[None, None], torch.from_numpy(wt), torch.from_numpy(bc), padding=1))[0].numpy()
+    assert _rel((ohi.astype(np.float32) + olo.astype(np.float32)).transpose(2, 0, 1), want) <= 2e-6
+
+
+def test_egolanes_feature_fusion_kernel(emu):
+    """backbone_feature_fusion.py:13-38: MaxPool2x2 applied 4/3/2/1/0 times to the five taps, concat along C."""
+    rng = np.random.default_rng(19)
+    OH, OW = 2, 3
+    creal, cpad, shift = [6, 5, 7, 9, 12], [32, 32, 32, 32, 32], [4, 3, 2, 1, 0]
+    taps, his, los = [], [], []
+    for cr, cp, sh in zip(creal, cpad, shift):
+        t = rng.standard_normal((cr, OH << sh, OW << sh)).astype(np.float32)
+        h, l = split16(nhwc(t, cp))
+        taps.append((h.astype(np.float32) + l.astype(np.float32)).transpose(2, 0, 1)[:cr])
+        his.append(h)
+        los.append(l)
+    Creal_out, Cout = sum(creal), 64
+    ohi, olo = np.full((OH, OW, Cout), 3, np.float16), np.full((OH, OW, Cout), 3, np.float16)
+    arr = lambda xs: (ct.c_void_p * 5)(*[x.ctypes.data for x in xs])
+    ints = lambda xs: (ct.c_int * 5)(*xs)
+    assert emu.emu_fusion(arr(his), arr(los), ints([OH << s for s in shift]), ints([OW << s for s in shift]), ints(cpad), ints(creal), ints(shift),
+                          ptr(ohi), ptr(olo), OH, OW, Cout, Creal_out) == 0
+    want = np.concatenate([F.max_pool2d(torch.from_numpy(t)[None], 1 << s)[0].numpy() if s else t for t, s in zip(taps, shift)], axis=0)
+    got = (ohi.astype(np.float32) + olo.astype(np.float32)).transpose(2, 0, 1)
+    assert np.abs(got[:Creal_out] - want).max() <= 3e-7 * np.abs(want).max()
+    assert not got[Creal_out:].any()
+
+
+def test_autodrive_glue_kernels(emu):
+    """torch.cat / chunk as channel-slice copies, and Attention's `x + conv1(v)` depthwise positional conv (common_layers.py:103)."""
+    rng = np.random.default_rng(23)
+    H, W, Cs, Cd = 5, 7, 32, 64
+    src = rng.standard_normal((H, W, Cs)).astype(np.float32)
+    shi, slo = split16(src)
+    dhi, dlo = np.zeros((H, W, Cd), np.float16), np.zeros((H, W, Cd), np.float16)
+    assert emu.emu_chan_copy(ptr(shi), ptr(slo), H, W, Cs, 16, ptr(dhi), ptr(dlo), Cd, 40, 16) == 0
+    assert np.array_equal(dhi[..., 40:56], shi[..., 16:32]) and np.array_equal(dlo[..., 40:56], slo[..., 16:32])
+    assert not dhi[..., :40].any() and not dhi[..., 56:].any()
+
+    C = 32
+    x, add = rng.standard_normal((C, H, W)).astype(np.float32), rng.standard_normal((C, H, W)).astype(np.float32)
+    wt, b = (rng.standard_normal((C, 1, 3, 3)) * 0.3).astype(np.float32), rng.standard_normal(C).astype(np.float32) * 0.1
+    xh, xl = split16(nhwc(x, C))
+    ah, al = split16(nhwc(add, C))
+    oh, ol = np.zeros((H, W, C), np.float16), np.zeros((H, W, C), np.float16)
+    w9 = np.ascontiguousarray(wt.reshape(C, 9).T)
+    assert emu.emu_dwconv_plain(ptr(xh), ptr(xl), ptr(ah), ptr(al), ptr(oh), ptr(ol), H, W, C, ptr(w9), ptr(b)) == 0
+    xin = torch.from_numpy((xh.astype(np.float32) + xl.astype(np.float32)).transpose(2, 0, 1))[None]
+    want = (F.conv2d(xin, torch.from_numpy(wt), torch.from_numpy(b), padding=1, groups=C)[0].numpy()
+            + (ah.astype(np.float32) + al.astype(np.float32)).transpose(2, 0, 1))
+    assert _rel((oh.astype(np.float32) + ol.astype(np.float32)).transpose(2, 0, 1), want) <= 2e-6
