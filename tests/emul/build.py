@@ -1,31 +1,57 @@
-"""TEST INFRASTRUCTURE: build tests/emul/_build/libvp_emul.so -- the non-MFMA kernel sources compiled for the HOST on top
-of the HIP-on-CPU shim (shim/hip/hip_runtime.h), so the CPU suite can execute the real kernel code against the oracle."""
+"""TEST INFRASTRUCTURE: build tests/emul/_build/libvp_emul.so -- EVERY csrc/ source (kernels, engine, C ABI) compiled for the
+HOST on top of the HIP-on-CPU shim (shim/hip/hip_runtime.h), so the CPU suite can execute the real kernel and engine code
+against the oracle.  Source rewrites (listed here, nothing else differs from what hipcc compiles):
+  * `extern __shared__`  ->  `extern`                      (dynamic LDS is static storage in harness.cpp)
+  * the two inline-asm statements (an AGPR read, an ablation-only register pin) -> their plain C++ equivalents.
+Linked with -Bsymbolic and meant to be dlopen-ed RTLD_LOCAL: it exports the same symbols as libvp_hip.so and must neither
+capture nor be captured by that library when both live in one test process."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(os.path.dirname(os.path.dirname(HERE)), "autoware_vision_pilot_amd", "csrc")
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "autoware_vision_pilot_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-KERNEL_FILES = ("kernels_misc.hip", "kernels_backbone.hip", "kernels_autodrive.hip")
-HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp")
+UNITS = ("kernels_conv.hip", "kernels_convt_stream.hip", "kernels_conv3x3.hip", "kernels_conv3x3_region.hip", "kernels_backbone.hip",
+         "kernels_misc.hip", "kernels_autodrive.hip", "engine.cpp", "onnx_reader.cpp", "vp_api.cpp")
+HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp", "conv_epilogue.hpp", "engine.hpp", "viridis_lut.inc")
+REWRITES = (
+    ("extern __shared__", "extern"),
+    ('asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));', "v = acc[i][j][4 * g + r];"),
+    ('asm volatile("" ::"v"(a_[i]), "v"(b_[j]));', "(void)0;"),
+)
 
 
 def build(force=False):
     lib = os.path.join(OUT, "libvp_emul.so")
-    srcs = [os.path.join(CSRC, f) for f in KERNEL_FILES + HEADERS] + [os.path.join(HERE, "harness.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h")]
-    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
+    deps = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(HERE, f) for f in ("harness.cpp", "build.py", os.path.join("shim", "hip", "hip_runtime.h"))]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in deps):
         return lib
     os.makedirs(OUT, exist_ok=True)
-    for f in KERNEL_FILES + HEADERS:
-        text = open(os.path.join(CSRC, f)).read().replace("extern __shared__", "extern")
+    for f in UNITS + HEADERS:
+        text = open(os.path.join(CSRC, f)).read()
+        for a, b in REWRITES:
+            text = text.replace(a, b)
+        text = text.replace('#include "../../include/vp_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "vp_hip.h"))
         with open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w") as o:
             o.write(text)
-    cmd = [CLANG, "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-everything", "-I", os.path.join(HERE, "shim"), "-I", OUT,
-           os.path.join(HERE, "harness.cpp"), "-o", lib]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    flags = [CLANG, "-std=c++20", "-O1", "-fPIC", "-pthread", "-ffp-contract=off", "-Wno-everything", "-I", os.path.join(HERE, "shim"), "-I", OUT]
+
+    def cc(src):
+        obj = os.path.join(OUT, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        r = subprocess.run(flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("emulation build failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return obj
+
+    srcs = [os.path.join(OUT, f.replace(".hip", ".cpp")) for f in UNITS] + [os.path.join(HERE, "harness.cpp")]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(cc, srcs))
+    r = subprocess.run([CLANG, "-shared", "-pthread", "-Wl,-Bsymbolic", "-o", lib] + objs, capture_output=True, text=True)
     if r.returncode:
-        raise RuntimeError("emulation build failed:\n" + r.stderr[-4000:])
+        raise RuntimeError("emulation link failed:\n" + r.stderr[-4000:])
     return lib
 
 

@@ -1,15 +1,14 @@
-// TEST INFRASTRUCTURE (see shim/hip/hip_runtime.h): the real kernel sources compiled for the host + plain-C entry points
-// for the CPU tests (tests/test_kernels_emulated.py).  The included files are csrc/*.hip with `extern __shared__`
-// rewritten to `extern` by build.py; nothing else is changed.
-#include "kernels_misc.cpp"
-#include "kernels_backbone.cpp"
-#include "kernels_autodrive.cpp"
+// TEST INFRASTRUCTURE (see shim/hip/hip_runtime.h): storage for the kernels' dynamic LDS + plain-C entry points onto the
+// kernel launchers for the CPU tests (tests/test_kernels_emulated.py).  Linked with every csrc/ source compiled for the host
+// (build.py), so the emulated library also exports the whole C ABI of include/vp_hip.h.
+#include "act_io.hpp"
 
-namespace vp {  // dynamic-LDS arrays of the kernels above (one workgroup runs at a time)
-alignas(16) unsigned char dw_smem[1 << 17];
-alignas(16) float mean[1 << 15];
-alignas(16) float xs[1 << 15];
-alignas(16) float sh[1 << 15];
+namespace vp {  // dynamic-LDS arrays of the kernels (one workgroup runs at a time): 160 KiB, the size of a CU's LDS
+alignas(16) char smem[160 << 10];
+alignas(16) unsigned char dw_smem[160 << 10];
+alignas(16) float mean[40 << 10];
+alignas(16) float xs[40 << 10];
+alignas(16) float sh[40 << 10];
 }  // namespace vp
 
 using namespace vp;

@@ -1,0 +1,100 @@
+"""The MFMA convolution kernels (csrc/kernels_conv.hip, kernels_conv3x3.hip, kernels_conv3x3_region.hip,
+kernels_convt_stream.hip) and the engine code that packs weights and plans them, executed on the CPU: every csrc/ source
+is compiled for the host on the HIP-on-CPU shim of tests/emul, whose `v_mfma_f32_32x32x16_f16` is a wave-level rendezvous
+with the ISA's register layout.  Same entry point (vp_op_conv2d), reference (PyTorch) and tolerances as the GPU op tests
+(tests/test_gpu_conv_op.py), on maps small enough for thread-per-work-item emulation: tile shapes, K blocks, split-K,
+ragged channels / odd images, residual modes, activations, ConvTranspose pixel shuffle, both precisions."""
+import ctypes as ct
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul"))
+
+ACT = {0: lambda t: t, 1: F.gelu, 2: F.silu}
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    """autoware_vision_pilot_amd.lib bound to the emulated library for the duration of this module."""
+    import build as emul_build
+
+    from autoware_vision_pilot_amd import lib
+
+    if not os.path.exists(emul_build.CLANG):
+        pytest.skip("host clang++ of the ROCm toolchain not found")
+    so = ct.CDLL(emul_build.build(), mode=os.RTLD_LOCAL | os.RTLD_NOW)     # never RTLD_GLOBAL: same symbol names as libvp_hip.so
+    for name, (res, args) in lib._SIGS.items():
+        fn = getattr(so, name)
+        fn.restype, fn.argtypes = res, args
+    saved = lib._lib
+    lib._lib = so
+    yield lib
+    lib._lib = saved
+
+
+def _h(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _case(lib, cin, cout, h, w, ks, mode, act, res_mode, precision, cfgs, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    k = 2 if mode == 1 else ks
+    wshape = (cin, cout, 2, 2) if mode == 1 else (cout, cin, k, k)
+    wt = rng.standard_normal(wshape, dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * (1 if mode == 1 else k * k))))
+    b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+    oh, ow = (2 * h, 2 * w) if mode == 1 else (h, w)
+    res = rng.standard_normal((cout, oh, ow), dtype=np.float32) if res_mode else None
+    xr, wr, rr = (x, wt, res) if precision == 1 else (_h(x), _h(wt), _h(res) if res is not None else None)
+    xt, wtt, bt = (torch.from_numpy(v).double() for v in (xr, wr, b))
+    y = F.conv_transpose2d(xt[None], wtt, bt, stride=2) if mode == 1 else F.conv2d(xt[None], wtt, bt, padding=ks // 2)
+    y = ACT[act](y)
+    if res_mode == 1:
+        y = y + torch.from_numpy(rr).double()[None]
+    elif res_mode == 2:
+        r = torch.from_numpy(rr).double()[None]
+        y = y * r + r
+    ref = y[0].float().numpy()
+    tol = 1.5e-3 if precision == 0 else 2e-5
+    for tile, bk, nsplit in cfgs:
+        got = lib.op_conv2d(x, wt, b, ks=ks, mode=mode, act=act, res=res, res_mode=res_mode, precision=precision, tile=tile, bk=bk, nsplit=nsplit)
+        assert got.shape == ref.shape
+        err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+        assert err <= tol, f"tile {tile} bk {bk} nsplit {nsplit}: err {err:.3e}"
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_halo_3x3_kernel_every_tile(emu_lib, precision):
+    """kernels_conv3x3.hip: the five workgroup tiles (128/64/32 output channels x 16x16 / 8x16 pixels), split-K, ragged
+    channel counts, an image that is not a multiple of the pixel tile."""
+    cfgs = [(100, -1, 1), (101, -1, 2), (102, -1, 1), (103, -1, 3), (104, -1, 1)]
+    _case(emu_lib, 32, 72, 11, 21, 3, 0, 1, 0, precision, cfgs, seed=1)
+    _case(emu_lib, 40, 24, 16, 16, 3, 0, 0, 1, precision, [(103, -1, 1), (104, -1, 2)], seed=2)
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_generic_gemm_kernel(emu_lib, precision):
+    """kernels_conv.hip: implicit GEMM, all four tiles, both K blocks, split-K, 1x1 (K1 fast path incl. the register
+    epilogues) and 3x3, residual add / mul-add, fewer input channels than one K block."""
+    _case(emu_lib, 96, 24, 7, 13, 1, 0, 2, 0, precision, [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 64, 1), (3, 32, 1)], seed=3)
+    _case(emu_lib, 48, 80, 6, 10, 1, 0, 0, 1, precision, [(-1, -1, -1), (2, 32, 2)], seed=4)
+    _case(emu_lib, 32, 40, 5, 8, 3, 0, 1, 2, precision, [(1, 32, 1), (2, 64, 2)], seed=5)
+    _case(emu_lib, 3, 32, 8, 8, 3, 0, 0, 0, precision, [(-1, -1, -1)], seed=6)
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_conv_transpose_pixel_shuffle(emu_lib, precision):
+    """ConvTranspose2d(k2, s2) as a GEMM with the pixel-shuffle store; K = 128 takes the persistent streaming kernel."""
+    _case(emu_lib, 64, 48, 5, 6, 2, 1, 0, 0, precision, [(-1, -1, -1), (1, 32, 1), (2, 64, 1)], seed=7)
+    _case(emu_lib, 128, 64, 4, 8, 2, 1, 1, 0, precision, [(-1, -1, -1)], seed=8)
+
+
+def test_region_kernel(emu_lib):
+    """kernels_conv3x3_region.hip (opt-in in the engine, fp16 engines only): 10x40 and 16x32 regions."""
+    _case(emu_lib, 64, 40, 10, 40, 3, 0, 1, 0, 0, [(200, -1, 1), (200, -1, 2)], seed=9)
+    _case(emu_lib, 96, 33, 16, 32, 3, 0, 0, 0, 0, [(201, -1, 1)], seed=10)
