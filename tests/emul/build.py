@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: build tests/emul/_build/libvp_emul.so -- EVERY csrc/ source (kernels, engine, C ABI) compiled for the
 HOST on top of the HIP-on-CPU shim (shim/hip/hip_runtime.h), so the CPU suite can execute the real kernel and engine code
 against the oracle.  Source rewrites (listed here, nothing else differs from what hipcc compiles):
-  * `extern __shared__`  ->  `extern`                      (dynamic LDS is static storage in harness.cpp)
+  * `extern __shared__`  ->  `extern thread_local`         (dynamic LDS is per-worker storage in harness.cpp)
   * the two inline-asm statements (an AGPR read, an ablation-only register pin) -> their plain C++ equivalents.
 Linked with -Bsymbolic and meant to be dlopen-ed RTLD_LOCAL: it exports the same symbols as libvp_hip.so and must neither
 capture nor be captured by that library when both live in one test process."""
@@ -18,7 +18,7 @@ UNITS = ("kernels_conv.hip", "kernels_convt_stream.hip", "kernels_conv3x3.hip", 
          "kernels_misc.hip", "kernels_autodrive.hip", "engine.cpp", "onnx_reader.cpp", "vp_api.cpp")
 HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp", "conv_epilogue.hpp", "engine.hpp", "viridis_lut.inc")
 REWRITES = (
-    ("extern __shared__", "extern"),
+    ("extern __shared__", "extern thread_local"),
     ('asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));', "v = acc[i][j][4 * g + r];"),
     ('asm volatile("" ::"v"(a_[i]), "v"(b_[j]));', "(void)0;"),
 )

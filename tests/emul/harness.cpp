@@ -3,12 +3,12 @@
 // (build.py), so the emulated library also exports the whole C ABI of include/vp_hip.h.
 #include "act_io.hpp"
 
-namespace vp {  // dynamic-LDS arrays of the kernels (one workgroup runs at a time): 160 KiB, the size of a CU's LDS
-alignas(16) char smem[160 << 10];
-alignas(16) unsigned char dw_smem[160 << 10];
-alignas(16) float mean[40 << 10];
-alignas(16) float xs[40 << 10];
-alignas(16) float sh[40 << 10];
+namespace vp {  // dynamic-LDS arrays of the kernels (per worker thread = per running workgroup): 160 KiB, the size of a CU's LDS
+alignas(16) thread_local char smem[160 << 10];
+alignas(16) thread_local unsigned char dw_smem[160 << 10];
+alignas(16) thread_local float mean[40 << 10];
+alignas(16) thread_local float xs[40 << 10];
+alignas(16) thread_local float sh[40 << 10];
 }  // namespace vp
 
 using namespace vp;

@@ -1,14 +1,18 @@
 // TEST INFRASTRUCTURE: a minimal HIP-on-CPU execution shim, so that the CPU test suite (-m "not gpu") can run the REAL
 // source of the non-MFMA kernels (csrc/kernels_misc.hip, kernels_backbone.hip, kernels_autodrive.hip) and check them
-// against the oracle without a GPU.  Not a performance model and not part of the product: one workgroup at a time, one
-// host thread per work-item, __syncthreads / wave shuffles as real rendezvous, LDS as static storage.
-// Built by tests/emul/build.py with the host clang++; `extern __shared__` declarations are rewritten to plain `extern`
-// (storage defined in harness.cpp).  Limits: 1-D workgroups, no MFMA / inline-asm kernels (those are GPU-only tests).
+// against the oracle without a GPU.  Not a performance model and not part of the product: work-items are fibers switched at
+// __syncthreads / wave shuffles / MFMA, workgroups run on a few host threads, LDS is thread_local storage.
+// Built by tests/emul/build.py with the host clang++; `extern __shared__` declarations are rewritten to `extern thread_local`
+// (storage defined in harness.cpp).  Limits: convergent wave operations only (a divergent one aborts with a message).
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <sys/mman.h>
+#include <ucontext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -24,7 +28,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 
 struct dim3 {
   unsigned x, y, z;
@@ -46,119 +50,196 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "s
 
 namespace emu {
 
-// Counting barrier whose participant count can shrink (work-items that return early) and be reset between workgroups.
-class Barrier {
- public:
-  void reset(int n) {
-    expected_ = n;
-    waiting_ = 0;
-  }
-  void wait() {
-    std::unique_lock<std::mutex> lk(m_);
-    const unsigned ph = phase_;
-    if (++waiting_ >= expected_) {
-      waiting_ = 0;
-      ++phase_;
-      cv_.notify_all();
-    } else {
-      cv_.wait(lk, [&] { return phase_ != ph; });
-    }
-  }
-  void drop() {
-    std::unique_lock<std::mutex> lk(m_);
-    if (--expected_ > 0 && waiting_ >= expected_) {
-      waiting_ = 0;
-      ++phase_;
-      cv_.notify_all();
-    }
-  }
-
- private:
-  std::mutex m_;
-  std::condition_variable cv_;
-  int expected_ = 0, waiting_ = 0;
-  unsigned phase_ = 0;
-};
-
-struct Team {
-  int threads = 0;
-  Barrier all, block;
-  std::vector<std::unique_ptr<Barrier>> wave;
-  std::vector<uint64_t> slots;  // [waves][64]
-  std::vector<float> mfma_a, mfma_b;  // [waves][64][8]
-};
-
-struct Ctx {
-  dim3 tid, bid, bdim, gdim;
-  Team* team = nullptr;
-  int lin = 0;
-};
-inline thread_local Ctx ctx;
-
-// "Graphs": while a capture is open every launch / copy is executed AND recorded as a closure; hipGraphLaunch replays them.
-struct Graph {
+// Execution model: a launch's workgroups are spread over a few OS worker threads; inside a workgroup every work-item is a
+// FIBER (ucontext) of that worker, run in lane order and switched only at synchronisation points (__syncthreads, wave
+// shuffles, MFMA).  LDS (`__shared__` -> static thread_local) is therefore private to the workgroup a worker is running.
+// Deterministic, no kernel-level blocking; global-memory atomics between concurrently running workgroups are real atomics.
+struct Graph {  // "graphs": while a capture is open every launch / copy is executed AND recorded; hipGraphLaunch replays
   std::vector<std::function<void()>> nodes;
 };
 inline Graph* capturing = nullptr;
 
-template <class K, class... A>
-void run_grid(K kern, dim3 grid, dim3 block, A... args);
+struct Ctx {  // what threadIdx / blockIdx / ... read for the running fiber
+  dim3 tid, bid, bdim, gdim;
+  int lin = 0;
+};
 
-template <class K, class... A>
-void launch(K kern, dim3 grid, dim3 block, size_t /*dynamic LDS: storage is static in harness.cpp*/, A... args) {
-  if (capturing) capturing->nodes.push_back([=] { run_grid(kern, grid, block, args...); });
-  run_grid(kern, grid, block, args...);
+enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
+
+struct Worker {
+  static constexpr size_t kStack = 256 << 10;
+  int T = 0, waves = 0, cur = 0, live = 0;
+  std::vector<ucontext_t> fib;
+  ucontext_t sched;
+  std::vector<Ctx> ctx;
+  std::vector<int> state;
+  std::vector<unsigned> wait_phase;
+  unsigned block_phase = 0;
+  int block_arrived = 0;
+  std::vector<unsigned> wave_phase;
+  std::vector<int> wave_arrived, wave_live;
+  std::vector<uint64_t> slots;       // [2][waves][64] shuffle payloads, double-buffered
+  std::vector<float> mfma_a, mfma_b; // [2][waves][64][8]
+  std::vector<unsigned> lane_ops;    // wave operations executed so far by each work-item (selects the buffer)
+  char* stacks = nullptr;
+  std::function<void()> body;
+
+  void prepare(int threads) {
+    if (threads != T) {
+      if (stacks) munmap(stacks, kStack * T);
+      T = threads;
+      waves = (T + 63) / 64;
+      stacks = static_cast<char*>(mmap(nullptr, kStack * T, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_STACK, -1, 0));
+      fib.resize(T);
+      ctx.resize(T);
+      state.resize(T);
+      wait_phase.resize(T);
+      wave_phase.resize(waves);
+      wave_arrived.resize(waves);
+      wave_live.resize(waves);
+      lane_ops.resize(T);
+      slots.resize((size_t)2 * waves * 64);
+      mfma_a.resize((size_t)2 * waves * 512);
+      mfma_b.resize((size_t)2 * waves * 512);
+    }
+  }
+  ~Worker() {
+    if (stacks) munmap(stacks, kStack * T);
+  }
+};
+inline thread_local Worker* worker = nullptr;
+inline thread_local Ctx* cur = nullptr;
+
+inline void yield_to_scheduler() {
+  Worker* w = worker;
+  swapcontext(&w->fib[w->cur], &w->sched);
+}
+inline void release_block(Worker* w) {
+  w->block_arrived = 0;
+  ++w->block_phase;
+}
+inline void release_wave(Worker* w, int wv) {
+  w->wave_arrived[wv] = 0;
+  ++w->wave_phase[wv];
+}
+inline void sync_block() {
+  Worker* w = worker;
+  const int i = w->cur;
+  w->wait_phase[i] = w->block_phase;
+  if (++w->block_arrived >= w->live) {
+    release_block(w);
+    return;
+  }
+  w->state[i] = WAIT_BLOCK;
+  yield_to_scheduler();
+}
+inline void sync_wave() {
+  Worker* w = worker;
+  const int i = w->cur, wv = i / 64;
+  w->wait_phase[i] = w->wave_phase[wv];
+  if (++w->wave_arrived[wv] >= w->wave_live[wv]) {
+    release_wave(w, wv);
+    return;
+  }
+  w->state[i] = WAIT_WAVE;
+  yield_to_scheduler();
+}
+inline void fiber_main() {
+  Worker* w = worker;
+  w->body();
+  const int i = w->cur, wv = i / 64;  // a work-item that returns stops counting towards every later rendezvous
+  w->state[i] = DONE;
+  --w->live;
+  --w->wave_live[wv];
+  if (w->live > 0 && w->block_arrived >= w->live) release_block(w);
+  if (w->wave_live[wv] > 0 && w->wave_arrived[wv] >= w->wave_live[wv]) release_wave(w, wv);
+  swapcontext(&w->fib[i], &w->sched);
+}
+
+inline void run_block(Worker* w, dim3 grid, dim3 block, long long b) {
+  const int T = w->T;
+  w->live = T;
+  w->block_phase = 0;
+  w->block_arrived = 0;
+  for (int wv = 0; wv < w->waves; ++wv) {
+    w->wave_phase[wv] = 0;
+    w->wave_arrived[wv] = 0;
+    w->wave_live[wv] = std::min(64, T - 64 * wv);
+  }
+  const dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y)));
+  for (int t = 0; t < T; ++t) {
+    Ctx& c = w->ctx[t];
+    c.lin = t;
+    c.bdim = block;
+    c.gdim = grid;
+    c.bid = bid;
+    c.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    w->state[t] = RUNNABLE;
+    w->lane_ops[t] = 0;
+    getcontext(&w->fib[t]);
+    w->fib[t].uc_stack.ss_sp = w->stacks + Worker::kStack * t;
+    w->fib[t].uc_stack.ss_size = Worker::kStack;
+    w->fib[t].uc_link = nullptr;
+    makecontext(&w->fib[t], fiber_main, 0);
+  }
+  while (w->live > 0) {
+    bool progressed = false;
+    for (int t = 0; t < T; ++t) {
+      const int st = w->state[t];
+      if (st == DONE) continue;
+      if (st == WAIT_BLOCK && w->block_phase == w->wait_phase[t]) continue;
+      if (st == WAIT_WAVE && w->wave_phase[t / 64] == w->wait_phase[t]) continue;
+      w->state[t] = RUNNABLE;
+      w->cur = t;
+      cur = &w->ctx[t];
+      swapcontext(&w->sched, &w->fib[t]);
+      progressed = true;
+    }
+    if (!progressed) {
+      std::fprintf(stderr, "tests/emul: deadlock -- divergent __syncthreads / wave operation in workgroup %lld\n", b);
+      std::abort();
+    }
+  }
 }
 
 template <class K, class... A>
 void run_grid(K kern, dim3 grid, dim3 block, A... args) {
   const int T = (int)(block.x * block.y * block.z);
   const long long B = (long long)grid.x * grid.y * grid.z;
-  Team team;
-  team.threads = T;
-  team.all.reset(T);
-  const int waves = (T + 63) / 64;
-  for (int w = 0; w < waves; ++w) team.wave.emplace_back(new Barrier);
-  team.slots.assign((size_t)waves * 64, 0);
-  team.mfma_a.assign((size_t)waves * 64 * 8, 0.f);
-  team.mfma_b.assign((size_t)waves * 64 * 8, 0.f);
-  auto body = [&](int t) {
-    Ctx& c = ctx;
-    c.team = &team;
-    c.lin = t;
-    c.bdim = block;
-    c.gdim = grid;
-    c.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-    for (long long b = 0; b < B; ++b) {
-      c.bid = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y)));
-      team.all.wait();  // everybody has left the previous workgroup (its LDS contents are dead)
-      if (t == 0) {
-        team.block.reset(T);
-        for (int w = 0; w < waves; ++w) team.wave[w]->reset(std::min(64, T - 64 * w));
-      }
-      team.all.wait();
-      kern(args...);
-      team.block.drop();
-      team.wave[t / 64]->drop();
-    }
+  std::atomic<long long> next{0};
+  auto work = [&] {
+    Worker me;
+    me.prepare(T);
+    me.body = [&] { kern(args...); };
+    worker = &me;
+    for (long long b = next.fetch_add(1); b < B; b = next.fetch_add(1)) run_block(&me, grid, block, b);
+    worker = nullptr;
+    cur = nullptr;
   };
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nw = (int)std::min<long long>(std::min(8u, hw), B);
   std::vector<std::thread> th;
-  th.reserve(T);
-  for (int t = 0; t < T; ++t) th.emplace_back(body, t);
+  for (int i = 0; i < nw; ++i) th.emplace_back(work);
   for (auto& x : th) x.join();
+}
+
+template <class K, class... A>
+void launch(K kern, dim3 grid, dim3 block, size_t /*dynamic LDS: thread_local storage in harness.cpp*/, A... args) {
+  if (capturing) capturing->nodes.push_back([=] { run_grid(kern, grid, block, args...); });
+  run_grid(kern, grid, block, args...);
 }
 
 template <class V>
 V shfl_xor(V v, int mask) {
   static_assert(sizeof(V) <= 8, "shuffle payload");
-  Ctx& c = ctx;
-  const int w = c.lin / 64, lane = c.lin % 64;
+  Worker* w = worker;
+  const int i = w->cur, wv = i / 64, lane = i % 64;
+  uint64_t* buf = w->slots.data() + ((size_t)(w->lane_ops[i]++ & 1) * w->waves + wv) * 64;
   uint64_t bits = 0;
   std::memcpy(&bits, &v, sizeof(V));
-  c.team->slots[(size_t)w * 64 + lane] = bits;
-  c.team->wave[w]->wait();
-  const uint64_t got = c.team->slots[(size_t)w * 64 + (lane ^ mask)];
-  c.team->wave[w]->wait();
+  buf[lane] = bits;
+  sync_wave();
+  const uint64_t got = buf[lane ^ mask];
   V r;
   std::memcpy(&r, &got, sizeof(V));
   return r;
@@ -171,15 +252,16 @@ V shfl_xor(V v, int mask) {
 // defined -- summed here in fp32 in k order (the kernel tests carry a tolerance for that, as the GPU ones do).
 template <class H8, class F16>
 F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
-  Ctx& x = ctx;
-  const int w = x.lin / 64, lane = x.lin % 64;
-  float* A = x.team->mfma_a.data() + (size_t)w * 512;
-  float* B = x.team->mfma_b.data() + (size_t)w * 512;
-  for (int i = 0; i < 8; ++i) {
-    A[lane * 8 + i] = (float)a[i];
-    B[lane * 8 + i] = (float)b[i];
+  Worker* w = worker;
+  const int i = w->cur, wv = i / 64, lane = i % 64;
+  const size_t base = ((size_t)(w->lane_ops[i]++ & 1) * w->waves + wv) * 512;
+  float* A = w->mfma_a.data() + base;
+  float* B = w->mfma_b.data() + base;
+  for (int e = 0; e < 8; ++e) {
+    A[lane * 8 + e] = (float)a[e];
+    B[lane * 8 + e] = (float)b[e];
   }
-  x.team->wave[w]->wait();
+  sync_wave();
   const int n = lane % 32;
   for (int r = 0; r < 16; ++r) {
     const int m = 8 * (r / 4) + 4 * (lane / 32) + (r % 4);
@@ -187,7 +269,6 @@ F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
     for (int k = 0; k < 16; ++k) acc += A[(m + 32 * (k / 8)) * 8 + (k % 8)] * B[(n + 32 * (k / 8)) * 8 + (k % 8)];
     c[r] = acc;
   }
-  x.team->wave[w]->wait();
   return c;
 }
 
@@ -198,13 +279,13 @@ F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0u
 
-#define threadIdx (emu::ctx.tid)
-#define blockIdx (emu::ctx.bid)
-#define blockDim (emu::ctx.bdim)
-#define gridDim (emu::ctx.gdim)
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::cur->bid)
+#define blockDim (emu::cur->bdim)
+#define gridDim (emu::cur->gdim)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, st, ...) emu::launch(kern, grid, block, shmem, __VA_ARGS__)
 
-inline void __syncthreads() { emu::ctx.team->block.wait(); }
+inline void __syncthreads() { emu::sync_block(); }
 template <class V>
 inline V __shfl_xor(V v, int mask) { return emu::shfl_xor(v, mask); }
 

@@ -1,0 +1,56 @@
+"""The whole engine on the CPU: csrc/ compiled for the host on the HIP-on-CPU shim (tests/emul), driven through the C ABI
+exactly as on the GPU -- weight blob, plan, every kernel incl. the MFMA convolutions (emulated wave-level MFMA), graph
+capture / replay as closure lists.  AutoDrive is the network small enough for the CPU suite (8 GFLOP, ~15 s emulated); it is
+also the one pinned end to end: tests/golden/autodrive.npz holds the outputs of the reference's OWN nn.Module
+(oracle/pin_autodrive.py), so this checks engine == reference without a GPU.  (The 360-GFLOP scene networks take ~10-20
+minutes emulated: run tests/emul/run_network.py by hand.)"""
+import ctypes as ct
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul"))
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "autodrive.npz")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    import build as emul_build
+
+    from autoware_vision_pilot_amd import lib
+
+    if not os.path.exists(emul_build.CLANG):
+        pytest.skip("host clang++ of the ROCm toolchain not found")
+    so = ct.CDLL(emul_build.build(), mode=os.RTLD_LOCAL | os.RTLD_NOW)     # never RTLD_GLOBAL: same symbol names as libvp_hip.so
+    for name, (res, args) in lib._SIGS.items():
+        fn = getattr(so, name)
+        fn.restype, fn.argtypes = res, args
+    saved = lib._lib
+    lib._lib = so
+    yield lib
+    lib._lib = saved
+
+
+def test_autodrive_engine_end_to_end_on_cpu(emu_lib):
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+    from oracle import pre_post
+
+    g = np.load(GOLDEN)
+    frames = [synthetic.synthetic_frame(1080, 1920, int(s)) for s in g["frame_seeds"]]
+    eng = emu_lib.Engine("autodrive", vw.pack_state_dict(synthetic.make_autodrive_state_dict(int(g["weight_seed"]))), precision="fp16x3")
+    try:
+        eng.infer_pair(frames[0], frames[1])                     # eager pass + graph capture
+        got = eng.logits().reshape(3)
+        assert np.abs(got - g["fp32_out"]).max() <= 1e-3, (got, g["fp32_out"])      # the GPU parity bar (measured 2.5e-6)
+        want_in = pre_post.preprocess(frames[1], input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024)
+        assert np.array_equal(eng.input_tensor(), want_in)
+        p5 = None
+        for i, (n, c, h, w) in enumerate(eng.tensors()):
+            if n == "backbone.p5.3.cv2":
+                p5 = eng.tensor_read(i)
+        ref = g["fp32_p5"]
+        assert p5 is not None and np.abs(p5.ravel()[g["fp32_p5_idx"]] - ref).max() <= 1e-3 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        eng.close()
