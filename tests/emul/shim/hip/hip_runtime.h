@@ -54,7 +54,7 @@ namespace emu {
 // FIBER (ucontext) of that worker, run in lane order and switched only at synchronisation points (__syncthreads, wave
 // shuffles, MFMA).  LDS (`__shared__` -> static thread_local) is therefore private to the workgroup a worker is running.
 // Deterministic, no kernel-level blocking; global-memory atomics between concurrently running workgroups are real atomics.
-struct Graph {  // "graphs": while a capture is open every launch / copy is executed AND recorded; hipGraphLaunch replays
+struct Graph {  // "graphs": while a capture is open every launch / copy is recorded as a closure; hipGraphLaunch replays them
   std::vector<std::function<void()>> nodes;
 };
 inline Graph* capturing = nullptr;
@@ -225,7 +225,10 @@ void run_grid(K kern, dim3 grid, dim3 block, A... args) {
 
 template <class K, class... A>
 void launch(K kern, dim3 grid, dim3 block, size_t /*dynamic LDS: thread_local storage in harness.cpp*/, A... args) {
-  if (capturing) capturing->nodes.push_back([=] { run_grid(kern, grid, block, args...); });
+  if (capturing) {  // as on the device: work issued into a capturing stream is recorded, not executed
+    capturing->nodes.push_back([=] { run_grid(kern, grid, block, args...); });
+    return;
+  }
   run_grid(kern, grid, block, args...);
 }
 
@@ -307,7 +310,10 @@ inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) {
-  if (emu::capturing && k != hipMemcpyHostToDevice) emu::capturing->nodes.push_back([=] { std::memmove(d, s, n); });
+  if (emu::capturing) {
+    emu::capturing->nodes.push_back([=] { std::memmove(d, s, n); });
+    return hipSuccess;
+  }
   std::memmove(d, s, n);
   return hipSuccess;
 }

@@ -54,3 +54,27 @@ def test_autodrive_engine_end_to_end_on_cpu(emu_lib):
         assert p5 is not None and np.abs(p5.ravel()[g["fp32_p5_idx"]] - ref).max() <= 1e-3 * max(1.0, float(np.abs(ref).max()))
     finally:
         eng.close()
+
+
+def test_autodrive_from_onnx_path_fp8_fp16_on_cpu(emu_lib, tmp_path):
+    """vp_create on a `*.onnx` model_path (native reader, exporter-folded Conv+BN form), VP_WEIGHTS_FP8, the fp16 engine and
+    the streaming vp_infer form -- BASELINE configs[4] as deployed -- against the reference-pinned fp8 golden outputs."""
+    from pbwriter import onnx_model
+    from test_gpu_onnx_folded import fold_like_exporter
+
+    from autoware_vision_pilot_amd import synthetic
+
+    g = np.load(GOLDEN)
+    frames = [synthetic.synthetic_frame(1080, 1920, int(s)) for s in g["frame_seeds"]]
+    path = tmp_path / "AutoDrive.onnx"
+    path.write_bytes(onnx_model(fold_like_exporter(synthetic.make_autodrive_state_dict(int(g["weight_seed"])))))
+    eng = emu_lib.Engine("autodrive", str(path), precision="fp16", weights_fp8=True)
+    try:
+        eng.infer(frames[0])            # streaming: the first frame pairs with itself
+        eng.infer(frames[1])            # (frames[0], frames[1])
+        got = eng.logits().reshape(3)
+        # fp8 quantisation of FOLDED weights differs slightly from quantising conv and norm separately (the golden path):
+        # the bar is the fp16 engine's (3e-2), not the 1e-3 of the parity mode
+        assert np.abs(got - g["fp8_out"]).max() <= 3e-2, (got, g["fp8_out"])
+    finally:
+        eng.close()
