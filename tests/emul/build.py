@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: build tests/emul/_build/libvp_emul.so -- EVERY csrc/ source (kernels, engine, C ABI) compiled for the
 HOST on top of the HIP-on-CPU shim (shim/hip/hip_runtime.h), so the CPU suite can execute the real kernel and engine code
 against the oracle.  Source rewrites (listed here, nothing else differs from what hipcc compiles):
-  * `extern __shared__`  ->  `extern thread_local`         (dynamic LDS is per-worker storage in harness.cpp)
+  * `extern __shared__`  ->  `extern VP_EMU_LDS`           (dynamic LDS is per-worker storage in harness.cpp)
   * the two inline-asm statements (an AGPR read, an ablation-only register pin) -> their plain C++ equivalents.
 Linked with -Bsymbolic and meant to be dlopen-ed RTLD_LOCAL: it exports the same symbols as libvp_hip.so and must neither
 capture nor be captured by that library when both live in one test process."""
@@ -18,7 +18,7 @@ UNITS = ("kernels_conv.hip", "kernels_convt_stream.hip", "kernels_conv3x3.hip", 
          "kernels_misc.hip", "kernels_autodrive.hip", "engine.cpp", "onnx_reader.cpp", "vp_api.cpp")
 HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp", "conv_epilogue.hpp", "engine.hpp", "viridis_lut.inc")
 REWRITES = (
-    ("extern __shared__", "extern thread_local"),
+    ("extern __shared__", "extern VP_EMU_LDS"),
     ('asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));', "v = acc[i][j][4 * g + r];"),
     ('asm volatile("" ::"v"(a_[i]), "v"(b_[j]));', "(void)0;"),
 )
@@ -55,5 +55,36 @@ def build(force=False):
     return lib
 
 
+def build_race_check(force=False):
+    """tests/emul/_build/race/race_check: the same sources + race_check.cpp under ThreadSanitizer (see shim: VP_EMU_TSAN)."""
+    build(force)  # refreshes the rewritten sources under _build/
+    out = os.path.join(OUT, "race")
+    exe = os.path.join(out, "race_check")
+    deps = [os.path.join(CSRC, f) for f in UNITS + HEADERS] + [os.path.join(HERE, f) for f in ("harness.cpp", "race_check.cpp", "build.py", os.path.join("shim", "hip", "hip_runtime.h"))]
+    if not force and os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(s) for s in deps):
+        return exe
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "vp_hip_path.h"), "w") as o:
+        o.write('#include "%s"\n' % os.path.join(ROOT, "include", "vp_hip.h"))
+    flags = [CLANG, "-std=c++20", "-O1", "-g", "-fPIC", "-pthread", "-ffp-contract=off", "-Wno-everything", "-fsanitize=thread", "-DVP_EMU_TSAN",
+             "-I", os.path.join(HERE, "shim"), "-I", OUT, "-I", out]
+
+    def cc(src):
+        obj = os.path.join(out, os.path.basename(src).rsplit(".", 1)[0] + ".o")
+        r = subprocess.run(flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("race-check build failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return obj
+
+    srcs = [os.path.join(OUT, f.replace(".hip", ".cpp")) for f in UNITS] + [os.path.join(HERE, "harness.cpp"), os.path.join(HERE, "race_check.cpp")]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(cc, srcs))
+    r = subprocess.run([CLANG, "-fsanitize=thread", "-pthread", "-o", exe] + objs, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("race-check link failed:\n" + r.stderr[-4000:])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_race_check(force=True))

@@ -4,11 +4,11 @@
 #include "act_io.hpp"
 
 namespace vp {  // dynamic-LDS arrays of the kernels (per worker thread = per running workgroup): 160 KiB, the size of a CU's LDS
-alignas(16) thread_local char smem[160 << 10];
-alignas(16) thread_local unsigned char dw_smem[160 << 10];
-alignas(16) thread_local float mean[40 << 10];
-alignas(16) thread_local float xs[40 << 10];
-alignas(16) thread_local float sh[40 << 10];
+alignas(16) VP_EMU_LDS char smem[160 << 10];
+alignas(16) VP_EMU_LDS unsigned char dw_smem[160 << 10];
+alignas(16) VP_EMU_LDS float mean[40 << 10];
+alignas(16) VP_EMU_LDS float xs[40 << 10];
+alignas(16) VP_EMU_LDS float sh[40 << 10];
 }  // namespace vp
 
 using namespace vp;

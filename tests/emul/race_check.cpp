@@ -1,0 +1,139 @@
+// TEST INFRASTRUCTURE: data-race check of the kernels.  Built by build.py (race target) from the same host-compiled sources
+// as libvp_emul.so, plus -fsanitize=thread -DVP_EMU_TSAN: every work-item is a ThreadSanitizer fiber and the only
+// happens-before edges are the GPU's own (__syncthreads, wave operations, kernel boundaries; shim/hip/hip_runtime.h).
+// Runs each kernel family once on small random inputs -- results are not checked here (the emulated parity tests do that);
+// ThreadSanitizer reports any pair of work-items touching the same LDS / global bytes without synchronisation.
+//   race_check            all production kernels (~2 min); exit code 0 and no report expected
+//   race_check --quick    the subset the CPU suite runs (every non-MFMA kernel, two halo tiles, a split-K GEMM, both ConvTranspose kernels)
+//   race_check --canary   a deliberately racy kernel; a report is expected (proves the detector sees LDS races)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "act_io.hpp"
+#include "vp_hip_path.h"
+
+using namespace vp;
+
+extern "C" {
+int emu_stem(const float*, int, int, const float*, const float*, void*, void*);
+int emu_dwconv(void*, void*, int, int, int, void*, void*, int, int, const float*, const float*, int, int, unsigned long long*, int);
+int emu_se_fc1(const unsigned long long*, int, int, int, int, float, const float*, const float*, float*);
+int emu_se_scale_weights(const float*, void*, void*, int, int, const float*, const float*, const float*, int, int);
+int emu_fc(const float*, const float*, const float*, float*, int, int, int);
+int emu_pool_partial(void*, void*, int, int, int, float*, int);
+int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
+int emu_depth_viz(const float*, size_t, const uint8_t*, uint8_t*);
+int emu_maxpool5(void*, int, int, int, int, void*, int, int, int);
+}
+
+static std::mt19937 rng(1);
+static std::vector<float> rnd(size_t n, float s = 1.0f) {
+  std::normal_distribution<float> d(0.f, s);
+  std::vector<float> v(n);
+  for (auto& x : v) x = d(rng);
+  return v;
+}
+static std::vector<half_t> rnd16(size_t n) {
+  std::vector<float> f = rnd(n);
+  std::vector<half_t> v(n);
+  for (size_t i = 0; i < n; ++i) v[i] = (half_t)f[i];
+  return v;
+}
+
+static int conv(int precision, int mode, int cin, int cout, int h, int w, int ks, int act, int tile, int bk, int nsplit) {
+  const int k = mode == 1 ? 2 : ks;
+  std::vector<float> x = rnd((size_t)cin * h * w), wt = rnd((size_t)cin * cout * k * k, 0.1f), b = rnd(cout, 0.1f);
+  std::vector<float> out((size_t)cout * (mode == 1 ? 4 : 1) * h * w);
+  char err[256] = {0};
+  const int rc = vp_op_conv2d(0, precision, mode, x.data(), cin, h, w, wt.data(), b.data(), cout, ks, act, 0, nullptr, tile, bk, nsplit, out.data(), err, sizeof err);
+  if (rc) std::fprintf(stderr, "vp_op_conv2d(tile %d) failed: %s\n", tile, err);
+  return rc;
+}
+
+__global__ void canary_kernel(float* out) {
+  __shared__ float lds[64];
+  lds[threadIdx.x] = (float)threadIdx.x;
+  out[threadIdx.x] = lds[threadIdx.x ^ 1];  // no __syncthreads between a neighbour's write and this read
+}
+
+__global__ void trivial_kernel(float* out) {
+  __shared__ float lds[256];
+  lds[threadIdx.x] = (float)threadIdx.x;
+  __syncthreads();
+  out[blockIdx.x * 256 + threadIdx.x] = lds[threadIdx.x ^ 1];
+}
+
+int main(int argc, char** argv) {
+  if (argc > 3 && !std::strcmp(argv[1], "--trivial")) {
+    const int blocks = std::atoi(argv[2]), reps = std::atoi(argv[3]);
+    std::vector<float> out((size_t)blocks * 256);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(trivial_kernel, dim3(blocks), dim3(256), 0, nullptr, out.data());
+    std::printf("trivial ok\n");
+    return 0;
+  }
+  if (argc > 1 && !std::strcmp(argv[1], "--canary")) {
+    std::vector<float> out(64);
+    hipLaunchKernelGGL(canary_kernel, dim3(1), dim3(64), 0, nullptr, out.data());
+    return 0;
+  }
+  int bad = 0;
+  const bool skip_conv = argc > 1 && !std::strcmp(argv[1], "--no-conv");
+  const bool quick = argc > 1 && !std::strcmp(argv[1], "--quick");  // the CPU suite's subset (~1 min); no flag = everything (~2 min)
+  for (int precision = 0; precision < (quick ? 1 : 2) && !skip_conv; ++precision) {
+    for (int tile : {100, 101, 102, 103, 104}) {  // halo 3x3
+      if (quick && tile != 101 && tile != 104) continue;
+      bad |= conv(precision, 0, 64, 72, 11, 21, 3, 1, tile, -1, tile == 101 || tile == 103 ? 2 : 1);
+    }
+    for (int tile : {0, 1, 2, 3}) {  // K1 GEMM
+      if (quick && tile != 1) continue;
+      bad |= conv(precision, 0, 96, 40, 7, 13, 1, 2, tile, tile == 2 ? 64 : 32, tile == 1 ? 2 : 1);
+    }
+    bad |= conv(precision, 0, 32, 40, 5, 8, 3, 1, 1, 32, 1);                                                                                  // generic 3x3
+    bad |= conv(precision, 1, 64, 48, 5, 6, 2, 0, -1, -1, -1);                                                                                // ConvTranspose GEMM
+    bad |= conv(precision, 1, 128, 64, 4, 8, 2, 1, -1, -1, -1);                                                                               // streaming ConvTranspose
+  }
+  if (!skip_conv && !quick) {
+    bad |= conv(0, 0, 64, 40, 10, 40, 3, 1, 200, -1, 2);  // region kernel
+    bad |= conv(0, 0, 96, 33, 16, 32, 3, 0, 201, -1, 1);
+  }
+
+  {  // encoder pieces
+    const int H = 18, W = 28;
+    std::vector<float> x = rnd(3 * H * W), w = rnd(27 * 32, 0.3f), b = rnd(32, 0.1f);
+    std::vector<half_t> hi((size_t)(H / 2) * (W / 2) * 32), lo(hi.size());
+    bad |= emu_stem(x.data(), H, W, w.data(), b.data(), hi.data(), lo.data());
+    for (int k : {3, 5})
+      for (int split = 0; split < 2; ++split) {
+        const int C = 144, h = 13, ww = 21, stride = k == 5 ? 2 : 1, oh = (h + stride - 1) / stride, ow = (ww + stride - 1) / stride;
+        std::vector<half_t> ih = rnd16((size_t)h * ww * C), il = rnd16(ih.size()), oh_((size_t)oh * ow * C), ol_(oh_.size());
+        std::vector<float> wk = rnd((size_t)k * k * C, 0.3f), bb = rnd(C, 0.1f);
+        std::vector<unsigned long long> sums(8 * C, 0ull);
+        bad |= emu_dwconv(ih.data(), split ? il.data() : nullptr, h, ww, C, oh_.data(), split ? ol_.data() : nullptr, oh, ow, wk.data(), bb.data(), k, stride,
+                          sums.data(), 8);
+        std::vector<float> w1 = rnd(6 * C, 0.2f), b1 = rnd(6, 0.1f), s1(6), w2 = rnd(C * 6, 0.5f), b2 = rnd(C, 0.1f), pw = rnd(64 * C);
+        bad |= emu_se_fc1(sums.data(), 8, C, C, 6, 1.0f / (oh * ow), w1.data(), b1.data(), s1.data());
+        std::vector<half_t> ph((size_t)64 * C), pl(ph.size());
+        bad |= emu_se_scale_weights(pw.data(), ph.data(), split ? pl.data() : nullptr, 64, C, s1.data(), w2.data(), b2.data(), 6, C);
+      }
+    std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
+    bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);
+    std::vector<half_t> ph = rnd16(10 * 20 * 96), pl = rnd16(ph.size());
+    std::vector<float> partial(4 * 96);
+    bad |= emu_pool_partial(ph.data(), pl.data(), 10, 20, 96, partial.data(), 4);
+  }
+  {  // AutoDrive attention, SPPF pool; depth visualisation
+    const int heads = 2, dk = 8, dv = 16, Hq = 6, Wq = 7, T = Hq * Wq, per = 2 * dk + dv;
+    std::vector<half_t> qh = rnd16((size_t)T * heads * per), ql = rnd16(qh.size()), oh((size_t)T * heads * dv), ol(oh.size()), vh(oh.size()), vl(oh.size());
+    bad |= emu_attention(qh.data(), ql.data(), Hq, Wq, heads, dk, dv, 0.35f, oh.data(), ol.data(), vh.data(), vl.data());
+    std::vector<half_t> src = rnd16(9 * 12 * 32), dst(9 * 12 * 64);
+    bad |= emu_maxpool5(src.data(), 9, 12, 32, 8, dst.data(), 64, 32, 16);
+    std::vector<float> depth = rnd(37 * 53);
+    std::vector<uint8_t> lut(768, 7), img(37 * 53 * 3);
+    bad |= emu_depth_viz(depth.data(), depth.size(), lut.data(), img.data());
+  }
+  std::printf("race_check: all launches done%s\n", bad ? " (some FAILED to launch)" : "");
+  return bad ? 2 : 0;
+}

@@ -28,7 +28,12 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static thread_local
+#ifdef VP_EMU_TSAN
+#define VP_EMU_LDS  // one workgroup at a time: LDS is plain static storage shared by its work-item threads
+#else
+#define VP_EMU_LDS thread_local  // per worker thread = per running workgroup
+#endif
+#define __shared__ static VP_EMU_LDS
 
 struct dim3 {
   unsigned x, y, z;
@@ -64,6 +69,104 @@ struct Ctx {  // what threadIdx / blockIdx / ... read for the running fiber
   int lin = 0;
 };
 
+#ifdef VP_EMU_TSAN
+// ---- race-check build (-DVP_EMU_TSAN, tests/emul/race_check.cpp): one OS THREAD per work-item, one workgroup at a time,
+// barriers on a mutex + condition variable.  ThreadSanitizer then sees exactly the happens-before edges the GPU gives
+// (__syncthreads, wave operations, kernel boundaries) and reports any two work-items that touch the same LDS / global bytes
+// without one in between.  Slow (a barrier is a futex round trip of 256 threads), so the race check runs small cases.
+class Barrier {
+ public:
+  void reset(int n) {
+    std::unique_lock<std::mutex> lk(m_);
+    expected_ = n;
+    waiting_ = 0;
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    const unsigned ph = phase_;
+    if (++waiting_ >= expected_) {
+      waiting_ = 0;
+      ++phase_;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return phase_ != ph; });
+    }
+  }
+  void drop() {
+    std::unique_lock<std::mutex> lk(m_);
+    if (--expected_ > 0 && waiting_ >= expected_) {
+      waiting_ = 0;
+      ++phase_;
+      cv_.notify_all();
+    }
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int expected_ = 0, waiting_ = 0;
+  unsigned phase_ = 0;
+};
+
+struct Team {
+  int waves = 0;
+  Barrier all, block;
+  std::vector<std::unique_ptr<Barrier>> wave;
+  std::vector<uint64_t> slots;        // [2][waves][64]
+  std::vector<float> mfma_a, mfma_b;  // [2][waves][512]
+};
+inline thread_local Ctx ctx_storage;
+inline thread_local Ctx* cur = &ctx_storage;
+inline thread_local Team* team = nullptr;
+inline thread_local unsigned lane_op = 0;
+
+inline int lin() { return cur->lin; }
+inline unsigned next_wave_op() { return lane_op++; }
+inline uint64_t* shfl_buf(int wv, unsigned op) { return team->slots.data() + ((size_t)(op & 1) * team->waves + wv) * 64; }
+inline float* mfma_buf_a(int wv, unsigned op) { return team->mfma_a.data() + ((size_t)(op & 1) * team->waves + wv) * 512; }
+inline float* mfma_buf_b(int wv, unsigned op) { return team->mfma_b.data() + ((size_t)(op & 1) * team->waves + wv) * 512; }
+inline void sync_block() { team->block.wait(); }
+inline void sync_wave() { team->wave[cur->lin / 64]->wait(); }
+
+template <class K, class... A>
+void run_grid(K kern, dim3 grid, dim3 block, A... args) {
+  const int T = (int)(block.x * block.y * block.z);
+  const long long B = (long long)grid.x * grid.y * grid.z;
+  Team tm;
+  tm.waves = (T + 63) / 64;
+  tm.all.reset(T);
+  for (int w = 0; w < tm.waves; ++w) tm.wave.emplace_back(new Barrier);
+  tm.slots.assign((size_t)2 * tm.waves * 64, 0);
+  tm.mfma_a.assign((size_t)2 * tm.waves * 512, 0.f);
+  tm.mfma_b.assign((size_t)2 * tm.waves * 512, 0.f);
+  auto body = [&](int t) {
+    team = &tm;
+    Ctx& c = *cur;
+    c.lin = t;
+    c.bdim = block;
+    c.gdim = grid;
+    c.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+    for (long long b = 0; b < B; ++b) {
+      c.bid = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long long)grid.x * grid.y)));
+      lane_op = 0;
+      tm.all.wait();  // everybody has left the previous workgroup (its LDS contents are dead)
+      if (t == 0) {
+        tm.block.reset(T);
+        for (int w = 0; w < tm.waves; ++w) tm.wave[w]->reset(std::min(64, T - 64 * w));
+      }
+      tm.all.wait();
+      kern(args...);
+      tm.block.drop();  // a work-item that returns stops counting towards every later rendezvous
+      tm.wave[t / 64]->drop();
+    }
+  };
+  std::vector<std::thread> th;
+  th.reserve(T);
+  for (int t = 0; t < T; ++t) th.emplace_back(body, t);
+  for (auto& x : th) x.join();
+}
+
+#else
 enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 
 struct Worker {
@@ -128,10 +231,10 @@ inline void sync_block() {
   w->wait_phase[i] = w->block_phase;
   if (++w->block_arrived >= w->live) {
     release_block(w);
-    return;
+  } else {
+    w->state[i] = WAIT_BLOCK;
+    yield_to_scheduler();
   }
-  w->state[i] = WAIT_BLOCK;
-  yield_to_scheduler();
 }
 inline void sync_wave() {
   Worker* w = worker;
@@ -139,10 +242,10 @@ inline void sync_wave() {
   w->wait_phase[i] = w->wave_phase[wv];
   if (++w->wave_arrived[wv] >= w->wave_live[wv]) {
     release_wave(w, wv);
-    return;
+  } else {
+    w->state[i] = WAIT_WAVE;
+    yield_to_scheduler();
   }
-  w->state[i] = WAIT_WAVE;
-  yield_to_scheduler();
 }
 inline void fiber_main() {
   Worker* w = worker;
@@ -223,6 +326,14 @@ void run_grid(K kern, dim3 grid, dim3 block, A... args) {
   for (auto& x : th) x.join();
 }
 
+inline int lin() { return worker->cur; }
+inline unsigned next_wave_op() { return worker->lane_ops[worker->cur]++; }
+inline uint64_t* shfl_buf(int wv, unsigned op) { return worker->slots.data() + ((size_t)(op & 1) * worker->waves + wv) * 64; }
+inline float* mfma_buf_a(int wv, unsigned op) { return worker->mfma_a.data() + ((size_t)(op & 1) * worker->waves + wv) * 512; }
+inline float* mfma_buf_b(int wv, unsigned op) { return worker->mfma_b.data() + ((size_t)(op & 1) * worker->waves + wv) * 512; }
+
+#endif  // VP_EMU_TSAN
+
 template <class K, class... A>
 void launch(K kern, dim3 grid, dim3 block, size_t /*dynamic LDS: thread_local storage in harness.cpp*/, A... args) {
   if (capturing) {  // as on the device: work issued into a capturing stream is recorded, not executed
@@ -235,9 +346,8 @@ void launch(K kern, dim3 grid, dim3 block, size_t /*dynamic LDS: thread_local st
 template <class V>
 V shfl_xor(V v, int mask) {
   static_assert(sizeof(V) <= 8, "shuffle payload");
-  Worker* w = worker;
-  const int i = w->cur, wv = i / 64, lane = i % 64;
-  uint64_t* buf = w->slots.data() + ((size_t)(w->lane_ops[i]++ & 1) * w->waves + wv) * 64;
+  const int i = lin(), wv = i / 64, lane = i % 64;
+  uint64_t* buf = shfl_buf(wv, next_wave_op());  // double-buffered: one rendezvous per operation is enough
   uint64_t bits = 0;
   std::memcpy(&bits, &v, sizeof(V));
   buf[lane] = bits;
@@ -255,11 +365,10 @@ V shfl_xor(V v, int mask) {
 // defined -- summed here in fp32 in k order (the kernel tests carry a tolerance for that, as the GPU ones do).
 template <class H8, class F16>
 F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
-  Worker* w = worker;
-  const int i = w->cur, wv = i / 64, lane = i % 64;
-  const size_t base = ((size_t)(w->lane_ops[i]++ & 1) * w->waves + wv) * 512;
-  float* A = w->mfma_a.data() + base;
-  float* B = w->mfma_b.data() + base;
+  const int i = lin(), wv = i / 64, lane = i % 64;
+  const unsigned op = next_wave_op();
+  float* A = mfma_buf_a(wv, op);
+  float* B = mfma_buf_b(wv, op);
   for (int e = 0; e < 8; ++e) {
     A[lane * 8 + e] = (float)a[e];
     B[lane * 8 + e] = (float)b[e];
