@@ -32,6 +32,8 @@ struct DwParams {
   // (integer atomics are associative -> bit-deterministic regardless of workgroup order); zeroed once per frame
   unsigned long long* sums;  // [replicas][C]
   int replicas;              // power of two <= kSeMaxReplicas: workgroup x-index & (replicas-1) picks the row
+  // batched encoder (frames > 1): grid.z = frame; tensors are [frames][H][W][C], sums [frames][replicas][C]
+  int frames;
 };
 
 struct PoolParams {
@@ -52,6 +54,7 @@ struct SeParams {
   const float* b2;  // [C]
   float* scale;     // [C]   (single-workgroup variant only)
   float* s1;        // [sq]  output of the squeeze FC (multi-workgroup variant)
+  int frames;       // batched encoder: grid.y = frame; sums [frames][replicas][C], s1 [frames][sq]
 };
 
 struct ScaleWParams {
@@ -65,6 +68,7 @@ struct ScaleWParams {
   const float* w2;  // [C][sq]
   const float* b2;  // [C]
   int sq, Creal;
+  int frames;       // batched encoder: grid.y = frame; s1 [frames][sq], out_hi / out_lo [frames][rows][C]
 };
 
 struct FcParams {

@@ -70,8 +70,18 @@ static int dw_octets_per_group(int CG) {
   return 1;
 }
 
-template <int K, bool SPLIT>
-__global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams p, const int G) {
+// BATCH (batched encoder): grid.z = camera frame; the same code on that frame's slice of [frames][H][W][C] tensors.
+template <int K, bool SPLIT, bool BATCH = false>
+__global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams pin, const int G) {
+  DwParams p = pin;
+  if constexpr (BATCH) {
+    const size_t f = blockIdx.z, in_fs = (size_t)p.in.H * p.in.W * p.in.C, out_fs = (size_t)p.out.H * p.out.W * p.out.C;
+    p.in.hi += f * in_fs;
+    if constexpr (SPLIT) p.in.lo += f * in_fs;
+    p.out.hi += f * out_fs;
+    if constexpr (SPLIT) p.out.lo += f * out_fs;
+    p.sums += f * (size_t)p.replicas * p.in.C;
+  }
   extern __shared__ unsigned char dw_smem[];
   const int GC = G * 8;                                            // channels of this workgroup
   float* wl = reinterpret_cast<float*>(dw_smem);                   // [K*K][GC]
@@ -187,7 +197,13 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
 // ------------------------------------------------------------------------------------- squeeze-excite FCs
 // Squeeze FC: the workgroup rebuilds the channel means from the slab partials into LDS once, then one wave per
 // squeeze unit does a 16-byte-wide dot product (all loads of a row in flight).
-__global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams pin) {
+  SeParams p = pin;
+  if constexpr (BATCH) {  // grid.y = camera frame
+    p.sums += (size_t)blockIdx.y * p.replicas * p.C;
+    p.s1 += (size_t)blockIdx.y * p.sq;
+  }
   extern __shared__ __attribute__((aligned(16))) float mean[];
   for (int c = threadIdx.x; c < p.C; c += 256) {
     float s = 0.f;
@@ -224,7 +240,14 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams p) {
 // the K axis of the following 1x1 projection (W'[n][k] = W[n][k] * gate[k]) and the activation tensor is never
 // re-written.  A workgroup owns 32 input channels: computes their sigmoid gates once, then scales that 32-wide
 // column slice of every weight row.
-__global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams p) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams pin) {
+  ScaleWParams p = pin;
+  if constexpr (BATCH) {  // grid.y = camera frame: its own gate, its own copy of the scaled projection weights
+    p.s1 += (size_t)blockIdx.y * p.sq;
+    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
+    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
+  }
   __shared__ float gate[32];
   __shared__ float part[8][32];
   const int c0 = blockIdx.x * 32;
@@ -319,6 +342,14 @@ hipError_t launch_dwconv(const DwParams& p, hipStream_t st) {
   const size_t lds = (size_t)p.k * p.k * G * 8 * sizeof(float) + (size_t)G * 8 * sizeof(unsigned long long);
   const bool split = p.in.lo != nullptr;
   if (split != (p.out.lo != nullptr)) return hipErrorInvalidValue;
+  if (p.frames > 1) {
+    const dim3 gridb(grid.x, grid.y, p.frames);
+    if (p.k == 3 && !split) VP_LAUNCH((dwconv_pool_kernel<3, false, true>), gridb, dim3(256), lds, st, p, G);
+    if (p.k == 5 && !split) VP_LAUNCH((dwconv_pool_kernel<5, false, true>), gridb, dim3(256), lds, st, p, G);
+    if (p.k == 3) VP_LAUNCH((dwconv_pool_kernel<3, true, true>), gridb, dim3(256), lds, st, p, G);
+    if (p.k == 5) VP_LAUNCH((dwconv_pool_kernel<5, true, true>), gridb, dim3(256), lds, st, p, G);
+    return hipErrorInvalidValue;
+  }
   if (p.k == 3 && !split) VP_LAUNCH((dwconv_pool_kernel<3, false>), grid, dim3(256), lds, st, p, G);
   if (p.k == 5 && !split) VP_LAUNCH((dwconv_pool_kernel<5, false>), grid, dim3(256), lds, st, p, G);
   if (p.k == 3) VP_LAUNCH((dwconv_pool_kernel<3, true>), grid, dim3(256), lds, st, p, G);
@@ -330,10 +361,15 @@ hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
   VP_LAUNCH(pool_partial_kernel, dim3(p.nslab, (CG + CGL - 1) / CGL), dim3(256), 0, st, p);
 }
 hipError_t launch_se_fc1(const SeParams& p, hipStream_t st) {
-  VP_LAUNCH(se_fc1_kernel, dim3((p.sq + 3) / 4), dim3(256), p.C * sizeof(float), st, p);
+  if (p.frames > 1) {
+    if (!p.sums) return hipErrorInvalidValue;
+    VP_LAUNCH(se_fc1_kernel<true>, dim3((p.sq + 3) / 4, p.frames), dim3(256), p.C * sizeof(float), st, p);
+  }
+  VP_LAUNCH(se_fc1_kernel<false>, dim3((p.sq + 3) / 4), dim3(256), p.C * sizeof(float), st, p);
 }
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st) {
-  VP_LAUNCH(se_scale_weights_kernel, dim3(p.C / 32), dim3(256), 0, st, p);
+  if (p.frames > 1) VP_LAUNCH(se_scale_weights_kernel<true>, dim3(p.C / 32, p.frames), dim3(256), 0, st, p);
+  VP_LAUNCH(se_scale_weights_kernel<false>, dim3(p.C / 32), dim3(256), 0, st, p);
 }
 hipError_t launch_fc(const FcParams& p, hipStream_t st) {
   VP_LAUNCH(fc_kernel, dim3((p.N + 7) / 8), dim3(256), p.K * sizeof(float), st, p);

@@ -49,6 +49,21 @@ int emu_dwconv(void* in_hi, void* in_lo, int H, int W, int C, void* out_hi, void
   DwParams p{view(in_hi, in_lo, H, W, C), view(out_hi, out_lo, OH, OW, C), w, b, k, stride, sums, replicas};
   return launch_dwconv(p, nullptr);
 }
+int emu_dwconv_batched(void* in_hi, void* in_lo, int H, int W, int C, void* out_hi, void* out_lo, int OH, int OW, const float* w, const float* b, int k,
+                       int stride, unsigned long long* sums, int replicas, int frames) {
+  DwParams p{view(in_hi, in_lo, H, W, C), view(out_hi, out_lo, OH, OW, C), w, b, k, stride, sums, replicas, frames};
+  return launch_dwconv(p, nullptr);
+}
+int emu_se_batched(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1, float* s1,
+                   const float* w, void* out_hi, void* out_lo, int rows, const float* w2, const float* b2, int frames) {
+  SeParams p{};
+  p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.s1 = s1; p.frames = frames;
+  if (launch_se_fc1(p, nullptr)) return 1;
+  ScaleWParams q{};
+  q.w = w; q.out_hi = static_cast<half_t*>(out_hi); q.out_lo = static_cast<half_t*>(out_lo); q.rows = rows; q.C = C; q.s1 = s1; q.w2 = w2; q.b2 = b2;
+  q.sq = sq; q.Creal = Creal; q.frames = frames;
+  return launch_se_scale_weights(q, nullptr);
+}
 int emu_se_fc1(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1, float* s1) {
   SeParams p{};
   p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.s1 = s1;

@@ -352,3 +352,42 @@ def test_autodrive_glue_kernels(emu):
     want = (F.conv2d(xin, torch.from_numpy(wt), torch.from_numpy(b), padding=1, groups=C)[0].numpy()
             + (ah.astype(np.float32) + al.astype(np.float32)).transpose(2, 0, 1))
     assert _rel((oh.astype(np.float32) + ol.astype(np.float32)).transpose(2, 0, 1), want) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ batched encoder kernels
+@pytest.mark.parametrize("split", [True, False])
+def test_batched_depthwise_and_se_kernels_equal_per_frame_launches(emu, split):
+    """Batched encoder (grid.z / grid.y = camera frame): the BATCH instantiations of the depthwise + pool kernel and of the
+    two squeeze-excite kernels must produce, per frame, exactly what the single-frame launches produce."""
+    rng = np.random.default_rng(29)
+    frames, C, k, stride, H, W, replicas, sq, rows = 3, 56, 5, 2, 9, 13, 8, 6, 40
+    OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+    xh, xl = split16(rng.standard_normal((frames, H, W, C)).astype(np.float32))
+    wk = (rng.standard_normal((k * k, C)) * 0.3).astype(np.float32)
+    b = (rng.standard_normal(C) * 0.1).astype(np.float32)
+    w1, b1 = (rng.standard_normal((sq, C)) * 0.2).astype(np.float32), (rng.standard_normal(sq) * 0.1).astype(np.float32)
+    w2, b2 = (rng.standard_normal((C, sq)) * 0.5).astype(np.float32), (rng.standard_normal(C) * 0.2).astype(np.float32)
+    pw = rng.standard_normal((rows, C)).astype(np.float32)
+    lo_or_none = (lambda a: ptr(a)) if split else (lambda a: None)
+
+    oh, ol = np.zeros((frames, OH, OW, C), np.float16), np.zeros((frames, OH, OW, C), np.float16)
+    sums = np.zeros((frames, replicas, C), np.uint64)
+    assert emu.emu_dwconv_batched(ptr(xh), lo_or_none(xl), H, W, C, ptr(oh), lo_or_none(ol), OH, OW, ptr(wk), ptr(b), k, stride, ptr(sums), replicas, frames) == 0
+    s1 = np.zeros((frames, sq), np.float32)
+    ph, pl = np.zeros((frames, rows, C), np.float16), np.zeros((frames, rows, C), np.float16)
+    emu.emu_se_batched.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 6 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
+    assert emu.emu_se_batched(ptr(sums), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(s1), ptr(pw), ptr(ph), lo_or_none(pl), rows, ptr(w2), ptr(b2), frames) == 0
+
+    emu.emu_se_fc1.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    for f in range(frames):
+        o1, o2 = np.zeros((OH, OW, C), np.float16), np.zeros((OH, OW, C), np.float16)
+        sm = np.zeros((replicas, C), np.uint64)
+        fx, fl = np.ascontiguousarray(xh[f]), np.ascontiguousarray(xl[f])
+        assert emu.emu_dwconv(ptr(fx), lo_or_none(fl), H, W, C, ptr(o1), lo_or_none(o2), OH, OW, ptr(wk), ptr(b), k, stride, ptr(sm), replicas) == 0
+        assert np.array_equal(oh[f], o1) and np.array_equal(ol[f], o2) and np.array_equal(sums[f], sm), f
+        t1 = np.zeros(sq, np.float32)
+        assert emu.emu_se_fc1(ptr(sm), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(t1)) == 0
+        q1, q2 = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
+        assert emu.emu_se_scale_weights(ptr(pw), ptr(q1), lo_or_none(q2), rows, C, ptr(t1), ptr(w2), ptr(b2), sq, C) == 0
+        assert np.array_equal(s1[f], t1) and np.array_equal(ph[f], q1) and np.array_equal(pl[f], q2), f
+    assert len({sums[f].tobytes() for f in range(frames)}) == frames            # the frames really differ
