@@ -114,8 +114,12 @@ void split_half(float v, half_t* hi, half_t* lo) {
 }  // namespace
 
 // ==================================================================================================== Engine
-Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base)
-    : kind_(kind), precision_(precision), gpu_(gpu_id), base_(base) {
+Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base, int frames, int frame_index)
+    : kind_(kind), precision_(precision), gpu_(gpu_id), frames_(frames), frame_index_(frame_index), base_(base) {
+  if (frames < 1 || frames > 16) throw std::invalid_argument("frames must be 1..16");
+  if (frames > 1 && (base || kind < 0 || kind > 3)) throw std::invalid_argument("a batched encoder is a base engine of a scene network kind");
+  if (base && (frame_index < 0 || frame_index >= base->frames_)) throw std::invalid_argument("frame_index out of the base engine's range");
+  if (!base && frame_index != 0) throw std::invalid_argument("frame_index needs a batched base engine");
   if ((precision & 15) > 1 || (precision & ~17) != 0) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3 (optionally | VP_WEIGHTS_FP8)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -214,6 +218,19 @@ T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
   VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return d;
+}
+
+Act* Engine::frame_view(const Act* a, int f) {
+  if (a->frames <= 1) return const_cast<Act*>(a);
+  auto v = std::make_unique<Act>(*a);
+  v->frames = 1;
+  v->H = a->H / a->frames;
+  v->name = a->name + "#" + std::to_string(f);
+  const size_t off = (size_t)f * v->H * v->W * v->C;
+  v->hi = a->hi + off;
+  if (a->lo) v->lo = a->lo + off;
+  acts_.push_back(std::move(v));
+  return acts_.back().get();
 }
 
 Act* Engine::new_act(const std::string& name, int creal, int h, int w) {
@@ -602,7 +619,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
   std::vector<Act*> stage_out;
   // ---- squeeze-excite pool accumulators of all 16 MBConv blocks: one arena, one memset node per frame
   constexpr int kSeBlocks = 16;
-  const size_t se_words = (size_t)kSeBlocks * 1536 * 8 + (size_t)6 * 256 * kSeMaxReplicas;  // >= sum of replicas*C below (checked)
+  const int N = frames_;  // batched encoder: activations are N frames stacked along H, one launch covers all of them where it can
+  const size_t se_words = (size_t)N * ((size_t)kSeBlocks * 1536 * 8 + (size_t)6 * 256 * kSeMaxReplicas);  // >= sum of N*replicas*C below (checked)
   unsigned long long* se_arena = static_cast<unsigned long long*>(dalloc(se_words * sizeof(unsigned long long)));
   int se_block = 0;
   size_t se_used = 0;
@@ -611,7 +629,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
     op.name = "se_pool_zero";
     op.kernel = "zero_u64";
     op.bytes = 8.0 * se_words;
-    op.run = [se_arena](hipStream_t st) { return launch_zero_u64(se_arena, se_words, st); };
+    op.run = [se_arena, se_words](hipStream_t st) { return launch_zero_u64(se_arena, se_words, st); };
     ops_.push_back(std::move(op));
   }
   // ---- features[0]: stem
@@ -622,19 +640,22 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
     for (int co = 0; co < 32; ++co)
       for (int k = 0; k < 27; ++k) wk[k * 32 + co] = f.w[co * 27 + k];
     StemParams sp{};
-    sp.in = d_input_;
     sp.H = net_h();
     sp.W = net_w();
     sp.w = dupload(wk);
     sp.b = dupload(f.b);
-    x = new_act(P + "0", 32, net_h() / 2, net_w() / 2);
-    sp.out = x->view();
-    Op op;
-    op.name = P + "0";
-    op.flops = 2.0 * 27 * 32 * x->H * x->W;
-    op.bytes = 4.0 * 3 * net_h() * net_w() + 2.0 * x->elems();
-    op.run = [sp](hipStream_t st) { return launch_stem(sp, st); };
-    ops_.push_back(std::move(op));
+    x = new_act(P + "0", 32, N * (net_h() / 2), net_w() / 2);
+    x->frames = N;
+    for (int fi = 0; fi < N; ++fi) {
+      sp.in = d_input_ + (size_t)fi * 3 * net_h() * net_w();
+      sp.out = frame_view(x, fi)->view();
+      Op op;
+      op.name = P + "0";
+      op.flops = 2.0 * 27 * 32 * (x->H / N) * x->W;
+      op.bytes = 4.0 * 3 * net_h() * net_w() + 2.0 * x->elems() / N;
+      op.run = [sp](hipStream_t st) { return launch_stem(sp, st); };
+      ops_.push_back(std::move(op));
+    }
   }
   stage_out.push_back(x);
   for (int si = 0; si < 7; ++si) {
@@ -648,19 +669,22 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         ConvOpts o;
         o.act = ACT_SILU;
-        y = add_conv(bp + std::to_string(j), x, f.w, f.b, cexp, 1, o);
+        Act* ye = add_conv(bp + std::to_string(j), x, f.w, f.b, cexp, 1, o);  // 1x1: M = N*H*W pixels in one launch
+        ye->frames = N;
+        y = ye;
         ++j;
       }
       // depthwise (+ fused squeeze-excite average pool: int64 fixed-point channel sums, zeroed once per frame)
-      Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);
+      Act* z = new_act(bp + std::to_string(j), cexp, y->H / stride, y->W / stride);  // y->H = N * per-frame height, all even
+      z->frames = N;
       const int sq = std::max(1, cin / 4);
-      const int HWz = z->H * z->W;
+      const int HWz = z->H / N * z->W;  // per frame
       // replica rows for the pool atomics (a workgroup covers >= 32 pixels of one channel group): ~4 per row, 8..64 rows
       int se_rep = 8;
       while (se_rep < kSeMaxReplicas && se_rep * 4 * 32 <= HWz) se_rep *= 2;
-      if (se_used + (size_t)se_rep * z->C > se_words) throw std::runtime_error("SE arena too small");
-      unsigned long long* sums = se_arena + se_used;
-      se_used += (size_t)se_rep * z->C;
+      if (se_used + (size_t)N * se_rep * z->C > se_words) throw std::runtime_error("SE arena too small");
+      unsigned long long* sums = se_arena + se_used;  // [N][se_rep][C]
+      se_used += (size_t)N * se_rep * z->C;
       ++se_block;
       {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
@@ -671,8 +695,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           bk[c] = f.b[c];
         }
         DwParams dp{};
-        dp.in = y->view();
-        dp.out = z->view();
+        dp.in = ActView{y->hi, y->lo, y->H / N, y->W, y->C};   // per-frame geometry; the kernel's grid.z walks the frames
+        dp.out = ActView{z->hi, z->lo, z->H / N, z->W, z->C};
+        dp.frames = N;
         dp.w = dupload(wk);
         dp.b = dupload(bk);
         dp.k = S.k;
@@ -684,12 +709,13 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         op.flops = 2.0 * kk * cexp * z->H * z->W;
         op.bytes = (split() ? 4.0 : 2.0) * (y->elems() + z->elems());
         op.kernel = S.k == 3 ? "dwconv_pool<3>" : "dwconv_pool<5>";
+        if (N > 1) op.kernel += ",batch";
         op.run = [dp](hipStream_t st) { return launch_dwconv(dp, st); };
         ops_.push_back(std::move(op));
         ++j;
       }
       // squeeze-excite -> per-frame scaled projection weights
-      float* s1 = static_cast<float*>(dalloc(sq * sizeof(float)));
+      float* s1 = static_cast<float*>(dalloc((size_t)N * sq * sizeof(float)));  // [N][sq]
       SeParams se{};
       {
         const std::string sp = bp + std::to_string(j);
@@ -719,6 +745,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         se.b2 = dupload(b2p);
         se.scale = nullptr;
         se.s1 = s1;
+        se.frames = N;
         Op op2;
         op2.name = sp + ".fc";
         op2.flops = 2.0 * sq * cexp;
@@ -737,7 +764,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           o.res = x;
         }
         PackedConv pc;
-        choose_conv_cfg(HWz, ncols, z->C, 1, o, &pc);
+        choose_conv_cfg(HWz, ncols, z->C, 1, o, &pc);  // per frame: every frame has its own gate, hence its own scaled weights
         std::vector<float> wf((size_t)pc.CoutW * z->C, 0.0f), bias(pc.CoutW, 0.0f);
         for (int co = 0; co < S.cout; ++co) {
           for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c];
@@ -753,18 +780,24 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         sw.b2 = se.b2;
         sw.sq = sq;
         sw.Creal = cexp;
-        sw.out_hi = static_cast<half_t*>(dalloc(wf.size() * sizeof(half_t)));
-        sw.out_lo = split() ? static_cast<half_t*>(dalloc(wf.size() * sizeof(half_t))) : nullptr;
+        sw.out_hi = static_cast<half_t*>(dalloc((size_t)N * wf.size() * sizeof(half_t)));  // [N][CoutW][C]
+        sw.out_lo = split() ? static_cast<half_t*>(dalloc((size_t)N * wf.size() * sizeof(half_t))) : nullptr;
+        sw.frames = N;
         Op op;
         op.name = bp + std::to_string(j) + ".se_scale_w";
-        op.bytes = 6.0 * wf.size();
+        op.bytes = 6.0 * wf.size() * N;
         op.run = [sw](hipStream_t st) { return launch_se_scale_weights(sw, st); };
         ops_.push_back(std::move(op));
-        pc.w_hi = sw.out_hi;
-        pc.w_lo = sw.out_lo;
         pc.bias = dupload(bias);
         Act* out = new_act(bp + std::to_string(j), S.cout, z->H, z->W);
-        push_conv_op(bp + std::to_string(j), z, pc, 1, ncols, o, out, STORE_NHWC, S.cout);
+        out->frames = N;
+        for (int fi = 0; fi < N; ++fi) {
+          pc.w_hi = sw.out_hi + (size_t)fi * wf.size();
+          pc.w_lo = sw.out_lo ? sw.out_lo + (size_t)fi * wf.size() : nullptr;
+          ConvOpts of = o;
+          if (residual) of.res = frame_view(x, fi);
+          push_conv_op(bp + std::to_string(j), frame_view(z, fi), pc, 1, ncols, of, frame_view(out, fi), STORE_NHWC, S.cout);
+        }
         x = out;
       }
     }
@@ -774,7 +807,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
     Folded f = fold_conv_bn(blob, P + "8");
     ConvOpts o;
     o.act = ACT_SILU;
-    stage_out.push_back(add_conv(P + "8", x, f.w, f.b, 1280, 1, o));
+    Act* last = add_conv(P + "8", x, f.w, f.b, 1280, 1, o);
+    last->frames = N;
+    stage_out.push_back(last);
   }
   // taps l0, l2, l3, l4, l8 (backbone.py:22)
   return {stage_out[0], stage_out[2], stage_out[3], stage_out[4], stage_out[8]};
@@ -942,17 +977,17 @@ void Engine::build_model(const WeightBlob& blob) {
     // and neck.  EgoLanes fuses all five taps before its context (ego_lanes_network.py:30-36): backbone only.
     if (hash_bb_ != base_->hash_bb_) throw std::invalid_argument("shared engine: backbone parameters differ from the base engine's");
     shared_level_ = 1;
-    if (kind_ != 3 && base_->kind_ != 3 && hash_ctx_ == base_->hash_ctx_ && hash_neck_ == base_->hash_neck_) shared_level_ = 2;
+    if (base_->frames_ == 1 && kind_ != 3 && base_->kind_ != 3 && hash_ctx_ == base_->hash_ctx_ && hash_neck_ == base_->hash_neck_) shared_level_ = 2;
   }
   if (!base_) {
-  d_input_ = static_cast<float*>(dalloc((size_t)3 * net_h() * net_w() * sizeof(float)));
-  // op 0: preprocess (parameters are patched per frame geometry in ensure_tables)
-  {
+  d_input_ = static_cast<float*>(dalloc((size_t)frames_ * 3 * net_h() * net_w() * sizeof(float)));
+  // op 0 (.. frames-1): preprocess (parameters are patched per frame geometry in ensure_tables)
+  for (int fi = 0; fi < frames_; ++fi) {
     Op op;
     op.name = "preprocess";
-    op.run = [this](hipStream_t st) {
+    op.run = [this, fi](hipStream_t st) {
       PreprocessParams pp{};
-      pp.frame = d_frame_;
+      pp.frame = d_frame_ + (size_t)fi * frame_h_ * frame_stride_;
       pp.stride = frame_stride_;
       pp.xtab = d_xtab_;
       pp.ytab = d_ytab_;
@@ -966,15 +1001,18 @@ void Engine::build_model(const WeightBlob& blob) {
         pp.mean[c] = mean_rgb[colour];
         pp.stdv[c] = std_rgb[colour];
       }
-      pp.out = d_input_;
+      pp.out = d_input_ + (size_t)fi * 3 * net_h() * net_w();
       return launch_preprocess(pp, st);
     };
     ops_.push_back(std::move(op));
-    first_net_op_ = 1;
+    first_net_op_ = (size_t)frames_;
   }
   }  // !base_
   std::vector<Act*> feats = base_ ? base_->feats_ : build_backbone(blob, pf.bb);
+  if (base_ && base_->frames_ > 1)
+    for (Act*& t : feats) t = frame_view(t, frame_index_);
   feats_ = feats;
+  if (frames_ > 1) return;  // batched encoder: taps only
   const int cctx = kind_ == 3 ? 1456 : 1280;
   const Act* deep = feats[4];
   if (kind_ == 3) {  // backbone_feature_fusion.py:13-38
@@ -1361,15 +1399,18 @@ void Engine::ensure_tables(int h, int w) {
   tab_w_ = w;
 }
 
-void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride) {
+void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int index) {
   if (base_) throw std::invalid_argument("shared engine: frames go to the base engine (vp_infer on the base, then vp_infer_shared)");
   if (!frame || h < 2 || w < 2 || stride < 3 * w) throw std::invalid_argument("bad frame geometry");
+  if (index < 0 || index >= frames_) throw std::invalid_argument("frame index out of range");
   VP_HIP_CHECK(hipSetDevice(gpu_));
   const size_t need = (size_t)h * stride;
-  if (need > frame_cap_) {
+  if ((h != frame_h_ || w != frame_w_ || stride != frame_stride_) && frames_ > 1 && index != 0 && frame_h_ != 0)
+    throw std::invalid_argument("batched encoder: all frames of a pass share one geometry (upload slot 0 first to change it)");
+  if (need * frames_ > frame_cap_) {
     VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    d_frame_ = static_cast<uint8_t*>(dalloc(need, false));
-    frame_cap_ = need;
+    d_frame_ = static_cast<uint8_t*>(dalloc(need * frames_, true));
+    frame_cap_ = need * frames_;
     graph_valid_ = false;
   }
   if (h != frame_h_ || w != frame_w_ || stride != frame_stride_) graph_valid_ = false;
@@ -1377,13 +1418,14 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride) {
   frame_h_ = h;
   frame_w_ = w;
   frame_stride_ = stride;
-  VP_HIP_CHECK(hipMemcpyAsync(d_frame_, frame, need, hipMemcpyHostToDevice, stream_));
+  VP_HIP_CHECK(hipMemcpyAsync(d_frame_ + (size_t)index * need, frame, need, hipMemcpyHostToDevice, stream_));
   if (input_is_tensor_) graph_valid_ = false;
   input_is_tensor_ = false;
 }
 
 void Engine::upload_tensor(const float* nchw) {
   if (base_) throw std::invalid_argument("shared engine: tensors go to the base engine");
+  if (frames_ > 1) throw std::invalid_argument("batched encoder: frames only (vp_upload_frame_n)");
   if (!nchw) throw std::invalid_argument("null tensor");
   VP_HIP_CHECK(hipSetDevice(gpu_));
   VP_HIP_CHECK(hipMemcpyAsync(d_input_, nchw, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyHostToDevice, stream_));
@@ -1448,6 +1490,7 @@ void Engine::enqueue() {
 void Engine::sync() { VP_HIP_CHECK(hipStreamSynchronize(stream_)); }
 
 void Engine::fetch_outputs() {
+  if (!d_logits_) throw std::runtime_error("this engine has no outputs (batched encoder: fetch from its shared-prefix engines)");
   VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
   VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
   VP_HIP_CHECK(hipStreamSynchronize(stream_));

@@ -44,6 +44,7 @@ std::vector<char> onnx_to_blob(const std::string& path);
 struct Act {
   std::string name;
   int Creal = 0, C = 0, H = 0, W = 0;
+  int frames = 1;  // batched encoder: `frames` camera frames stacked along H (H = frames * per-frame height)
   half_t* hi = nullptr;
   half_t* lo = nullptr;
   ActView view() const { return ActView{hi, lo, H, W, C}; }
@@ -73,7 +74,9 @@ class Engine {
   // base != nullptr builds a SHARED-PREFIX engine (vp_create_shared): sub-networks whose parameters equal the base
   // engine's (backbone; backbone + context + neck) are not rebuilt -- this engine's plan starts from the base
   // engine's feature tensors and runs on the base engine's stream, after it, on the frame the base last processed.
-  Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base = nullptr);
+  // frames > 1 (base == nullptr): BATCHED ENCODER -- preprocess + EfficientNet backbone of `frames` camera frames per pass,
+  // no context / neck / head; its taps feed shared-prefix engines built with (base = this, frame_index = f).
+  Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base = nullptr, int frames = 1, int frame_index = 0);
   ~Engine();
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
@@ -88,7 +91,8 @@ class Engine {
   void prime_previous();
 
   // frame path
-  void upload_frame(const uint8_t* frame, int h, int w, int stride);
+  void upload_frame(const uint8_t* frame, int h, int w, int stride, int index = 0);  // index: slot of a batched encoder
+  int frames() const { return frames_; }
   void upload_tensor(const float* nchw);
   void enqueue();
   void sync();
@@ -160,7 +164,9 @@ class Engine {
   void ensure_tables(int h, int w);
   void capture_graph();
 
+  Act* frame_view(const Act* a, int f);  // per-frame window of a stacked activation (no allocation)
   int kind_, precision_, gpu_;
+  int frames_ = 1, frame_index_ = 0;
   hipStream_t stream_ = nullptr;
   Engine* base_ = nullptr;
   int shared_level_ = 0;

@@ -36,7 +36,7 @@ int guarded(vp_engine* e, F&& f) {
 }
 
 int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int precision, int gpu_id, char* err, size_t err_len,
-                vp::Engine* base = nullptr) {
+                vp::Engine* base = nullptr, int frames = 1, int frame_index = 0) {
   if (!out) return VP_ERR_ARG;
   *out = nullptr;
   try {
@@ -49,7 +49,7 @@ int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int p
     }
     auto h = std::make_unique<vp_engine>();
     try {
-      h->impl = std::make_unique<vp::Engine>(kind, &wb, precision, gpu_id, base);
+      h->impl = std::make_unique<vp::Engine>(kind, &wb, precision, gpu_id, base, frames, frame_index);
     } catch (const std::invalid_argument& ex) {
       set_err(err, err_len, ex.what());
       return VP_ERR_ARG;
@@ -143,6 +143,52 @@ int vp_create_shared(vp_engine** out, vp_engine* base, int model_kind, const cha
   std::vector<char> buf;
   if (const int rc = read_weights(weights_path, buf, err, err_len)) return rc;
   return vp_create_shared_from_memory(out, base, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
+}
+
+int vp_create_batched_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id, int frames,
+                                  char* err, size_t err_len) {
+  if (!blob) {
+    set_err(err, err_len, "null weight blob");
+    return VP_ERR_ARG;
+  }
+  return create_impl(out, model_kind, blob, blob_bytes, precision, gpu_id, err, err_len, nullptr, frames, 0);
+}
+
+int vp_create_batched(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, int frames, char* err,
+                      size_t err_len) {
+  if (!weights_path || !*weights_path) {
+    set_err(err, err_len, "No path to weight file provided");
+    return VP_ERR_ARG;
+  }
+  std::vector<char> buf;
+  if (const int rc = read_weights(weights_path, buf, err, err_len)) return rc;
+  return create_impl(out, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len, nullptr, frames, 0);
+}
+
+int vp_create_shared_frame_from_memory(vp_engine** out, vp_engine* base, int frame_index, int model_kind, const void* blob, size_t blob_bytes,
+                                       int precision, int gpu_id, char* err, size_t err_len) {
+  if (!blob || !base || !base->impl) {
+    set_err(err, err_len, !blob ? "null weight blob" : "null base engine");
+    return VP_ERR_ARG;
+  }
+  return create_impl(out, model_kind, blob, blob_bytes, precision, gpu_id, err, err_len, base->impl.get(), 1, frame_index);
+}
+
+int vp_create_shared_frame(vp_engine** out, vp_engine* base, int frame_index, int model_kind, const char* weights_path, int precision,
+                           int gpu_id, char* err, size_t err_len) {
+  if (!weights_path || !*weights_path) {
+    set_err(err, err_len, "No path to weight file provided");
+    return VP_ERR_ARG;
+  }
+  std::vector<char> buf;
+  if (const int rc = read_weights(weights_path, buf, err, err_len)) return rc;
+  return vp_create_shared_frame_from_memory(out, base, frame_index, model_kind, buf.data(), buf.size(), precision, gpu_id, err, err_len);
+}
+
+int vp_frames(const vp_engine* e) { return (e && e->impl) ? e->impl->frames() : -1; }
+
+int vp_upload_frame_n(vp_engine* e, int index, const uint8_t* frame, int h, int w, int stride_bytes) {
+  return guarded(e, [&](vp::Engine& g) { g.upload_frame(frame, h, w, stride_bytes, index); });
 }
 
 int vp_convert_onnx(const char* onnx_path, const char* vpw_path, char* err, size_t err_len) {

@@ -31,6 +31,12 @@ _SIGS = {
     "vp_create_from_memory": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "vp_create_shared": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "vp_create_shared_from_memory": (C.c_int, [C.POINTER(_P), _P, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_batched": (C.c_int, [C.POINTER(_P), C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_batched_from_memory": (C.c_int, [C.POINTER(_P), C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_shared_frame": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_create_shared_frame_from_memory": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, _P, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_frames": (C.c_int, [_P]),
+    "vp_upload_frame_n": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vp_shared_level": (C.c_int, [_P]),
     "vp_infer_shared": (C.c_int, [_P]),
     "vp_destroy": (None, [_P]),
@@ -111,9 +117,11 @@ def convert_onnx(onnx_path, vpw_path):
 class Engine:
     """Thin RAII wrapper over a vp_engine handle."""
 
-    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None, weights_fp8=False):
+    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None, weights_fp8=False, frames=1, frame_index=None):
         """base: another Engine -> shared-prefix engine (vp_create_shared): reuses the base engine's backbone (and
-        context + neck when their parameters are identical) on the frame the base last processed."""
+        context + neck when their parameters are identical) on the frame the base last processed.
+        frames > 1: batched encoder (vp_create_batched) -- preprocess + backbone of `frames` cameras per pass, no head;
+        heads are Engine(kind, weights, base=encoder, frame_index=f) (vp_create_shared_frame)."""
         lib = load()
         self._lib = lib
         self._h = C.c_void_p()
@@ -123,7 +131,17 @@ class Engine:
         if weights_fp8:
             pr |= VP_WEIGHTS_FP8
         self._base = base  # keeps the base engine alive as long as this one
-        if isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)):
+        path = None if isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)) else (os.fsencode(weights) if weights else b"")
+        if frames != 1 or frame_index is not None:
+            buf = None if path is not None else (np.frombuffer(weights, dtype=np.uint8) if not isinstance(weights, np.ndarray) else weights)
+            if base is None:
+                rc = (lib.vp_create_batched(C.byref(self._h), k, path, pr, gpu_id, frames, err, len(err)) if path is not None else
+                      lib.vp_create_batched_from_memory(C.byref(self._h), k, _ptr(buf), buf.nbytes, pr, gpu_id, frames, err, len(err)))
+            else:
+                fi = int(frame_index or 0)
+                rc = (lib.vp_create_shared_frame(C.byref(self._h), base._h, fi, k, path, pr, gpu_id, err, len(err)) if path is not None else
+                      lib.vp_create_shared_frame_from_memory(C.byref(self._h), base._h, fi, k, _ptr(buf), buf.nbytes, pr, gpu_id, err, len(err)))
+        elif isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)):
             buf = np.frombuffer(weights, dtype=np.uint8) if not isinstance(weights, np.ndarray) else weights
             if base is not None:
                 rc = lib.vp_create_shared_from_memory(C.byref(self._h), base._h, k, _ptr(buf), buf.nbytes, pr, gpu_id, err, len(err))
@@ -240,10 +258,19 @@ class Engine:
         return out
 
     # ---- device-resident path
-    def upload_frame(self, frame_u8):
+    def upload_frame(self, frame_u8, index=None):
+        """index: slot of a batched encoder (vp_upload_frame_n); None = the single-frame call."""
         f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
-        self._keep = f
-        self._ck(self._lib.vp_upload_frame(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
+        if index is None:
+            self._keep = f
+            self._ck(self._lib.vp_upload_frame(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
+        else:
+            self._keep_n = getattr(self, "_keep_n", {})
+            self._keep_n[index] = f
+            self._ck(self._lib.vp_upload_frame_n(self._h, int(index), _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
+
+    def frames(self):
+        return self._lib.vp_frames(self._h)
 
     def enqueue(self):
         self._ck(self._lib.vp_enqueue(self._h))

@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight per GPU (independent engines/HIP streams, round-robin): the latency-bound "
                          "encoder of frame n+1 overlaps the MFMA-bound decoder of frame n")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="EXPERIMENTAL, default off: cameras per batched-encoder pass (vp_create_batched + one shared-prefix head per "
+                         "camera); a step is then one pass = BATCH frames.  The reported default configuration is --batch 1")
     ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -127,14 +130,45 @@ def main():
     seed = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}[args.kind]
     sd = synthetic.make_state_dict(args.kind, seed)
     blob = vw.pack_state_dict(sd)
-    engines = [lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank) for _ in range(max(1, args.streams))]
-    eng = engines[0]
     frame = synthetic.synthetic_frame(fh, fw, 10 + rank)  # camera r
-    for e in engines:
-        e.upload_frame(frame)  # resident in HBM before the timed region
-        e.enqueue()            # first pass is eager (sets kernel attributes), second captures the graph
-        e.enqueue()
-        e.sync()
+    if args.batch > 1:
+        class Group:  # one batched encoder + one head per camera, all on the encoder's stream
+            def __init__(self):
+                self.enc = lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank, frames=args.batch)
+                self.heads = [lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank, base=self.enc, frame_index=f)
+                              for f in range(args.batch)]
+                for f in range(args.batch):
+                    self.enc.upload_frame(synthetic.synthetic_frame(fh, fw, 10 + rank + 100 * f), index=f)
+
+            def enqueue(self):
+                self.enc.enqueue()
+                for h in self.heads:
+                    h.enqueue()
+
+            def sync(self):
+                self.enc.sync()
+
+            def close(self):
+                for h in self.heads:
+                    h.close()
+                self.enc.close()
+
+        engines = [Group() for _ in range(max(1, args.streams))]
+        for e in engines:
+            e.enqueue()
+            e.enqueue()
+            e.sync()
+        eng = engines[0].heads[0]
+        if args.gather:
+            raise SystemExit("--gather is a --batch 1 option")
+    else:
+        engines = [lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank) for _ in range(max(1, args.streams))]
+        eng = engines[0]
+        for e in engines:
+            e.upload_frame(frame)  # resident in HBM before the timed region
+            e.enqueue()            # first pass is eager (sets kernel attributes), second captures the graph
+            e.enqueue()
+            e.sync()
 
     gather_buf = mask_t = None
     if args.gather and dist is not None:
@@ -172,14 +206,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    fps_total = world * args.steps / elapsed
+    fps_total = world * args.steps * args.batch / elapsed
 
     # ---- per-frame latency (sync per iteration, benchmark.py:17-47 protocol), rank-local
     lat = []
     for _ in range(args.latency_iters):
         t1 = time.perf_counter()
-        eng.enqueue()
-        eng.sync()
+        (engines[0] if args.batch > 1 else eng).enqueue()  # batch mode: one whole pass (encoder + BATCH heads)
+        (engines[0] if args.batch > 1 else eng).sync()
         lat.append((time.perf_counter() - t1) * 1e3)
     lat = np.array(lat)
 
@@ -247,7 +281,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "fp16x3(fp32-class)", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {args.kind} {fw}x{fh} batch=1, one camera per GPU, {args.precision}",
-                       "frames_per_step_per_gpu": 1, "net_input": "1x3x320x640", "gather": bool(args.gather),
+                       "frames_per_step_per_gpu": args.batch, "batched_encoder": args.batch > 1, "net_input": "1x3x320x640", "gather": bool(args.gather),
                        "frames_in_flight_per_gpu": len(engines)},
             "fps_per_gpu": round(fps_total / world, 2),
             "p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),

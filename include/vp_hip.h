@@ -102,6 +102,28 @@ int vp_create_shared_from_memory(vp_engine** out, vp_engine* base, int model_kin
 int vp_shared_level(const vp_engine* e);
 int vp_infer_shared(vp_engine* e);
 
+/* ---- batched encoder (multi-camera rigs, BASELINE configs[2]/[3]: several cameras per GPU) -----------------
+ * Every backend instance of the reference runs batch 1 (onnx_runtime_backend.cpp:59, tensorrt_backend.cpp:124), one
+ * instance per camera.  The EfficientNet encoder is ~100 latency-sized launches per frame; a batched encoder engine runs
+ * preprocess + encoder for `frames` cameras per pass (activations [frames][H][W][C]: 1x1 convolutions as one GEMM over all
+ * pixels, depthwise + squeeze-excite kernels with the frame on a grid axis, the SE-gated projections per frame) and owns no
+ * context / neck / head.  Each camera's head is a shared-prefix engine on its slot:
+ *     vp_create_batched(&enc, VP_SCENESEG, "SceneSeg.onnx", VP_FP16, gpu, 3, ...);
+ *     for f in 0..2: vp_create_shared_frame(&head[f], enc, f, VP_SCENESEG, "SceneSeg.onnx", VP_FP16, gpu, ...);
+ *     per pass: vp_upload_frame_n(enc, f, frame_f, h, w, stride) x3;  vp_enqueue(enc);  vp_infer_shared(head[f]) x3.
+ * All frames of a pass share one geometry.  Errors as for vp_create_shared; frames in 1..16.  Functionally validated on
+ * the CPU emulation (tests/emul); see DESIGN.md for its GPU status. */
+int vp_create_batched(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, int frames, char* err,
+                      size_t err_len);
+int vp_create_batched_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id,
+                                  int frames, char* err, size_t err_len);
+int vp_create_shared_frame(vp_engine** out, vp_engine* base, int frame_index, int model_kind, const char* weights_path, int precision,
+                           int gpu_id, char* err, size_t err_len);
+int vp_create_shared_frame_from_memory(vp_engine** out, vp_engine* base, int frame_index, int model_kind, const void* blob,
+                                       size_t blob_bytes, int precision, int gpu_id, char* err, size_t err_len);
+int vp_frames(const vp_engine* e);
+int vp_upload_frame_n(vp_engine* e, int index, const uint8_t* frame, int h, int w, int stride_bytes);
+
 /* ---- configuration ------------------------------------------------------------------------------------- */
 int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order);
 int vp_set_decode_mode(vp_engine* e, int decode_mode);

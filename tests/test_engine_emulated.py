@@ -78,3 +78,43 @@ def test_autodrive_from_onnx_path_fp8_fp16_on_cpu(emu_lib, tmp_path):
         assert np.abs(got - g["fp8_out"]).max() <= 3e-2, (got, g["fp8_out"])
     finally:
         eng.close()
+
+
+def test_batched_encoder_taps_on_cpu(emu_lib):
+    """Batched encoder (vp_create_batched, frames = 2): preprocess + EfficientNet backbone of two different camera frames in
+    one pass -- stacked 1x1 GEMMs, the BATCH depthwise / squeeze-excite kernels, per-frame SE-gated projections -- against the
+    oracle's backbone taps of each frame; then once more through graph replay with the frames swapped."""
+    import torch
+
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+    from oracle import nets, pre_post
+
+    sd = synthetic.make_state_dict("sceneseg", 0)
+    frames = [synthetic.synthetic_frame(360, 640, s) for s in (11, 12)]
+    tsd = nets.to_torch(sd)
+    want = []
+    for f in frames:
+        x = torch.from_numpy(pre_post.preprocess(f, input_is_bgr=True, planes_rgb=False))
+        want.append([t[0].numpy() for t in nets.backbone(tsd, "Backbone.encoder.", x)])
+    enc = emu_lib.Engine("sceneseg", vw.pack_state_dict(sd), precision="fp16x3", frames=2)
+    try:
+        assert enc.frames() == 2
+        taps = ("Backbone.encoder.0", "Backbone.encoder.2.1.block.3", "Backbone.encoder.3.1.block.3", "Backbone.encoder.4.2.block.3", "Backbone.encoder.8")
+        for order in ((0, 1), (1, 0)):                   # second pass: graph replay, frames swapped between the slots
+            for slot, fi in enumerate(order):
+                enc.upload_frame(frames[fi], index=slot)
+            enc.enqueue()
+            enc.sync()
+            names = [n for n, *_ in enc.tensors()]
+            for ti, name in enumerate(taps):
+                t = enc.tensor_read(names.index(name))  # C x (2 * H) x W: the two frames stacked along H
+                c, h2, w = t.shape
+                for slot, fi in enumerate(order):
+                    got, ref = t[:, slot * (h2 // 2):(slot + 1) * (h2 // 2)], want[fi][ti]
+                    assert got.shape == ref.shape, name
+                    err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+                    assert err <= 1e-3, f"{name} slot {slot} frame {fi}: {err:.2e}"
+        with pytest.raises(emu_lib.VpError, match="no outputs"):
+            enc._ck(enc._lib.vp_fetch_outputs(enc._h))
+    finally:
+        enc.close()
