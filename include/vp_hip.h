@@ -111,8 +111,8 @@ int vp_infer_shared(vp_engine* e);
  *     vp_create_batched(&enc, VP_SCENESEG, "SceneSeg.onnx", VP_FP16, gpu, 3, ...);
  *     for f in 0..2: vp_create_shared_frame(&head[f], enc, f, VP_SCENESEG, "SceneSeg.onnx", VP_FP16, gpu, ...);
  *     per pass: vp_upload_frame_n(enc, f, frame_f, h, w, stride) x3;  vp_enqueue(enc);  vp_infer_shared(head[f]) x3.
- * All frames of a pass share one geometry.  Errors as for vp_create_shared; frames in 1..16.  Functionally validated on
- * the CPU emulation (tests/emul); see DESIGN.md for its GPU status. */
+ * All frames of a pass share one geometry.  Errors as for vp_create_shared; frames in 1..16.  Bit-identical per
+ * camera to the single-frame engine (CPU emulation and MI355X); throughput not yet measured, see DESIGN.md. */
 int vp_create_batched(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, int frames, char* err,
                       size_t err_len);
 int vp_create_batched_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id,
