@@ -37,7 +37,7 @@ def build(force=False):
         text = text.replace('#include "../../include/vp_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "vp_hip.h"))
         with open(os.path.join(OUT, f.replace(".hip", ".cpp")), "w") as o:
             o.write(text)
-    flags = [CLANG, "-std=c++20", "-O1", "-fPIC", "-pthread", "-ffp-contract=off", "-Wno-everything", "-I", os.path.join(HERE, "shim"), "-I", OUT]
+    flags = [CLANG, "-std=c++20", "-O1", "-march=native", "-fPIC", "-pthread", "-ffp-contract=off", "-Wno-everything", "-I", os.path.join(HERE, "shim"), "-I", OUT]
 
     def cc(src):
         obj = os.path.join(OUT, os.path.basename(src).rsplit(".", 1)[0] + ".o")

@@ -13,6 +13,33 @@ alignas(16) VP_EMU_LDS float sh[40 << 10];
 
 using namespace vp;
 
+#ifndef VP_EMU_TSAN
+// Work-item context switch of the fiber core (System V x86-64): callee-saved registers + stack pointer.  ucontext's
+// swapcontext costs two sigprocmask system calls per switch; an emulated MFMA is 64 switches.
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch, .-emu_switch
+)");
+#endif
+
 static ActView view(void* hi, void* lo, int H, int W, int C) { return ActView{static_cast<half_t*>(hi), static_cast<half_t*>(lo), H, W, C}; }
 
 extern "C" {

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE: one whole network through the emulated engine (tests/emul) on the CPU, against the oracle.
     python tests/emul/run_network.py [sceneseg|scene3d|domainseg|egolanes] [fp16x3|fp16]
-Too slow for the suite (EgoLanes ~5 min, the 360-GFLOP scene networks 10-20 min on 8 cores); AutoDrive, which takes ~15 s,
-is tests/test_engine_emulated.py."""
+The 360-GFLOP scene networks take a few minutes on 8 cores; AutoDrive (~8 s) and EgoLanes (~1 min) are in
+tests/test_engine_emulated.py."""
 import sys, time, os, ctypes as ct, numpy as np, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE))); sys.path.insert(0, HERE)

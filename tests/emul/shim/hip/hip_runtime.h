@@ -8,7 +8,6 @@
 #include <math.h>
 #include <stdint.h>
 #include <sys/mman.h>
-#include <ucontext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -53,10 +52,13 @@ typedef void* hipStream_t;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated HIP error"; }
 
+// saves the callee-saved registers and stack pointer of the caller in *save_sp, continues on load_sp (harness.cpp)
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+
 namespace emu {
 
 // Execution model: a launch's workgroups are spread over a few OS worker threads; inside a workgroup every work-item is a
-// FIBER (ucontext) of that worker, run in lane order and switched only at synchronisation points (__syncthreads, wave
+// FIBER (own stack, hand-written x86-64 context switch: emu_switch in harness.cpp) of that worker, run in lane order and switched only at synchronisation points (__syncthreads, wave
 // shuffles, MFMA).  LDS (`__shared__` -> static thread_local) is therefore private to the workgroup a worker is running.
 // Deterministic, no kernel-level blocking; global-memory atomics between concurrently running workgroups are real atomics.
 struct Graph {  // "graphs": while a capture is open every launch / copy is recorded as a closure; hipGraphLaunch replays them
@@ -172,8 +174,8 @@ enum { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
 struct Worker {
   static constexpr size_t kStack = 256 << 10;
   int T = 0, waves = 0, cur = 0, live = 0;
-  std::vector<ucontext_t> fib;
-  ucontext_t sched;
+  std::vector<void*> fib;  // saved stack pointer of every suspended work-item
+  void* sched = nullptr;   // ... and of the scheduler
   std::vector<Ctx> ctx;
   std::vector<int> state;
   std::vector<unsigned> wait_phase;
@@ -183,6 +185,7 @@ struct Worker {
   std::vector<int> wave_arrived, wave_live;
   std::vector<uint64_t> slots;       // [2][waves][64] shuffle payloads, double-buffered
   std::vector<float> mfma_a, mfma_b; // [2][waves][64][8]
+  std::vector<float> mfma_d;         // [2][waves][32][32] product of the wave's A and B, computed once per MFMA
   std::vector<unsigned> lane_ops;    // wave operations executed so far by each work-item (selects the buffer)
   char* stacks = nullptr;
   std::function<void()> body;
@@ -204,6 +207,7 @@ struct Worker {
       slots.resize((size_t)2 * waves * 64);
       mfma_a.resize((size_t)2 * waves * 512);
       mfma_b.resize((size_t)2 * waves * 512);
+      mfma_d.resize((size_t)2 * waves * 1024);
     }
   }
   ~Worker() {
@@ -215,7 +219,7 @@ inline thread_local Ctx* cur = nullptr;
 
 inline void yield_to_scheduler() {
   Worker* w = worker;
-  swapcontext(&w->fib[w->cur], &w->sched);
+  emu_switch(&w->fib[w->cur], w->sched);
 }
 inline void release_block(Worker* w) {
   w->block_arrived = 0;
@@ -236,16 +240,21 @@ inline void sync_block() {
     yield_to_scheduler();
   }
 }
-inline void sync_wave() {
+template <class F>
+inline void sync_wave_then(F&& last_arriver_work) {  // the work runs once, after every lane has arrived, before any lane continues
   Worker* w = worker;
   const int i = w->cur, wv = i / 64;
   w->wait_phase[i] = w->wave_phase[wv];
   if (++w->wave_arrived[wv] >= w->wave_live[wv]) {
+    last_arriver_work();
     release_wave(w, wv);
   } else {
     w->state[i] = WAIT_WAVE;
     yield_to_scheduler();
   }
+}
+inline void sync_wave() {
+  sync_wave_then([] {});
 }
 inline void fiber_main() {
   Worker* w = worker;
@@ -256,7 +265,7 @@ inline void fiber_main() {
   --w->wave_live[wv];
   if (w->live > 0 && w->block_arrived >= w->live) release_block(w);
   if (w->wave_live[wv] > 0 && w->wave_arrived[wv] >= w->wave_live[wv]) release_wave(w, wv);
-  swapcontext(&w->fib[i], &w->sched);
+  emu_switch(&w->fib[i], w->sched);  // never resumed
 }
 
 inline void run_block(Worker* w, dim3 grid, dim3 block, long long b) {
@@ -279,11 +288,13 @@ inline void run_block(Worker* w, dim3 grid, dim3 block, long long b) {
     c.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
     w->state[t] = RUNNABLE;
     w->lane_ops[t] = 0;
-    getcontext(&w->fib[t]);
-    w->fib[t].uc_stack.ss_sp = w->stacks + Worker::kStack * t;
-    w->fib[t].uc_stack.ss_size = Worker::kStack;
-    w->fib[t].uc_link = nullptr;
-    makecontext(&w->fib[t], fiber_main, 0);
+    // fresh stack: [six callee-saved registers][entry point][fake return address]; emu_switch pops the registers and
+    // `ret`s into fiber_main with the stack pointer at 8 mod 16, as after a call
+    void** top = reinterpret_cast<void**>(w->stacks + Worker::kStack * (t + 1));
+    top[-1] = nullptr;
+    top[-2] = reinterpret_cast<void*>(&fiber_main);
+    for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
+    w->fib[t] = top - 8;
   }
   while (w->live > 0) {
     bool progressed = false;
@@ -295,7 +306,7 @@ inline void run_block(Worker* w, dim3 grid, dim3 block, long long b) {
       w->state[t] = RUNNABLE;
       w->cur = t;
       cur = &w->ctx[t];
-      swapcontext(&w->sched, &w->fib[t]);
+      emu_switch(&w->sched, w->fib[t]);
       progressed = true;
     }
     if (!progressed) {
@@ -331,6 +342,7 @@ inline unsigned next_wave_op() { return worker->lane_ops[worker->cur]++; }
 inline uint64_t* shfl_buf(int wv, unsigned op) { return worker->slots.data() + ((size_t)(op & 1) * worker->waves + wv) * 64; }
 inline float* mfma_buf_a(int wv, unsigned op) { return worker->mfma_a.data() + ((size_t)(op & 1) * worker->waves + wv) * 512; }
 inline float* mfma_buf_b(int wv, unsigned op) { return worker->mfma_b.data() + ((size_t)(op & 1) * worker->waves + wv) * 512; }
+inline float* mfma_buf_d(int wv, unsigned op) { return worker->mfma_d.data() + ((size_t)(op & 1) * worker->waves + wv) * 1024; }
 
 #endif  // VP_EMU_TSAN
 
@@ -362,7 +374,7 @@ V shfl_xor(V v, int mask) {
 //   A: lane l holds row m = l % 32, columns k = 8 * (l / 32) + 0..7;   B: lane l holds column n = l % 32, rows k = 8 * (l / 32) + 0..7;
 //   C / D: lane l holds column n = l % 32; element r (0..15) is row m = 8 * (r / 4) + 4 * (l / 32) + (r % 4).
 // Products of two fp16 values are exact in fp32; the accumulation order inside the instruction is not architecturally
-// defined -- summed here in fp32 in k order (the kernel tests carry a tolerance for that, as the GPU ones do).
+// defined -- here D = C + (sum over k, in k order, fp32) (the kernel tests carry a tolerance for that, as the GPU ones do).
 template <class H8, class F16>
 F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
   const int i = lin(), wv = i / 64, lane = i % 64;
@@ -373,14 +385,33 @@ F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
     A[lane * 8 + e] = (float)a[e];
     B[lane * 8 + e] = (float)b[e];
   }
-  sync_wave();
   const int n = lane % 32;
+#ifdef VP_EMU_TSAN
+  sync_wave();
   for (int r = 0; r < 16; ++r) {
     const int m = 8 * (r / 4) + 4 * (lane / 32) + (r % 4);
-    float acc = c[r];
+    float acc = 0.0f;
     for (int k = 0; k < 16; ++k) acc += A[(m + 32 * (k / 8)) * 8 + (k % 8)] * B[(n + 32 * (k / 8)) * 8 + (k % 8)];
-    c[r] = acc;
+    c[r] += acc;
   }
+#else
+  float* D = mfma_buf_d(wv, op);
+  sync_wave_then([=] {  // the last lane to arrive multiplies the whole 32x16 by 16x32 tile once (vectorisable row updates)
+    float Bt[16][32];
+    for (int k = 0; k < 16; ++k)
+      for (int nn = 0; nn < 32; ++nn) Bt[k][nn] = B[(nn + 32 * (k / 8)) * 8 + (k % 8)];
+    for (int m = 0; m < 32; ++m) {
+      float row[32];
+      for (int nn = 0; nn < 32; ++nn) row[nn] = 0.0f;
+      for (int k = 0; k < 16; ++k) {
+        const float av = A[(m + 32 * (k / 8)) * 8 + (k % 8)];
+        for (int nn = 0; nn < 32; ++nn) row[nn] += av * Bt[k][nn];
+      }
+      for (int nn = 0; nn < 32; ++nn) D[m * 32 + nn] = row[nn];
+    }
+  });
+  for (int r = 0; r < 16; ++r) c[r] += D[(8 * (r / 4) + 4 * (lane / 32) + (r % 4)) * 32 + n];
+#endif
   return c;
 }
 

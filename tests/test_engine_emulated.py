@@ -1,9 +1,8 @@
 """The whole engine on the CPU: csrc/ compiled for the host on the HIP-on-CPU shim (tests/emul), driven through the C ABI
 exactly as on the GPU -- weight blob, plan, every kernel incl. the MFMA convolutions (emulated wave-level MFMA), graph
-capture / replay as closure lists.  AutoDrive is the network small enough for the CPU suite (8 GFLOP, ~15 s emulated); it is
-also the one pinned end to end: tests/golden/autodrive.npz holds the outputs of the reference's OWN nn.Module
-(oracle/pin_autodrive.py), so this checks engine == reference without a GPU.  (The 360-GFLOP scene networks take ~10-20
-minutes emulated: run tests/emul/run_network.py by hand.)"""
+capture / replay as closure lists.  AutoDrive (8 GFLOP, ~8 s emulated) is pinned end to end: tests/golden/autodrive.npz holds the outputs of the reference's OWN nn.Module
+(oracle/pin_autodrive.py), so this checks engine == reference without a GPU.  EgoLanes (197 GFLOP, ~1 min) stands for the scene networks; the 360-GFLOP ones
+run by hand with tests/emul/run_network.py (a few minutes)."""
 import ctypes as ct
 import os
 import sys
@@ -118,3 +117,32 @@ def test_batched_encoder_taps_on_cpu(emu_lib):
             enc._ck(enc._lib.vp_fetch_outputs(enc._h))
     finally:
         enc.close()
+
+
+def test_egolanes_network_end_to_end_on_cpu(emu_lib):
+    """A whole scene network through the production plan on the CPU (about a minute emulated): preprocess, EfficientNet encoder,
+    five-tap feature fusion, context, neck with the fused ConvTranspose + skip GEMMs, head, decode -- EgoLanes is the smallest
+    (197 GFLOP).  Same bar as the GPU parity test: input tensor bit-exact, logits within 1e-3, lane-priority mask identical
+    outside the float tolerance band."""
+    import torch
+
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+    from oracle import nets, pre_post
+
+    sd = synthetic.make_state_dict("egolanes", 2)
+    frame = synthetic.synthetic_frame(720, 1280, 9)
+    x = pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=False)
+    ref = nets.forward("egolanes", nets.to_torch(sd), torch.from_numpy(x))[0].numpy()
+    eng = emu_lib.Engine("egolanes", vw.pack_state_dict(sd), precision="fp16x3")
+    try:
+        eng.set_decode_mode(emu_lib.VP_DECODE_LANE_LABEL)
+        eng._ck(eng._lib.vp_use_graph(eng._h, 0))          # one eager pass is enough here
+        eng.infer(frame)
+        assert np.array_equal(eng.input_tensor(), x)
+        got = eng.logits()
+        assert float(np.abs(got - ref).max() / np.abs(ref).max()) <= 1e-3
+        want_mask = pre_post.egolanes_priority_mask(ref)
+        differ = eng.mask() != want_mask
+        assert not differ.any() or np.abs(ref)[:, differ].min() <= 1e-3      # flips only where a logit sits on the threshold
+    finally:
+        eng.close()
