@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void convt_stream_kernel(const ConvGemmParams 
           for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[4 * g + r] + bias4[g][r]);
           *reinterpret_cast<h4_t*>(mypatch + (lane & 31) * 80 + (8 * g + 4 * (lane >> 5)) * 2) = h;
         }
-        // same wave wrote and reads the patch: LDS operations of a wave complete in order
+        // same wave wrote and reads the patch: LDS operations of a wave complete in order.  The wave barrier emits no
+        // instruction (the ISA is unchanged); it states the dependency for the compiler and for the CPU emulation (tests/emul).
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int idx = lane + 64 * i, r = idx >> 2, c8 = idx & 3;  // 32 rows x 4 pieces of 8 channels

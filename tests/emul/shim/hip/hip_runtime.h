@@ -419,6 +419,7 @@ F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
 
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma_32x32x16_f16(a, b, c)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::sync_wave()  // lanes of a wave run in lockstep on the device; here they must meet
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0u
 

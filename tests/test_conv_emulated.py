@@ -92,6 +92,9 @@ def test_conv_transpose_pixel_shuffle(emu_lib, precision):
     """ConvTranspose2d(k2, s2) as a GEMM with the pixel-shuffle store; K = 128 takes the persistent streaming kernel."""
     _case(emu_lib, 64, 48, 5, 6, 2, 1, 0, 0, precision, [(-1, -1, -1), (1, 32, 1), (2, 64, 1)], seed=7)
     _case(emu_lib, 128, 64, 4, 8, 2, 1, 1, 0, precision, [(-1, -1, -1)], seed=8)
+    # >= 2048 pixels, no activation: the fp16 engine takes the persistent streaming kernel (several tiles per workgroup, deep
+    # register ring, wave-private epilogue patch); the fp16x3 engine the GEMM kernel
+    _case(emu_lib, 128, 128, 40, 64, 2, 1, 0, 0, precision, [(-1, -1, -1)], seed=11)
 
 
 def test_region_kernel(emu_lib):
