@@ -151,3 +151,37 @@ def test_scene_network_end_to_end_on_cpu(emu_lib, kind, seed):
             assert margin[differ].max() <= 1e-3 * np.abs(ref).max()
     finally:
         eng.close()
+
+
+def test_sceneseg_fp16_benchmark_mode_on_cpu(emu_lib):
+    """The precision bench.py reports (VP_FP16: single fp16 plane, fp16 activation variants, register epilogues, the
+    persistent streaming ConvTranspose) through the whole SceneSeg network on the CPU; the GPU test's bar: max |error| within
+    3e-2 of the largest logit, >= 99.5 % class agreement."""
+    import torch
+
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+    from oracle import nets, pre_post
+
+    sd = synthetic.make_state_dict("sceneseg", 0)
+    frame = synthetic.synthetic_frame(720, 1280, 9)
+    ref = nets.forward("sceneseg", nets.to_torch(sd), torch.from_numpy(pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=False)))[0].numpy()
+    eng = emu_lib.Engine("sceneseg", vw.pack_state_dict(sd), precision="fp16")
+    try:
+        eng._ck(eng._lib.vp_use_graph(eng._h, 0))
+        eng.infer(frame)
+        got = eng.logits()
+        assert float(np.abs(got - ref).max() / np.abs(ref).max()) <= 3e-2
+        assert float((got.argmax(0) == ref.argmax(0)).mean()) >= 0.995
+        kernels = {eng_k for eng_k in _layer_kernels(eng)}
+        assert any(k.startswith("convt_stream") for k in kernels) and any("regepi" in k for k in kernels)   # the fp16-only paths ran
+    finally:
+        eng.close()
+
+
+def _layer_kernels(eng):
+    out = []
+    for i in range(eng._ck(eng._lib.vp_layer_count(eng._h))):
+        tag = ct.c_char_p()
+        eng._ck(eng._lib.vp_layer_kernel(eng._h, i, ct.byref(tag)))
+        out.append(tag.value.decode())
+    return out
