@@ -1,8 +1,8 @@
 """The whole engine on the CPU: csrc/ compiled for the host on the HIP-on-CPU shim (tests/emul), driven through the C ABI
 exactly as on the GPU -- weight blob, plan, every kernel incl. the MFMA convolutions (emulated wave-level MFMA), graph
 capture / replay as closure lists.  AutoDrive (8 GFLOP, ~8 s emulated) is pinned end to end: tests/golden/autodrive.npz holds the outputs of the reference's OWN nn.Module
-(oracle/pin_autodrive.py), so this checks engine == reference without a GPU.  SceneSeg (the headline network) and EgoLanes run whole, 1 - 1.5 min each; the other
-kinds / the fp16 mode by hand with tests/emul/run_network.py."""
+(oracle/pin_autodrive.py), so this checks engine == reference without a GPU.  EgoLanes runs whole in the parity mode and SceneSeg (the headline network) in the benchmark's
+fp16 mode, ~1 min each; other kinds / modes by hand with tests/emul/run_network.py."""
 import ctypes as ct
 import os
 import sys
@@ -119,7 +119,7 @@ def test_batched_encoder_taps_on_cpu(emu_lib):
         enc.close()
 
 
-@pytest.mark.parametrize("kind,seed", [("egolanes", 2), ("sceneseg", 0)])
+@pytest.mark.parametrize("kind,seed", [("egolanes", 2)])  # ("sceneseg", 0) passes too (2 min): run_network.py; its fp16 mode is below
 def test_scene_network_end_to_end_on_cpu(emu_lib, kind, seed):
     """Whole scene networks through the production plan on the CPU (1 - 1.5 min each, emulated): preprocess, EfficientNet
     encoder, (EgoLanes: five-tap feature fusion), context, neck with the fused ConvTranspose + skip GEMMs, head, decode.
