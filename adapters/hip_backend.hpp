@@ -13,6 +13,8 @@
 #ifndef HIP_BACKEND_HPP_
 #define HIP_BACKEND_HPP_
 
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,6 +31,39 @@
 
 namespace autoware_pov::vision
 {
+
+// Host logits pointers handed out by live HipBackend instances -> their engines.  Lets the reference's STATIC mask helper
+// (MasksVisualizationKernels::createMaskFromTensorHIP(const float*, shape, cv::Mat&), see masks_visualization_kernels_hip.hpp)
+// recognise "this tensor is an engine's own output" and return the mask that engine already decoded on the device.
+class HipTensorRegistry
+{
+public:
+  static HipTensorRegistry & instance()
+  {
+    static HipTensorRegistry r;
+    return r;
+  }
+  void add(const float * p, vp_engine * e)
+  {
+    std::lock_guard<std::mutex> g(m_);
+    map_[p] = e;
+  }
+  void remove(vp_engine * e)
+  {
+    std::lock_guard<std::mutex> g(m_);
+    for (auto it = map_.begin(); it != map_.end();) it = it->second == e ? map_.erase(it) : std::next(it);
+  }
+  vp_engine * find(const float * p)
+  {
+    std::lock_guard<std::mutex> g(m_);
+    auto it = map_.find(p);
+    return it == map_.end() ? nullptr : it->second;
+  }
+
+private:
+  std::mutex m_;
+  std::map<const float *, vp_engine *> map_;
+};
 
 class HipBackend : public InferenceBackend
 {
@@ -59,7 +94,11 @@ public:
     vp_set_input_format(engine_, VP_BGR8, kind == VP_EGOLANES ? VP_PLANES_RGB : VP_PLANES_BGR);
     vp_input_hw(engine_, &in_h_, &in_w_);
   }
-  ~HipBackend() override { vp_destroy(engine_); }
+  ~HipBackend() override
+  {
+    HipTensorRegistry::instance().remove(engine_);
+    vp_destroy(engine_);
+  }
   HipBackend(const HipBackend &) = delete;
   HipBackend & operator=(const HipBackend &) = delete;
 
@@ -84,6 +123,7 @@ public:
     int64_t shape[4];
     if (!ran_ || vp_logits(engine_, &data, shape) != VP_OK)
       throw std::runtime_error("Inference has not been run yet. Call doInference() first.");
+    HipTensorRegistry::instance().add(data, engine_);
     return data;
   }
   std::vector<int64_t> getTensorShape() const override
@@ -122,10 +162,17 @@ public:
     if (!ran_) return false;
     const int t = viz_type == "scene" ? VP_VIZ_SCENE : viz_type == "domain" ? VP_VIZ_DOMAIN : viz_type == "egolanes" ? VP_VIZ_EGOLANES : -1;
     if (t < 0) return false;
+    int fh = 0, fw = 0;  // the blend is defined on the frame of the last doInference: refuse any other geometry
+    if (vp_frame_hw(engine_, &fh, &fw) != VP_OK || fh != frame_size.height || fw != frame_size.width) return false;
     blended.create(frame_size, CV_8UC3);
     if (!blended.isContinuous()) return false;
-    return vp_visualize_mask_bgr8(engine_, t, blended.data) == VP_OK;
+    return vp_visualize_mask_bgr8(engine_, t, blended.data, frame_size.height, frame_size.width) == VP_OK;
   }
+
+  // A host that consumes only the decoded mask (createMask / visualizeMask) can drop the 2.4 MB logits copy per frame:
+  // logits then stay in HBM until getRawTensorData() asks for them.
+  void setCopyLogitsEveryFrame(bool on) { vp_set_outputs(engine_, (on ? VP_OUT_LOGITS : 0) | VP_OUT_MASK); }
+  vp_engine * handle() { return engine_; }
 
 private:
   vp_engine * engine_ = nullptr;

@@ -9,6 +9,8 @@
 
 #include "egolanes_hip_engine.hpp"
 #include "hip_backend.hpp"
+#define VP_HIP_DEFINE_MASK_KERNELS 1
+#include "masks_visualization_kernels_hip.hpp"  // the reference's static helper signature on libvp_hip
 
 using autoware_pov::vision::HipBackend;
 using autoware_pov::vision::egolanes::EgoLanesHipEngine;
@@ -45,6 +47,9 @@ int main(int argc, char ** argv)
   } catch (const std::runtime_error &) {
   }
   if (argc < 4) {
+#ifdef VP_ADAPTER_CHECK_REAL_HEADERS
+    std::puts("adapter_check: compiled against the reference's own inference_backend_base.hpp / masks_visualization_kernels.hpp");
+#endif
     std::puts("adapter_check: construction-failure conventions OK");
     return 0;
   }
@@ -87,6 +92,19 @@ int main(int argc, char ** argv)
     } else {
       if (!b.createMask(mask, frame.size())) return fail("createMask");
       f.write(reinterpret_cast<const char *>(mask.data), 720 * 1280);
+    }
+    if (kind != "depth") {
+      // the reference's static helper, same signature: (a) on the backend's own tensor (no upload), (b) on a foreign copy
+      using autoware_pov::common::MasksVisualizationKernels;
+      cv::Mat m1, m2;
+      if (!MasksVisualizationKernels::createMaskFromTensorHIP(b.getRawTensorData(), shape, m1)) return fail("createMaskFromTensorHIP (own tensor)");
+      std::vector<float> copy(b.getRawTensorData(), b.getRawTensorData() + n);
+      if (!MasksVisualizationKernels::createMaskFromTensorHIP(copy.data(), shape, m2)) return fail("createMaskFromTensorHIP (host tensor)");
+      if (m1.rows != 320 || m1.cols != 640 || std::memcmp(m1.data, m2.data, 320 * 640) != 0) return fail("createMaskFromTensorHIP paths disagree");
+      f.write(reinterpret_cast<const char *>(m1.data), 320 * 640);
+      cv::Mat blended;
+      if (b.visualizeMask("scene", blended, cv::Size(640, 360))) return fail("visualizeMask must refuse a size that is not the last frame's");
+      if (!b.visualizeMask(kind == "domain" ? "domain" : "scene", blended, frame.size())) return fail("visualizeMask");
     }
     cv::Mat bad(10, 10, CV_8UC1);
     if (b.doInference(bad)) return fail("doInference must reject a non-BGR8 image with false");

@@ -12,6 +12,7 @@
 // loop carries no mode branches (the all-runtime version was ~1600 instructions per pass; SQ_ACTIVE_INST showed
 // waves of the memory-bound layers spending 40 % of their life issuing it).
 #pragma once
+#include <atomic>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -300,5 +301,25 @@ constexpr int epilogue_fp16_stage_bytes() {
 }
 
 hipError_t launch_splitk_finish(const ConvGemmParams& p, hipStream_t st);  // kernels_conv.hip
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: an engine on a second gpu_id in the same
+// process (thread-per-GPU hosts) must set it again.  One bit per device id, set after the attribute call succeeded; racing
+// first launches from two threads both make the (idempotent) call.  Read-mostly atomic, no lock on the launch path.
+struct LdsAttrOnce {
+  std::atomic<unsigned long long> done[4] = {};
+};
+inline hipError_t set_max_dynamic_lds(LdsAttrOnce& once, const void* fn, int lds_bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::atomic<unsigned long long>& word = once.done[(dev >> 6) & 3];
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (word.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e != hipSuccess) return e;
+  word.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
+
 
 }  // namespace vp

@@ -126,6 +126,15 @@ Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engi
     throw std::runtime_error("libvp_hip: no HIP device visible (this library has no CPU fallback)");
   if (gpu_id < 0 || gpu_id >= ndev) throw std::invalid_argument("gpu_id out of range");
   VP_HIP_CHECK(hipSetDevice(gpu_id));
+  try {
+    construct(kind, blob, precision, gpu_id, base);
+  } catch (...) {  // ~Engine never runs for a throwing constructor: free the stream, events and every dalloc() made so far
+    release();
+    throw;
+  }
+}
+
+void Engine::construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base) {
   if (base) {
     if (kind < 0 || base->kind_ < 0) throw std::invalid_argument("shared engines need model kinds on both sides");
     if (base->base_) throw std::invalid_argument("the base of a shared engine must own its whole network");
@@ -150,17 +159,28 @@ Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engi
   }
 }
 
-Engine::~Engine() {
+Engine::~Engine() { release(); }
+
+void Engine::release() {
   hipSetDevice(gpu_);
   if (stream_) hipStreamSynchronize(stream_);
   if (graph_exec_) hipGraphExecDestroy(graph_exec_);
   if (graph_) hipGraphDestroy(graph_);
+  graph_exec_ = nullptr;
+  graph_ = nullptr;
   for (void* p : allocs_) hipFree(p);
+  allocs_.clear();
   if (h_logits_) hipHostFree(h_logits_);
   if (h_mask_) hipHostFree(h_mask_);
+  if (h_frame_) hipHostFree(h_frame_);
+  h_logits_ = nullptr;
+  h_mask_ = nullptr;
+  h_frame_ = nullptr;
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
+  ev0_ = ev1_ = nullptr;
   if (stream_ && !base_) hipStreamDestroy(stream_);
+  stream_ = nullptr;
 }
 
 unsigned long long WeightBlob::group_hash(const std::string& prefix) const {
@@ -377,6 +397,13 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
+    if (ht == 6) {
+      if (!conv3x3_x3w8_supported(p)) throw std::invalid_argument("halo tile 6 (8-wave fp16x3 kernel): conv + bias + {GELU, none}, NHWC, 128-channel tiles, no split-K: " + name);
+      op.kernel = "conv3x3_x3w8<co128,px256>";
+      op.run = [p](hipStream_t st) { return launch_conv3x3_x3w8(p, st); };
+      ops_.push_back(std::move(op));
+      return;
+    }
     // ",regepi": the register-GELU single-pass epilogue instantiation (same condition as launch_halo_cfg)
     const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1;
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
@@ -431,6 +458,16 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       }
     }
     if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
+    // parity mode, 128-channel tiles, enough 16x16 patches to need no split-K: the 8-wave pipelined kernel (halo tile 6)
+    {
+      static const char* env8 = std::getenv("VP_X3W8");
+      auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
+      const long long wgs = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128);
+      if (split() && o.tile < 0 && !(env8 && env8[0] == '0') && (halo == 1 || halo == 3) && ncols % 128 == 0 && wgs >= 160 &&
+          (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !o.logits_out && !o.in2)
+        halo = 6;
+    }
+    if (halo == 6 && !split()) throw std::invalid_argument("halo tile 6 is the fp16x3 kernel: " + name);
   }
   // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
   // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
@@ -489,6 +526,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       ns = std::min(ns, std::max(1, KC / 2));
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
+    if (halo == 6) pc.nsplit = 1;  // one 512-thread workgroup per CU: >= 160 tiles already cover most of the machine
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }
@@ -1418,7 +1456,32 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int in
   frame_h_ = h;
   frame_w_ = w;
   frame_stride_ = stride;
-  VP_HIP_CHECK(hipMemcpyAsync(d_frame_ + (size_t)index * need, frame, need, hipMemcpyHostToDevice, stream_));
+  // A strided view (cv::Mat ROI, numpy slice) guarantees only (h-1)*stride + 3*w readable bytes: the tail of the last row
+  // belongs to the parent image or to nobody.  Packed frames go as one copy, views row by row (hipMemcpy2D).
+  // The caller's buffer is pageable (cv::Mat); the copy is staged through this engine's pinned buffer so the transfer
+  // itself is one DMA that overlaps other engines' kernels (the reference does the same H2D: tensorrt_backend.cpp:184-186).
+  uint8_t* dst = d_frame_ + (size_t)index * need;
+  const size_t packed = (size_t)(h - 1) * stride + (size_t)3 * w;
+  if (pinned_staging_) {
+    if (need > h_frame_cap_) {
+      VP_HIP_CHECK(hipStreamSynchronize(stream_));
+      if (h_frame_) hipHostFree(h_frame_);
+      h_frame_ = nullptr;
+      VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_frame_), need * 2, hipHostMallocDefault));  // two slots: frame n+1 is staged while n flies
+      h_frame_cap_ = need;
+    }
+    uint8_t* slot = h_frame_ + (size_t)(h_frame_slot_ ^= 1) * h_frame_cap_;
+    if (stride == 3 * w) {
+      std::memcpy(slot, frame, packed);
+    } else {
+      for (int y = 0; y < h; ++y) std::memcpy(slot + (size_t)y * stride, frame + (size_t)y * stride, (size_t)3 * w);
+    }
+    VP_HIP_CHECK(hipMemcpyAsync(dst, slot, packed, hipMemcpyHostToDevice, stream_));
+  } else if (stride == 3 * w) {
+    VP_HIP_CHECK(hipMemcpyAsync(dst, frame, packed, hipMemcpyHostToDevice, stream_));
+  } else {
+    VP_HIP_CHECK(hipMemcpy2DAsync(dst, stride, frame, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, stream_));
+  }
   if (input_is_tensor_) graph_valid_ = false;
   input_is_tensor_ = false;
 }
@@ -1476,6 +1539,7 @@ void Engine::enqueue() {
     VP_HIP_CHECK(hipStreamSynchronize(stream_));
     warmed_ = true;
     have_outputs_ = true;
+    host_logits_valid_ = host_mask_valid_ = false;
     if (!use_graph_ || kind_ == 4) return;  // AutoDrive carries state (feature shift): a frame must run exactly once
   }
   if (use_graph_) {
@@ -1485,15 +1549,45 @@ void Engine::enqueue() {
     run_eager();
   }
   have_outputs_ = true;
+  host_logits_valid_ = host_mask_valid_ = false;
 }
 
 void Engine::sync() { VP_HIP_CHECK(hipStreamSynchronize(stream_)); }
 
 void Engine::fetch_outputs() {
   if (!d_logits_) throw std::runtime_error("this engine has no outputs (batched encoder: fetch from its shared-prefix engines)");
-  VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
-  VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
+  enqueue_fetch();
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// D2H of the outputs the caller selected (vp_set_outputs), asynchronous on the engine stream, into pinned host memory.
+void Engine::enqueue_fetch() {
+  if (!d_logits_) throw std::runtime_error("this engine has no outputs (batched encoder: fetch from its shared-prefix engines)");
+  if (outputs_ & 1)
+    VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  if ((outputs_ & 2) && d_mask_) VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
+  host_logits_valid_ = (outputs_ & 1) != 0;
+  host_mask_valid_ = (outputs_ & 2) != 0;
+}
+
+// Lazy variants behind vp_logits / vp_mask_u8: an output de-selected with vp_set_outputs is fetched on first use.
+const float* Engine::host_logits() {
+  if (!host_logits_valid_ && d_logits_ && have_outputs_) {
+    VP_HIP_CHECK(hipSetDevice(gpu_));
+    VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    host_logits_valid_ = true;
+  }
+  return h_logits_;
+}
+const uint8_t* Engine::host_mask() {
+  if (!host_mask_valid_ && d_mask_ && have_outputs_) {
+    VP_HIP_CHECK(hipSetDevice(gpu_));
+    VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
+    VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    host_mask_valid_ = true;
+  }
+  return h_mask_;
 }
 
 void Engine::copy_outputs_device(void* logits_dst, void* mask_dst) {
@@ -1557,11 +1651,16 @@ void Engine::mask_resized(uint8_t* dst, int h, int w) {
 
 // MasksVisualizationEngine::visualize on the device: the mask of the LAST inference, coloured, nearest-resized to the frame
 // that produced it and blended 50/50 with that (still resident) frame; BGR8 out, frame size.
-void Engine::visualize_mask(int viz_type, uint8_t* dst) {
+void Engine::visualize_mask(int viz_type, uint8_t* dst, int dst_h, int dst_w) {
   if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
   if (!dst || viz_type < 0 || viz_type > 2) throw std::invalid_argument("bad visualisation request");
   if (!d_frame_ || input_is_tensor_ || base_) throw std::runtime_error("visualize_mask needs the frame path (vp_infer) on a base engine");
   const int h = frame_h_, w = frame_w_;
+  // The blend writes h*w*3 bytes: the caller's buffer must have the geometry of the frame that was inferred last (the
+  // reference takes the size from original_image itself, masks_visualization_engine.cpp:19-27, so it cannot mismatch).
+  if (dst_h != h || dst_w != w)
+    throw std::invalid_argument("visualize_mask: destination is " + std::to_string(dst_w) + "x" + std::to_string(dst_h) +
+                                " but the last inferred frame was " + std::to_string(w) + "x" + std::to_string(h));
   if (!d_viz_lut_) {
     // createColorMask (masks_visualization_engine.cpp:41-58), BGR
     std::vector<uint8_t> lut(3 * 256 * 3, 0);
@@ -1666,7 +1765,11 @@ int Engine::profile_layers(int iters, float* ms, int cap) {
   const size_t first = input_is_tensor_ ? first_net_op_ : 0;
   const int n = (int)ops_.size();
   if (cap < n) throw std::invalid_argument("profile buffer too small");
-  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident");
+  if (base_) {
+    if (!base_->have_outputs_) throw std::runtime_error("shared engine: run the base engine on a frame first");
+  } else if (!input_is_tensor_ && !d_frame_) {
+    throw std::runtime_error("no frame resident");
+  }
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& e : ev) VP_HIP_CHECK(hipEventCreate(&e));
   std::vector<double> acc(n, 0.0);

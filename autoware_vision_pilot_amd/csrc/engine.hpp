@@ -96,16 +96,26 @@ class Engine {
   void upload_tensor(const float* nchw);
   void enqueue();
   void sync();
-  void fetch_outputs();
+  void fetch_outputs();      // enqueue_fetch() + sync
+  void enqueue_fetch();      // async D2H of the selected outputs (set_outputs) into the pinned host buffers
+  // bit 0: logits, bit 1: mask.  De-selected outputs stay in HBM and are copied on first use (vp_logits / vp_mask_u8).
+  void set_outputs(int mask) {
+    if (mask < 0 || mask > 3) throw std::invalid_argument("outputs: bit 0 = logits, bit 1 = mask");
+    outputs_ = mask;
+  }
+  // stage vp_infer's H2D through a pinned double buffer owned by the engine (default on)
+  void set_pinned_staging(bool on) { pinned_staging_ = on; }
   void copy_outputs_device(void* logits_dst, void* mask_dst);
   void mask_resized(uint8_t* dst, int h, int w);
   void depth_resized(float* dst, int h, int w);
-  void visualize_mask(int viz_type, uint8_t* dst_bgr);
+  void visualize_mask(int viz_type, uint8_t* dst_bgr, int dst_h, int dst_w);
   void visualize_depth(uint8_t* dst_bgr, int h, int w);
   void read_input_tensor(float* dst);
 
-  const float* host_logits() const { return h_logits_; }
-  const uint8_t* host_mask() const { return h_mask_; }
+  const float* host_logits();   // pinned host copy; fetched now if the last pass did not copy it
+  const uint8_t* host_mask();
+  int frame_h() const { return frame_h_; }
+  int frame_w() const { return frame_w_; }
   void* dev_logits() const { return d_logits_; }
   void* dev_mask() const { return d_mask_; }
   int out_c() const { return out_c_; }
@@ -134,6 +144,7 @@ class Engine {
   void run_eager();
   void upload_act(Act* a, const float* chw);
   hipStream_t stream() const { return stream_; }
+  int gpu() const { return gpu_; }
   bool split() const { return (precision_ & 15) == 1; }
   bool fp8_weights() const { return (precision_ & 16) != 0; }
   int shared_level() const { return shared_level_; }  // 0 own network, 1 backbone shared, 2 backbone + context + neck shared
@@ -147,6 +158,8 @@ class Engine {
     float* bias = nullptr;
     int CoutW = 0, tile = 0, bk = 32, nsplit = 1;
   };
+  void construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base);
+  void release();  // frees every device / host resource; idempotent (destructor and failed construction)
   void* dalloc(size_t bytes, bool zero = true);
   template <class T>
   T* dupload(const std::vector<T>& v);
@@ -198,6 +211,13 @@ class Engine {
   float* h_logits_ = nullptr;
   uint8_t* h_mask_ = nullptr;
   bool have_outputs_ = false;
+  int outputs_ = 3;  // vp_set_outputs: bit 0 logits, bit 1 mask copied to the host by vp_infer*
+  bool host_logits_valid_ = false, host_mask_valid_ = false;
+  // pinned staging of the caller's (pageable) frame: two slots
+  uint8_t* h_frame_ = nullptr;
+  size_t h_frame_cap_ = 0;
+  int h_frame_slot_ = 0;
+  bool pinned_staging_ = true;
 
   // split-K scratch
   std::vector<float**> partial_slots_;

@@ -307,12 +307,8 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
     if (epi == 3) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 3>;
     if (epi == 4) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 4>;
   }
-  static bool attr_done[2][5] = {};
-  if (!attr_done[k1][epi]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done[k1][epi] = true;
-  }
+  static LdsAttrOnce attr_once[2][5];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[k1][epi], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   const int M = p.H * p.W;
   dim3 grid(((M + PX - 1) / PX) * (p.CoutW / CO) * p.nsplit);  // decoded in the kernel (XCD-aware)
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);

@@ -263,12 +263,8 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
   const bool fast = !SPLIT && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1 &&
                     p.out_lo == nullptr;
   auto k = fast ? conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, !SPLIT> : conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, false>;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[fast]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done[fast] = true;
-  }
+  static LdsAttrOnce attr_once[2];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[fast], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW) * (p.CoutW / CO) * p.nsplit);  // decoded in the kernel (XCD-aware)
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
@@ -278,10 +274,11 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
 }
 
 // halo tile ids: 0 = 128co x (16x16)px, 1 = 128co x (8x16)px, 2 = 64co x (16x16)px, 3 = 64co x (8x16)px, 4 = 32co x (8x16)px,
-//                5 = 32co x (16x16)px
+//                5 = 32co x (16x16)px, 6 = 128co x (16x16)px with 8 waves, fp16x3 only (kernels_conv3x3_x3.hip)
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st) {
 #define VP_HCASE(T, CO, TH, TW, WCO, WPX) \
   if (tile == T) return split ? launch_halo_cfg<CO, TH, TW, WCO, WPX, true>(p, st) : launch_halo_cfg<CO, TH, TW, WCO, WPX, false>(p, st);
+  if (tile == 6) return split ? launch_conv3x3_x3w8(p, st) : hipErrorInvalidValue;  // 8-wave parity-mode kernel (kernels_conv3x3_x3.hip)
   if (tile == 3 && !split) return launch_halo_cfg<64, 8, 16, 1, 4, false>(p, st);
   VP_HCASE(1, 128, 8, 16, 2, 2)
   VP_HCASE(3, 64, 8, 16, 2, 2)
@@ -294,8 +291,8 @@ hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hi
   if (tile == 2) return split ? hipErrorInvalidValue : launch_halo_cfg<64, 16, 16, 1, 4, false>(p, st);
   return hipErrorInvalidValue;
 }
-int halo_tile_co(int tile) { return tile <= 1 ? 128 : (tile <= 3 ? 64 : 32); }
-int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5) ? 256 : 128; }
-int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5) ? 16 : 8; }
+int halo_tile_co(int tile) { return (tile <= 1 || tile == 6) ? 128 : (tile <= 3 ? 64 : 32); }
+int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 256 : 128; }
+int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 16 : 8; }
 
 }  // namespace vp

@@ -202,12 +202,8 @@ static hipError_t launch_region_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds = lds_main > epilogue_stage_bytes<512, 1>() ? lds_main : epilogue_stage_bytes<512, 1>();
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = conv3x3_region_kernel<RH, RW, CO, SPLIT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttrOnce attr_once;
+  if (hipError_t e = set_max_dynamic_lds(attr_once, reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   const int n_regs = ((p.H + RH - 1) / RH) * ((p.W + RW - 1) / RW);
   dim3 grid(n_regs * (p.CoutW / CO) * p.nsplit);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);

@@ -176,12 +176,8 @@ static hipError_t launch_stream_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds = 64 * PITCH + 2 * 64 * PITCH + 4 * 32 * 80;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = convt_stream_kernel<KT, DEPTH, SKIP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static LdsAttrOnce attr_once;
+  if (hipError_t e = set_max_dynamic_lds(attr_once, reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   const int M = p.H * p.W, n_tiles = (M + 63) / 64, slices = p.Ncols / 64;
   // persistent: as many workgroups as the LDS plan keeps resident (no second round), at least 4 pixel tiles each
   const int resident = 256 * std::max(1, (160 * 1024) / lds);

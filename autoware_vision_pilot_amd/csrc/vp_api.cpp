@@ -4,13 +4,7 @@
 #include <cstring>
 #include <fstream>
 
-#include "../../include/vp_hip.h"
-#include "engine.hpp"
-
-struct vp_engine {
-  std::unique_ptr<vp::Engine> impl;
-  std::string err;
-};
+#include "vp_handle.hpp"
 
 namespace {
 
@@ -103,6 +97,32 @@ int read_weights(const char* path, std::vector<char>& buf, char* err, size_t err
 }  // namespace
 
 extern "C" {
+
+// Stateless twin of MasksVisualizationKernels::createMaskFromTensor{CUDA,HIP} / createEgoLanesMaskFromTensorCUDA
+// (common/include/masks_visualization_kernels.hpp:14-45, masks_viz.hip.cpp:41-97): HOST logits up, decode kernel, mask down.
+// Same shape of work as the reference helper (allocate, copy, launch, copy, free); the engine-resident path (vp_mask_u8)
+// never re-uploads the logits.
+int vp_decode_logits_host(int gpu_id, const float* logits_nchw, int channels, int h, int w, int decode_mode, uint8_t* mask_out) {
+  if (!logits_nchw || !mask_out || channels < 1 || h < 1 || w < 1 || decode_mode < 0 || decode_mode > 2) return VP_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || gpu_id < 0 || gpu_id >= ndev) return VP_ERR_HIP;
+  if (hipSetDevice(gpu_id) != hipSuccess) return VP_ERR_HIP;
+  const size_t hw = (size_t)h * w, in_bytes = hw * channels * sizeof(float);
+  float* d_in = nullptr;
+  uint8_t* d_out = nullptr;
+  hipStream_t st = nullptr;
+  int rc = VP_ERR_HIP;
+  if (hipMalloc(reinterpret_cast<void**>(&d_in), in_bytes) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&d_out), hw) == hipSuccess &&
+      hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+      hipMemcpyAsync(d_in, logits_nchw, in_bytes, hipMemcpyHostToDevice, st) == hipSuccess &&
+      vp::launch_decode_mask(d_in, channels, (int)hw, decode_mode, d_out, st) == hipSuccess &&
+      hipMemcpyAsync(mask_out, d_out, hw, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+    rc = VP_OK;
+  if (st) hipStreamDestroy(st);
+  if (d_in) hipFree(d_in);
+  if (d_out) hipFree(d_out);
+  return rc;
+}
 
 const char* vp_version(void) { return "libvp_hip 0.1 (gfx950)"; }
 
@@ -244,6 +264,36 @@ int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes)
     g.fetch_outputs();
   });
 }
+int vp_set_outputs(vp_engine* e, int outputs) {
+  return guarded(e, [&](vp::Engine& g) { g.set_outputs(outputs); });
+}
+int vp_set_pinned_staging(vp_engine* e, int enable) {
+  return guarded(e, [&](vp::Engine& g) { g.set_pinned_staging(enable != 0); });
+}
+int vp_frame_hw(const vp_engine* e, int* h, int* w) {
+  if (!e || !e->impl || !h || !w) return VP_ERR_ARG;
+  *h = e->impl->frame_h();
+  *w = e->impl->frame_w();
+  return VP_OK;
+}
+// One camera frame through a base engine and its shared-prefix heads: ONE H2D, every network enqueued back to back on the
+// base engine's stream, the selected outputs of every engine copied D2H behind them, ONE host synchronisation.
+int vp_infer_multi(vp_engine* base, vp_engine* const* shared, int n_shared, const uint8_t* frame, int h, int w, int stride_bytes) {
+  if (n_shared < 0 || (n_shared > 0 && !shared)) return VP_ERR_ARG;
+  for (int i = 0; i < n_shared; ++i)
+    if (!shared[i] || !shared[i]->impl) return VP_ERR_ARG;
+  return guarded(base, [&](vp::Engine& g) {
+    for (int i = 0; i < n_shared; ++i)
+      if (shared[i]->impl->shared_level() == 0 || shared[i]->impl->stream() != g.stream())
+        throw std::invalid_argument("vp_infer_multi: every head must be a shared-prefix engine of this base");
+    g.upload_frame(frame, h, w, stride_bytes);
+    g.enqueue();
+    for (int i = 0; i < n_shared; ++i) shared[i]->impl->enqueue();
+    g.enqueue_fetch();
+    for (int i = 0; i < n_shared; ++i) shared[i]->impl->enqueue_fetch();
+    g.sync();
+  });
+}
 int vp_infer_pair(vp_engine* e, const uint8_t* prev, const uint8_t* curr, int h, int w, int stride_bytes) {
   return guarded(e, [&](vp::Engine& g) {
     g.upload_frame(prev, h, w, stride_bytes);
@@ -266,7 +316,12 @@ int vp_logits(const vp_engine* e, const float** data, int64_t shape[4]) {
     const_cast<vp_engine*>(e)->err = "Inference has not been run yet. Call vp_infer() first.";  // onnx_runtime_backend.cpp:86-88
     return VP_ERR_STATE;
   }
-  *data = e->impl->host_logits();
+  try {
+    *data = e->impl->host_logits();
+  } catch (const std::exception& ex) {
+    const_cast<vp_engine*>(e)->err = ex.what();
+    return VP_ERR_HIP;
+  }
   shape[0] = 1;
   shape[1] = e->impl->out_c();
   shape[2] = e->impl->out_h();
@@ -279,7 +334,12 @@ int vp_mask_u8(const vp_engine* e, const uint8_t** data, int* h, int* w) {
     const_cast<vp_engine*>(e)->err = "Inference has not been run yet. Call vp_infer() first.";
     return VP_ERR_STATE;
   }
-  *data = e->impl->host_mask();
+  try {
+    *data = e->impl->host_mask();
+  } catch (const std::exception& ex) {
+    const_cast<vp_engine*>(e)->err = ex.what();
+    return VP_ERR_HIP;
+  }
   *h = e->impl->out_h();
   *w = e->impl->out_w();
   return VP_OK;
@@ -293,8 +353,8 @@ int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w) {
 int vp_visualize_depth_bgr8(vp_engine* e, uint8_t* dst, int h, int w) {
   return guarded(e, [&](vp::Engine& g) { g.visualize_depth(dst, h, w); });
 }
-int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst) {
-  return guarded(e, [&](vp::Engine& g) { g.visualize_mask(viz_type, dst); });
+int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst, int h, int w) {
+  return guarded(e, [&](vp::Engine& g) { g.visualize_mask(viz_type, dst, h, w); });
 }
 int vp_input_tensor(vp_engine* e, float* dst) {
   return guarded(e, [&](vp::Engine& g) { g.read_input_tensor(dst); });

@@ -49,9 +49,14 @@ _SIGS = {
     "vp_infer_pair": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int]),
     "vp_logits": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]),
     "vp_mask_u8": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_decode_logits_host": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vp_mask_resized_u8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_depth_resized_f32": (C.c_int, [_P, _P, C.c_int, C.c_int]),
-    "vp_visualize_mask_bgr8": (C.c_int, [_P, C.c_int, _P]),
+    "vp_visualize_mask_bgr8": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
+    "vp_frame_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_set_outputs": (C.c_int, [_P, C.c_int]),
+    "vp_set_pinned_staging": (C.c_int, [_P, C.c_int]),
+    "vp_infer_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vp_visualize_depth_bgr8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_input_tensor": (C.c_int, [_P, _P]),
     "vp_upload_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
@@ -75,7 +80,22 @@ _SIGS = {
     "vp_version": (C.c_char_p, []),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
-EXPORTED_SYMBOLS = tuple(_SIGS)
+# multi-camera exchange (csrc/vp_comm.cpp): part of libvp_hip.so, absent from the CPU-emulated test build
+_COMM_SIGS = {
+    "vp_comm_unique_id": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "vp_comm_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "vp_comm_destroy": (None, [_P]),
+    "vp_comm_last_error": (C.c_char_p, [_P]),
+    "vp_comm_rank": (C.c_int, [_P]),
+    "vp_comm_world": (C.c_int, [_P]),
+    "vp_gather": (C.c_int, [_P, _P, C.c_int]),
+    "vp_comm_device_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "vp_comm_fetch": (C.c_int, [_P, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS) + tuple(_COMM_SIGS)
+VP_OUT_LOGITS, VP_OUT_MASK = 1, 2
+VP_GATHER_MASK, VP_GATHER_LOGITS = 0, 1
+VP_COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -92,7 +112,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VpError(f"{LIB_PATH} not built -- run __graft_entry__.build(); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in _SIGS.items():
+    for name, (res, args) in list(_SIGS.items()) + list(_COMM_SIGS.items()):
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
@@ -246,10 +266,31 @@ class Engine:
         return out
 
     def visualize_mask(self, viz_type, frame_hw):
-        """Blended BGR visualisation (masks_visualization_engine.cpp) of the last inference at the last frame's size."""
+        """Blended BGR visualisation (masks_visualization_engine.cpp) of the last inference at the last frame's size;
+        ValueError if ``frame_hw`` is not the geometry of the frame that was inferred last."""
         out = np.empty((frame_hw[0], frame_hw[1], 3), dtype=np.uint8)
-        self._ck(self._lib.vp_visualize_mask_bgr8(self._h, int(viz_type), _ptr(out)))
+        self._ck(self._lib.vp_visualize_mask_bgr8(self._h, int(viz_type), _ptr(out), int(frame_hw[0]), int(frame_hw[1])))
         return out
+
+    def frame_hw(self):
+        h, w = C.c_int(), C.c_int()
+        self._ck(self._lib.vp_frame_hw(self._h, C.byref(h), C.byref(w)))
+        return h.value, w.value
+
+    def set_outputs(self, logits=True, mask=True):
+        """Which outputs infer() / infer_shared() / infer_multi() copy to the host; the rest is fetched on first use."""
+        self._ck(self._lib.vp_set_outputs(self._h, (VP_OUT_LOGITS if logits else 0) | (VP_OUT_MASK if mask else 0)))
+
+    def set_pinned_staging(self, on):
+        self._ck(self._lib.vp_set_pinned_staging(self._h, int(bool(on))))
+
+    def infer_multi(self, heads, frame_u8):
+        """One frame through this base engine and its shared-prefix ``heads``: one H2D, one host synchronisation."""
+        f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
+        if f.ndim != 3 or f.shape[2] != 3:
+            raise ValueError("frame must be HxWx3 uint8")
+        arr = (C.c_void_p * max(1, len(heads)))(*[h._h for h in heads])
+        self._ck(self._lib.vp_infer_multi(self._h, arr, len(heads), _ptr(f), f.shape[0], f.shape[1], f.strides[0]))
 
     def input_tensor(self):
         h, w = self.input_hw()
@@ -336,6 +377,75 @@ class Engine:
         out = np.empty((c, h, w), dtype=np.float32)
         self._ck(self._lib.vp_tensor_read(self._h, i, _ptr(out)))
         return out
+
+
+def decode_logits_host(logits_chw, decode_mode=VP_DECODE_SEG_MASK, gpu_id=0):
+    """createMaskFromTensorHIP twin (vp_decode_logits_host): host CxHxW fp32 logits -> HxW u8 mask."""
+    x = np.ascontiguousarray(logits_chw, dtype=np.float32)
+    c, h, w = x.shape
+    out = np.empty((h, w), dtype=np.uint8)
+    rc = load().vp_decode_logits_host(gpu_id, _ptr(x), c, h, w, int(decode_mode), _ptr(out))
+    if rc != 0:
+        raise (ValueError if rc == -1 else VpError)(f"vp_decode_logits_host failed ({rc})")
+    return out
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (vp_comm_*): per-frame all-gather of the per-camera result records."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(VP_COMM_ID_BYTES)
+        err = C.create_string_buffer(512)
+        rc = load().vp_comm_unique_id(buf, err, len(err))
+        if rc != 0:
+            raise VpError(f"vp_comm_unique_id failed ({rc}): {err.value.decode(errors='replace')}")
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world, gpu_id, record_bytes_max):
+        self._lib = load()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        idbuf = C.create_string_buffer(bytes(unique_id), VP_COMM_ID_BYTES)
+        rc = self._lib.vp_comm_create(C.byref(self._h), idbuf, rank, world, gpu_id, record_bytes_max, err, len(err))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise (ValueError if rc == -1 else VpError)(f"vp_comm_create failed ({rc}): {err.value.decode(errors='replace')}")
+        self.rank, self.world = rank, world
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._h = None
+            self._lib.vp_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            msg = self._lib.vp_comm_last_error(self._h).decode(errors="replace")
+            raise (ValueError if rc == -1 else VpError)(f"libvp_hip comm error {rc}: {msg}")
+        return rc
+
+    def gather(self, engine, what=VP_GATHER_MASK):
+        """Enqueue the all-gather of ``engine``'s last record on the engine's stream (no host sync)."""
+        self._ck(self._lib.vp_gather(engine._h, self._h, int(what)))
+
+    def fetch(self, engine, dtype=np.uint8):
+        """[world][record] host copy of the last gather (synchronises the engine's stream)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._lib.vp_comm_fetch(self._h, engine._h, C.byref(p), C.byref(n)))
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.world * n.value,)).copy()
+        return raw.view(dtype).reshape(self.world, -1)
+
+    def device_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._lib.vp_comm_device_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
 
 def op_conv2d(x, weight, bias, ks=3, mode=0, act=0, res=None, res_mode=0, precision=VP_FP16, tile=-1, bk=-1, nsplit=-1, gpu_id=0):

@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
-"""Headline benchmark: frames/s of the VisionPilot per-frame hot path on MI355X.
+"""Headline benchmark: frames/s of the VisionPilot per-frame hot path on MI355X, on BASELINE.json's metric configuration.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run, one rank
-per GPU).  A *step* is one pass of the hot path over one frame: integer-bilinear preprocess of a synthetic
-1280x720 BGR frame that is already resident in HBM -> SceneSeg forward (EfficientNet-B0 encoder + context +
-neck + head, 367 GFLOP) -> argmax decode, replayed as one hipGraph on the engine's own stream
-(BASELINE.json configs[1]: "SceneSeg 1280x720 batch=1 on 1 MI355X, fp16").  Random-init weights of that
-architecture, synthetic frame: data = "synthetic".
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by torch.distributed.run, one rank per GPU).
 
-Multi-GPU: the path shards by camera: rank r owns camera r, weights replicated, no data-path
-collective (the reference has none) -> "scaling": "weak".  ``--gather`` adds the optional per-frame RCCL
-all-gather of the per-camera masks (BASELINE configs[3]).
+Workload (BASELINE.json ``metric``: "frames/sec/GPU (SceneSeg+Scene3D 1280x720); p50 per-frame latency"): one synthetic
+1280x720 BGR camera frame per GPU goes through integer-bilinear preprocess -> EfficientNet-B0 encoder (run ONCE, shared:
+the reference builds Scene3D on SceneSeg's pre-trained backbone, scene_3d_network.py:9-13) -> SceneSeg context + neck + head
+-> argmax decode, and -> Scene3D context + neck + head (vp_create + vp_create_shared engines on one HIP stream, each replayed
+as a hipGraph).  760.9 GFLOP per frame.  A *step* is one such frame.  Random-init weights of that architecture, synthetic
+frame: data = "synthetic".
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : dominant kernel family's ALGORITHMIC TFLOP/s from per-launch HIP-event timing on the engine
-                 stream vs the dense fp16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
-  cpu_baseline : the CPU oracle (torch fp32 restatement of the reference path) timed on this box's host cores
-                 on a bounded sample (rank 0, N=1 only)
+``value`` is measured in the PARITY mode (fp16x3: every tensor a (hi, lo) fp16 pair, three fp16 MFMAs per product, fp32
+accumulate -- class maps bit-exact and floats within 1e-3 of the fp32 oracle, tests/test_gpu_networks.py), with the frame
+resident in HBM and ``--streams`` frames in flight per GPU.  The same JSON line also carries
+  single_stream_fps / p50_ms : one frame at a time (back-to-back / synchronised per frame), parity mode
+  fp16_value ...             : the same three figures in plain fp16 (the reference's "fp16" configuration; NOT parity-grade)
+  host_to_host_fps           : through the synchronous boundary call (vp_infer_multi: pageable host frame in, H2D, both
+                               networks, D2H of logits + masks, one sync -- what TensorRTBackend::doInference brackets,
+                               tensorrt_backend.cpp:184-199), one host thread per in-flight engine
+  roofline                   : dominant kernel's ALGORITHMIC TFLOP/s from per-launch HIP events on the engine stream vs
+                               the dense fp16 MFMA peak (2.5 PFLOP/s), plus the whole-frame fraction
+  cpu_baseline               : the CPU oracle (torch fp32 restatement of the reference path) on this box's host cores
+The timed region is floored at >= 1 s: if K steps would take less, K is raised (reported in ``steps``).
+
+Multi-GPU: the path shards by camera: rank r owns camera r, weights replicated, no data-path collective (the
+reference has none) -> "scaling": "weak".  ``--gather`` adds the per-frame RCCL all-gather of the per-camera masks through
+the C ABI (vp_gather), enqueued on the engine's stream behind the frame's graph with no host synchronisation.
 """
 import argparse
 import json
+import math
 import os
+import re
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,17 +45,23 @@ import torch  # noqa: E402  (before libvp_hip: one shared HIP runtime)
 
 PEAK_FP16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 FRAME_GFLOP = {"sceneseg": 367.0, "scene3d": 397.0, "domainseg": 366.6, "egolanes": 196.7}
+BACKBONE_GFLOP = 3.136
+SEEDS = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}
+WORKLOADS = {  # name -> network kinds; the first owns the encoder, the others are shared-prefix heads on it
+    "seg+3d": ("sceneseg", "scene3d"),
+    "seg+3d+ego": ("sceneseg", "scene3d", "egolanes"),
+    "sceneseg": ("sceneseg",), "scene3d": ("scene3d",), "domainseg": ("domainseg",), "egolanes": ("egolanes",),
+}
+
+
+def workload_gflop(kinds):
+    return sum(FRAME_GFLOP[k] for k in kinds) - BACKBONE_GFLOP * (len(kinds) - 1)
 
 
 def pmc_traffic(tag):
     """HBM-side bytes per launch of the kernel instantiation behind ``tag`` from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
+    (profiles/r0N_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
     1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  None if not profiled."""
-    import re
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    ks = json.load(open(path))["kernels"]
     m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
     if m:
         co, px, x, reg = int(m.group(1)), int(m.group(2)), m.group(3), m.group(4)
@@ -55,36 +73,78 @@ def pmc_traffic(tag):
         else:
             pat = (rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'}, "
                    rf"\d, (true|false), {m.group(5) or 0}>")
-    hit = [v for k, v in ks.items() if re.search(pat, k)]
-    n = sum(v["launches_seen"] for v in hit)
-    if not n:
-        return None
-    f = sum(v["fetch_bytes"] * v["launches_seen"] for v in hit) / n
-    w = sum(v["write_bytes"] * v["launches_seen"] for v in hit) / n
-    return {"bytes": round(f + w), "fetch_bytes": round(f), "write_bytes": round(w)}
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        ks = json.load(open(path))["kernels"]
+        hit = [v for k, v in ks.items() if re.search(pat, k)]
+        n = sum(v["launches_seen"] for v in hit)
+        if not n:
+            continue
+        f = sum(v["fetch_bytes"] * v["launches_seen"] for v in hit) / n
+        w = sum(v["write_bytes"] * v["launches_seen"] for v in hit) / n
+        return {"bytes": round(f + w), "fetch_bytes": round(f), "write_bytes": round(w),
+                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_conv.py, average over "
+                          "that instantiation's launches)"}
+    return None
 
 
-def cpu_baseline(kind, sd, frame, seconds, nthreads=0):
-    """The CPU oracle (oracle/nets.py, torch fp32) on `nthreads` host threads (0 = all, capped at 32): whole frames
-    (preprocess + forward + decode) for about `seconds`.  SURVEY.md 8(d) also asks for a per-core figure: --cpu-threads 1
-    (tools/cpu_baseline.py runs this leg alone, no GPU needed)."""
+def cpu_baseline(kinds, sds, frame, seconds, nthreads=0):
+    """The CPU oracle (oracle/nets.py, torch fp32) on `nthreads` host threads (0 = all, capped at 32): whole frames of the
+    same workload for about `seconds`.  Each network runs its own full forward, as the reference's Models/inference classes
+    do (one *NetworkInfer object per network, each with its own backbone pass: scene_seg_infer.py:38-55)."""
     from oracle import nets, pre_post
 
     nthreads = nthreads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(nthreads)
-    tsd = nets.to_torch(sd)
+    tsds = [nets.to_torch(sd) for sd in sds]
+
+    def one():
+        x = torch.from_numpy(pre_post.preprocess(frame))
+        for k, tsd in zip(kinds, tsds):
+            y = nets.forward(k, tsd, x)[0].numpy()
+            pre_post.seg_mask_u8(y) if k != "egolanes" else pre_post.egolanes_priority_mask(y)
+
+    one()  # warm-up
     n_done, t_cpu = 0, 0.0
-    nets.forward(kind, tsd, torch.from_numpy(pre_post.preprocess(frame)))  # warm-up
     while t_cpu < seconds and n_done < 50:
         t1 = time.perf_counter()
-        x = torch.from_numpy(pre_post.preprocess(frame))
-        y = nets.forward(kind, tsd, x)[0].numpy()
-        pre_post.seg_mask_u8(y) if kind != "egolanes" else pre_post.egolanes_priority_mask(y)
+        one()
         t_cpu += time.perf_counter() - t1
         n_done += 1
     return {"value": round(n_done / t_cpu, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n_done} frames of the same 1280x720 workload (preprocess+forward+decode), torch "
-                      f"{torch.__version__} CPU fp32, {t_cpu:.1f} s"}
+            "sample": f"{n_done} frames of the same workload ({'+'.join(kinds)} on one 1280x720 frame: preprocess + "
+                      f"{len(kinds)} full forwards + decode), torch {torch.__version__} CPU fp32, {t_cpu:.1f} s"}
+
+
+class Camera:
+    """One in-flight frame slot: the encoder-owning engine plus its shared-prefix heads, all on one HIP stream."""
+
+    def __init__(self, lib, kinds, blobs, precision, gpu, frame):
+        self.base = lib.Engine(kinds[0], blobs[0], precision=precision, gpu_id=gpu)
+        self.heads = [lib.Engine(k, b, precision=precision, gpu_id=gpu, base=self.base) for k, b in zip(kinds[1:], blobs[1:])]
+        self.frame = frame
+        self.base.upload_frame(frame)  # resident in HBM before any timed region
+        for _ in range(2):             # first pass is eager (sets kernel attributes), second captures the graphs
+            self.enqueue()
+        self.sync()
+
+    def enqueue(self):
+        self.base.enqueue()
+        for h in self.heads:
+            h.enqueue()
+
+    def sync(self):
+        self.base.sync()
+
+    def host_frame(self):
+        self.base.infer_multi(self.heads, self.frame)
+
+    def close(self):
+        for h in self.heads:
+            h.close()
+        self.base.close()
 
 
 def main():
@@ -92,28 +152,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--kind", default="sceneseg")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp16x3"])
+    ap.add_argument("--workload", default="seg+3d", choices=sorted(WORKLOADS))
+    ap.add_argument("--kind", default=None, help="deprecated alias: --workload <kind>")
+    ap.add_argument("--precision", default="fp16x3", choices=["fp16", "fp16x3"],
+                    help="precision of `value`; fp16x3 is the parity mode (default), fp16 is reported beside it as fp16_value")
     ap.add_argument("--frame", default="1280x720")
     ap.add_argument("--streams", type=int, default=3,
-                    help="frames in flight per GPU (independent engines/HIP streams, round-robin): the latency-bound "
+                    help="frames in flight per GPU (independent engines / HIP streams, round-robin): the latency-bound "
                          "encoder of frame n+1 overlaps the MFMA-bound decoder of frame n")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="EXPERIMENTAL, default off: cameras per batched-encoder pass (vp_create_batched + one shared-prefix head per "
-                         "camera); a step is then one pass = BATCH frames.  The reported default configuration is --batch 1")
-    ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="floor of every timed region")
+    ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL through the C ABI)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp16 and host-to-host legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, max 32)")
     ap.add_argument("--latency-iters", type=int, default=100)
     args = ap.parse_args()
+    if args.kind:
+        args.workload = args.kind
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -126,116 +188,143 @@ def main():
 
     from autoware_vision_pilot_amd import lib, synthetic, weights as vw
 
+    kinds = WORKLOADS[args.workload]
     fw, fh = (int(v) for v in args.frame.split("x"))
-    seed = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}[args.kind]
-    sd = synthetic.make_state_dict(args.kind, seed)
-    blob = vw.pack_state_dict(sd)
+    sds = [synthetic.make_state_dict(kinds[0], SEEDS[kinds[0]])]
+    for k in kinds[1:]:  # heads share the first network's backbone, as the reference's pre-trained wrappers do
+        sds.append(synthetic.share_backbone(synthetic.make_state_dict(k, SEEDS[k]), k, sds[0], kinds[0]))
+    blobs = [vw.pack_state_dict(sd) for sd in sds]
     frame = synthetic.synthetic_frame(fh, fw, 10 + rank)  # camera r
-    if args.batch > 1:
-        class Group:  # one batched encoder + one head per camera, all on the encoder's stream
-            def __init__(self):
-                self.enc = lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank, frames=args.batch)
-                self.heads = [lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank, base=self.enc, frame_index=f)
-                              for f in range(args.batch)]
-                for f in range(args.batch):
-                    self.enc.upload_frame(synthetic.synthetic_frame(fh, fw, 10 + rank + 100 * f), index=f)
+    nstreams = max(1, args.streams)
 
-            def enqueue(self):
-                self.enc.enqueue()
-                for h in self.heads:
-                    h.enqueue()
-
-            def sync(self):
-                self.enc.sync()
-
-            def close(self):
-                for h in self.heads:
-                    h.close()
-                self.enc.close()
-
-        engines = [Group() for _ in range(max(1, args.streams))]
-        for e in engines:
-            e.enqueue()
-            e.enqueue()
-            e.sync()
-        eng = engines[0].heads[0]
-        if args.gather:
-            raise SystemExit("--gather is a --batch 1 option")
-    else:
-        engines = [lib.Engine(args.kind, blob, precision=args.precision, gpu_id=local_rank) for _ in range(max(1, args.streams))]
-        eng = engines[0]
-        for e in engines:
-            e.upload_frame(frame)  # resident in HBM before the timed region
-            e.enqueue()            # first pass is eager (sets kernel attributes), second captures the graph
-            e.enqueue()
-            e.sync()
-
-    gather_buf = mask_t = None
-    if args.gather and dist is not None:
-        mask_t = torch.empty(320 * 640 if args.kind != "egolanes" else 80 * 160, dtype=torch.uint8, device="cuda")
-        gather_buf = torch.empty(world * mask_t.numel(), dtype=torch.uint8, device="cuda")
-
-    counter = [0]
-
-    def step():
-        e = engines[counter[0] % len(engines)]
-        counter[0] += 1
-        e.enqueue()
-        if gather_buf is not None:
-            e.copy_outputs_device(None, mask_t.data_ptr())
-            e.sync()
-            dist.all_gather_into_tensor(gather_buf, mask_t)
-
-    def fence():
-        for e in engines:
-            e.sync()
+    def fence(cams):
+        for c in cams:
+            c.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    fps_total = world * args.steps * args.batch / elapsed
+    comms = None
 
-    # ---- per-frame latency (sync per iteration, benchmark.py:17-47 protocol), rank-local
-    lat = []
-    for _ in range(args.latency_iters):
-        t1 = time.perf_counter()
-        (engines[0] if args.batch > 1 else eng).enqueue()  # batch mode: one whole pass (encoder + BATCH heads)
-        (engines[0] if args.batch > 1 else eng).sync()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    lat = np.array(lat)
+    def timed(cams, steps, gather=False):
+        """EXACTLY `steps` frames round-robin over the in-flight slots, fenced on both sides; returns seconds (max over ranks)."""
+        n = len(cams)
+        fence(cams)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            c = cams[i % n]
+            c.enqueue()
+            if gather:
+                comms[i % n].gather(c.base, lib.VP_GATHER_MASK)  # async on the engine's stream, no host sync
+        fence(cams)
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
+    def throughput(cams, steps, warmup, gather=False):
+        timed(cams, max(1, warmup), gather)
+        probe = timed(cams, min(max(steps, 1), 20), gather) / min(max(steps, 1), 20)
+        k = max(steps, int(math.ceil(1.15 * args.min_seconds / max(probe, 1e-6))))
+        if dist is not None:  # every rank must run the same number of steps
+            t = torch.tensor([k], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            k = int(t.item())
+        return k, timed(cams, k, gather)
+
+    def latency(cam, iters):
+        lat = []
+        for _ in range(iters):
+            t1 = time.perf_counter()
+            cam.enqueue()
+            cam.sync()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        return np.array(lat)
+
+    def three_figures(cams, steps, warmup, gather=False):
+        k, el = throughput(cams, steps, warmup, gather)
+        k1, el1 = throughput(cams[:1], max(steps // 3, 1), 3)
+        lat = latency(cams[0], args.latency_iters)
+        return dict(steps=k, elapsed=el, fps=world * k / el, single=k1 / el1,
+                    p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)))
+
+    # ---- the reported configuration
+    cams = [Camera(lib, kinds, blobs, args.precision, local_rank, frame) for _ in range(nstreams)]
+    if args.gather:
+        rec = 320 * 640 if kinds[0] != "egolanes" else 80 * 160
+        comms = []
+        for i in range(nstreams):  # one communicator per engine in flight (RCCL ops of one comm must not overlap)
+            ids = [lib.Comm.unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ids, src=0)
+            comms.append(lib.Comm(ids[0], rank, world, local_rank, rec))
+    main_fig = three_figures(cams, args.steps, args.warmup, args.gather)
+
+    # ---- host-to-host through the synchronous boundary call, one host thread per in-flight engine
+    h2h = None
+    if not args.no_secondary:
+        def host_loop(cam, seconds, out, idx):
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                cam.host_frame()
+                n += 1
+            out[idx] = (n, time.perf_counter() - t0)
+
+        def host_run(seconds):
+            res = [None] * len(cams)
+            ts = [threading.Thread(target=host_loop, args=(c, seconds, res, i)) for i, c in enumerate(cams)]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            wall = time.perf_counter() - t0
+            return sum(r[0] for r in res) / wall
+
+        for c in cams:
+            c.host_frame()
+        host_run(0.2)
+        h2h = {"fps": host_run(max(args.min_seconds, 1.0))}
+        lat = []
+        for _ in range(max(20, args.latency_iters // 2)):
+            t1 = time.perf_counter()
+            cams[0].host_frame()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        h2h["p50"] = float(np.percentile(lat, 50))
+        for c in cams:  # masks only: logits stay in HBM (vp_set_outputs), the hosts that publish the mask never read them
+            c.base.set_outputs(logits=False, mask=True)
+            for h in c.heads:
+                h.set_outputs(logits=(h.kind == "scene3d"), mask=False)  # depth consumers read the fp32 map
+        h2h["fps_masks_only"] = host_run(max(args.min_seconds, 1.0))
+        for c in cams:
+            c.base.set_outputs(True, True)
+            for h in c.heads:
+                h.set_outputs(True, True)
+
+    # ---- roofline of the dominant kernel family of the REPORTED precision: per-launch HIP events (eager replay, one stream)
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel family: per-launch HIP events on the engine stream (eager replay)
-        ms = eng.profile_layers(10)
-        layers, kernels = eng.layers(), eng.layer_kernels()
+        engs = [cams[0].base] + cams[0].heads
+        rows = []
+        for e in engs:
+            ms = e.profile_layers(10)
+            rows += list(zip(e.layers(), e.layer_kernels(), [float(t) for t in ms]))
         fam = {}
-        for (name, fl, by), k, t in zip(layers, kernels, ms):
+        for (name, fl, by), k, t in rows:
             f = fam.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, worst=("", 0.0)))
-            f["ms"] += float(t)
+            f["ms"] += t
             f["flops"] += fl
             f["bytes"] += by
             f["n"] += 1
             if t > f["worst"][1]:
-                f["worst"] = (name, float(t))
-        # dominant = the single kernel instantiation (= one rocprofv3 kernel name) with the largest total time; "+splitk"
-        # ops are two launches (conv + finish kernel) per timing interval, so they cannot give a per-kernel duration
-        # The path is a dense contraction (bound = MFMA): the roofline kernel is the instantiation with the
-        # largest total time among those carrying >= 5 % of the frame's FLOPs; `by_time` lists the top kernels of ANY kind
-        # (the latency-bound depthwise launches are within a few us of it in eager timing) with their own bound and fraction.
+                f["worst"] = (name, t)
+        tot_ms = sum(t for _, _, t in rows)
+        # The path is a dense contraction (SURVEY.md 8d: bound = MFMA): the roofline kernel is the single instantiation
+        # (= one rocprofv3 kernel name) with the largest total time among those carrying >= 5 % of the frame's FLOPs;
+        # "+splitk" ops are two launches per timing interval and cannot give a per-kernel duration.
         single = [k for k in fam if "+splitk" not in k]
         tot_fl = sum(f["flops"] for f in fam.values())
         heavy = [k for k in single if fam[k]["flops"] >= 0.05 * tot_fl]
@@ -248,54 +337,86 @@ def main():
                 return "mfma", f["flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS
             return "hbm", f["bytes"] / (f["ms"] * 1e-3) / 1e9 / 8000.0
 
-        by_time = [{"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / float(ms.sum()), 3),
+        by_time = [{"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / tot_ms, 3),
                     "bound": frac_of(k)[0], "frac": round(frac_of(k)[1], 4)}
-                   for k in sorted(single, key=lambda k: -fam[k]["ms"])[:4]]
-        frame_tflops = FRAME_GFLOP[args.kind] * (fps_total / world) / 1e3
+                   for k in sorted(single, key=lambda k: -fam[k]["ms"])[:5]]
+        gflop = workload_gflop(kinds)
+        frame_tflops = gflop * (main_fig["fps"] / world) / 1e3
         if dom.startswith("conv"):
             achieved, peak, unit, bound = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_FP16_TFLOPS, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = d["bytes"] / (d["ms"] * 1e-3) / 1e9, 8000.0, "GB/s", "hbm"
-        tr = pmc_traffic(dom) if args.precision == "fp16" and args.kind == "sceneseg" else None
+        tr = pmc_traffic(dom)
+        mfma_per_product = 3 if args.precision == "fp16x3" else 1
         roofline = {
             "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": (tr or {}).get("bytes"),
-            "traffic_detail": dict(tr, source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                              "tools/pmc_conv.py, average over that instantiation's launches)") if tr else None,
+            "frac": round(achieved / peak, 4), "traffic": (tr or {}).get("bytes"), "traffic_detail": tr,
             "kernel": dom, "launches_per_frame": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
             "algorithmic_mb_per_launch": round(d["bytes"] / d["n"] / 1e6, 3),
+            "mfma_issue_frac": round(mfma_per_product * achieved / peak, 4) if bound == "mfma" else None,
             "slowest_layer": d["worst"][0], "slowest_layer_us": round(1e3 * d["worst"][1], 1),
-            "kernel_time_share": round(d["ms"] / float(ms.sum()), 3), "by_time": by_time,
+            "kernel_time_share": round(d["ms"] / tot_ms, 3), "by_time": by_time,
             "whole_frame": {"achieved": round(frame_tflops, 2), "frac": round(frame_tflops / PEAK_FP16_TFLOPS, 4),
-                            "gflop_per_frame": FRAME_GFLOP[args.kind], "unit": "TFLOP/s"},
-            "sustained_mfma_peak": {"value": 1700.0, "unit": "TFLOP/s",
-                                    "note": "bare v_mfma_f32_32x32x16_f16 loop on this GPU: 1570-1820 TFLOP/s, shader clock drops to "
-                                            "1.55-1.85 GHz under MFMA load (tools/mfma_peak.hip, profiles/r01_mfma_peak.txt)"},
-            "note": "per-launch HIP events on the engine stream (eager replay, single stream); fp16x3 issues 3 MFMAs per "
-                    "algorithmic product, achieved counts algorithmic FLOPs only",
+                            "mfma_issue_frac": round(mfma_per_product * frame_tflops / PEAK_FP16_TFLOPS, 4),
+                            "gflop_per_frame": round(gflop, 1), "unit": "TFLOP/s"},
+            "note": "per-launch HIP events on the engine stream (eager replay, single stream); `achieved` counts ALGORITHMIC "
+                    "FLOPs (one multiply-add per product); fp16x3 issues 3 fp16 MFMAs per product, `mfma_issue_frac` = "
+                    "issued MFMA FLOPs / peak",
         }
+        prec_name = {"fp16": "fp16", "fp16x3": "fp16x3 (hi+lo fp16 pairs on the fp16 MFMA pipe, fp32 accumulate; fp32-class: "
+                                               "class maps bit-exact, floats within 1e-3 of the fp32 oracle)"}[args.precision]
+        names = {"sceneseg": "SceneSeg", "scene3d": "Scene3D", "egolanes": "EgoLanes", "domainseg": "DomainSeg"}
+        wl = "+".join(names[k] for k in kinds)
         out = {
-            "metric": "frames/sec (SceneSeg 1280x720 -> 640x320 net input, preprocess+forward+decode)",
-            "value": round(fps_total, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp16" if args.precision == "fp16" else "fp16x3(fp32-class)", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.kind} {fw}x{fh} batch=1, one camera per GPU, {args.precision}",
-                       "frames_per_step_per_gpu": args.batch, "batched_encoder": args.batch > 1, "net_input": "1x3x320x640", "gather": bool(args.gather),
-                       "frames_in_flight_per_gpu": len(engines)},
-            "fps_per_gpu": round(fps_total / world, 2),
-            "p50_ms": round(float(np.percentile(lat, 50)), 4), "p99_ms": round(float(np.percentile(lat, 99)), 4),
-            # FpsTimer-style split (common/benchmark/fps_timer.cpp:37-63) from the per-launch HIP events (eager, single stream)
-            "split_us": {"preprocess": round(1e3 * sum(float(t) for (n, _, _), t in zip(layers, ms) if n == "preprocess"), 1),
-                         "inference": round(1e3 * sum(float(t) for (n, _, _), t in zip(layers, ms) if n not in ("preprocess", "decode")), 1),
-                         "output_decode": round(1e3 * sum(float(t) for (n, _, _), t in zip(layers, ms) if n == "decode"), 1)},
+            "metric": f"frames/sec ({wl} {fw}x{fh}, one camera per GPU: preprocess + shared encoder + "
+                      f"{len(kinds)} decoder(s) + decode per frame); p50 per-frame latency beside it",
+            "value": round(main_fig["fps"], 2), "unit": "frames/s", "n_gpus": world, "steps": main_fig["steps"],
+            "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * main_fig["elapsed"] / main_fig["steps"], 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": prec_name, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json metric configuration: {wl} on one {fw}x{fh} camera per GPU, batch 1, "
+                                   f"shared EfficientNet-B0 encoder (vp_create_shared), {args.precision}",
+                       "precision": args.precision, "parity_mode": args.precision == "fp16x3",
+                       "frames_in_flight_per_gpu": nstreams, "net_input": "1x3x320x640", "gather": bool(args.gather),
+                       "gflop_per_frame": round(gflop, 1), "timed_region_s": round(main_fig["elapsed"], 3)},
+            "fps_per_gpu": round(main_fig["fps"] / world, 2),
+            "single_stream_fps": round(main_fig["single"], 2),
+            "p50_ms": round(main_fig["p50"], 4), "p99_ms": round(main_fig["p99"], 4),
             "roofline": roofline,
         }
-        # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.kind, sd, frame, args.cpu_seconds, args.cpu_threads)
-    for e in engines:
-        e.close()
+        if h2h is not None:
+            out["host_to_host_fps"] = round(h2h["fps"], 2)
+            out["host_to_host_p50_ms"] = round(h2h["p50"], 4)
+            out["host_to_host_masks_only_fps"] = round(h2h["fps_masks_only"], 2)
+            out["host_to_host_note"] = (f"vp_infer_multi per frame from {nstreams} host threads (one per in-flight engine): pageable "
+                                        f"{fw}x{fh}x3 frame -> pinned staging -> H2D, all networks, D2H of every network's fp32 logits "
+                                        "+ u8 mask, one sync; p50 = one thread alone; masks_only = logits left in HBM "
+                                        "(vp_set_outputs) except Scene3D's depth map")
+    for c in cams:
+        c.close()
+    if comms:
+        for cm in comms:
+            cm.close()
+
+    # ---- the other precision beside it (fp16 when value is the parity mode, and vice versa)
+    if not args.no_secondary:
+        other = "fp16" if args.precision == "fp16x3" else "fp16x3"
+        cams2 = [Camera(lib, kinds, blobs, other, local_rank, frame) for _ in range(nstreams)]
+        fig2 = three_figures(cams2, args.steps, max(3, args.warmup // 3))
+        for c in cams2:
+            c.close()
+        if rank == 0:
+            tag = "fp16" if other == "fp16" else "fp16x3"
+            out[f"{tag}_value"] = round(fig2["fps"], 2)
+            out[f"{tag}_single_stream_fps"] = round(fig2["single"], 2)
+            out[f"{tag}_p50_ms"] = round(fig2["p50"], 4)
+            out[f"{tag}_note"] = ("plain fp16 tensors / one MFMA per product: the reference's 'fp16' configuration; ~2e-2 max error "
+                                  "vs the fp32 oracle, NOT parity-grade" if other == "fp16" else "parity mode beside an fp16 headline")
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kinds, sds, frame, args.cpu_seconds, args.cpu_threads)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -129,8 +129,21 @@ int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order);
 int vp_set_decode_mode(vp_engine* e, int decode_mode);
 int vp_input_hw(const vp_engine* e, int* h, int* w);
 
+/* Which outputs vp_infer / vp_infer_shared / vp_infer_multi copy to the host before they return (default both, what
+ * TensorRTBackend::doInference does: tensorrt_backend.cpp:184-199).  A de-selected output stays in HBM and is copied on the
+ * first vp_logits / vp_mask_u8 call instead: a host that only consumes the decoded mask (RunModelNode publishes the mask,
+ * run_model_node.cpp:173-190) saves the 2.4 MB fp32 logits transfer per frame. */
+enum vp_output_bits { VP_OUT_LOGITS = 1, VP_OUT_MASK = 2 };
+int vp_set_outputs(vp_engine* e, int output_bits);
+/* vp_infer stages the caller's pageable frame through a pinned double buffer owned by the engine (default 1). */
+int vp_set_pinned_staging(vp_engine* e, int enable);
+
 /* ---- synchronous per-frame path (host buffers in, host buffers out) -------------------------------------- */
 int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes);
+/* One frame through a base engine AND its shared-prefix heads (BASELINE metric: SceneSeg + Scene3D on one camera): one H2D,
+ * all networks enqueued back to back on the base engine's stream, the selected outputs of every engine copied D2H behind
+ * them, ONE host synchronisation -- instead of vp_infer + n x vp_infer_shared (n + 1 synchronisations). */
+int vp_infer_multi(vp_engine* base, vp_engine* const* shared, int n_shared, const uint8_t* frame, int h, int w, int stride_bytes);
 int vp_infer_tensor(vp_engine* e, const float* nchw_1x3x320x640);
 /* AutoDrive.forward(image_prev, image_curr) (autodrive_network.py:32-36): backbone on `prev`, then backbone + head on `curr`.
  * Plain vp_infer on a VP_AUTODRIVE engine is the streaming form: the previous call's frame is `prev` (the first frame of
@@ -138,13 +151,20 @@ int vp_infer_tensor(vp_engine* e, const float* nchw_1x3x320x640);
 int vp_infer_pair(vp_engine* e, const uint8_t* prev, const uint8_t* curr, int h, int w, int stride_bytes);
 int vp_logits(const vp_engine* e, const float** data, int64_t shape[4]);       /* host pointer, valid until next infer */
 int vp_mask_u8(const vp_engine* e, const uint8_t** data, int* h, int* w);      /* host pointer, network resolution */
+/* MasksVisualizationKernels::createMaskFromTensor{CUDA,HIP}(const float* host_tensor, shape, cv::Mat&) and
+ * createEgoLanesMaskFromTensorCUDA (common/include/masks_visualization_kernels.hpp:14-45; Zenoh models/run_model.cpp): stateless,
+ * HOST logits in, u8 mask out at tensor resolution, decode_mode as vp_decode_mode.  adapters/masks_visualization_kernels_hip.hpp
+ * gives it the reference's exact signature (and skips the upload when the tensor is an engine's own logits). */
+int vp_decode_logits_host(int gpu_id, const float* logits_nchw, int channels, int h, int w, int decode_mode, uint8_t* mask_out);
 int vp_mask_resized_u8(vp_engine* e, uint8_t* dst, int h, int w);              /* nearest, to frame size */
 int vp_depth_resized_f32(vp_engine* e, float* dst, int h, int w);              /* bilinear, plane 0 of the logits */
 /* MasksVisualizationEngine::visualize (middleware_recipes/common/visualizers/masks_visualization_engine.cpp:11-58, SURVEY.md
  * 8f N4): colour LUT on the last mask (viz_type: 0 "scene", 1 "domain", 2 "egolanes" -- use VP_DECODE_LANE_LABEL for it),
  * nearest resize to the frame of the last vp_infer, 50/50 blend with that frame.  dst: BGR8 [frame_h][frame_w][3], packed. */
 enum vp_viz_type { VP_VIZ_SCENE = 0, VP_VIZ_DOMAIN = 1, VP_VIZ_EGOLANES = 2 };
-int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst_bgr8);
+/* h, w: geometry of dst; VP_ERR_ARG unless it equals the last inferred frame's (the reference reads the size off original_image). */
+int vp_visualize_mask_bgr8(vp_engine* e, int viz_type, uint8_t* dst_bgr8, int h, int w);
+int vp_frame_hw(const vp_engine* e, int* h, int* w);                           /* geometry of the last uploaded frame */
 /* DepthVisualizationEngine::visualize (middleware_recipes/common/visualizers/depth_visualization_engine.cpp:9-26): plane 0 of
  * the logits bilinear-resized to h x w (the map vp_depth_resized_f32 returns, run_model_node.cpp:100-104), min-max
  * normalised to u8 (convertTo with alpha = 255/(max-min), beta = -min*alpha; all zero if max == min) and mapped through
@@ -163,6 +183,32 @@ int vp_copy_outputs_device(vp_engine* e, void* logits_dst, void* mask_dst);   /*
 int vp_use_graph(vp_engine* e, int enable);                                    /* hipGraph replay (default on) */
 int vp_timer_begin(vp_engine* e);                                              /* hipEvent on the engine stream */
 int vp_timer_end(vp_engine* e, float* elapsed_ms);                             /* records, syncs, returns elapsed */
+
+/* ---- multi-camera result exchange (BASELINE configs[3]) ---------------------------------------
+ * One process (or thread) per GPU, camera r on rank r, weights replicated, no data-path collective in the networks.  For the
+ * fused ego-path / BEV consumer every rank needs all cameras' results: ONE ncclAllGather (RCCL over xGMI) per frame of a
+ * fixed-size record -- the u8 mask (320x640 = 204.8 KB; EgoLanes label map 80x160 = 12.8 KB) or the fp32 logits (EgoLanes
+ * 3x80x160 = 153.6 KB) -- enqueued on the ENGINE's stream behind the frame's graph, no host synchronisation:
+ *     rank 0: vp_comm_unique_id(id);  host distributes the 128 bytes (ROS parameter / file / MPI / ...)
+ *     all   : vp_comm_create(&c, id, rank, world, gpu, record_bytes_max, ...)
+ *     frame : vp_enqueue(e);  vp_gather(e, c, VP_GATHER_MASK);            // overlaps the next in-flight frame's encoder
+ *     read  : vp_comm_device_buffer (device consumer) or vp_comm_fetch (host copy, synchronises).
+ * RCCL is bound with dlopen at the first vp_comm_* call (librccl.so is not a load-time dependency of libvp_hip.so).
+ * One communicator per engine in flight: RCCL operations on one communicator must not run concurrently on two streams.
+ * The reference has no counterpart (single camera per backend instance). */
+typedef struct vp_comm vp_comm;
+#define VP_COMM_ID_BYTES 128
+enum vp_gather_what { VP_GATHER_MASK = 0, VP_GATHER_LOGITS = 1 };
+int vp_comm_unique_id(void* id_out_128, char* err, size_t err_len);
+int vp_comm_create(vp_comm** out, const void* unique_id_128, int rank, int world, int gpu_id, size_t record_bytes_max, char* err,
+                   size_t err_len);
+void vp_comm_destroy(vp_comm* c);
+const char* vp_comm_last_error(const vp_comm* c);
+int vp_comm_rank(const vp_comm* c);
+int vp_comm_world(const vp_comm* c);
+int vp_gather(vp_engine* e, vp_comm* c, int what);                              /* async, on the engine's stream */
+int vp_comm_device_buffer(const vp_comm* c, void** dev, size_t* record_bytes);  /* [world][record_bytes] */
+int vp_comm_fetch(vp_comm* c, vp_engine* e, const void** host, size_t* record_bytes); /* D2H + sync; pinned, valid until next fetch */
 
 /* ---- introspection (profiling, per-layer parity tests) --------------------------------------------------- */
 int vp_layer_count(const vp_engine* e);

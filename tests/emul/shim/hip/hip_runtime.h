@@ -441,6 +441,7 @@ typedef emu::Graph* hipGraph_t;
 typedef emu::Graph* hipGraphExec_t;
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
@@ -456,6 +457,10 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
     return hipSuccess;
   }
   std::memmove(d, s, n);
+  return hipSuccess;
+}
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+  for (size_t y = 0; y < height; ++y) std::memmove(static_cast<char*>(d) + y * dpitch, static_cast<const char*>(s) + y * spitch, width);
   return hipSuccess;
 }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(1); return hipSuccess; }

@@ -46,7 +46,9 @@ def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, engines, mtype, kind
     assert np.array_equal(rest[:n].view(np.float32).reshape(lg.shape), lg)
     tail = rest[n:]
     if kind == "sceneseg":
-        assert np.array_equal(tail.reshape(720, 1280), pre_post.resize_nearest_u8(pre_post.seg_mask_u8(lg), 720, 1280))
+        assert np.array_equal(tail[:720 * 1280].reshape(720, 1280), pre_post.resize_nearest_u8(pre_post.seg_mask_u8(lg), 720, 1280))
+        # MasksVisualizationKernels::createMaskFromTensorHIP (reference signature) on the backend's own tensor
+        assert np.array_equal(tail[720 * 1280:].reshape(320, 640), pre_post.seg_mask_u8(lg))
     elif kind == "scene3d":
         assert np.array_equal(tail.view(np.float32).reshape(720, 1280), pre_post.resize_bilinear_f32(lg[0], 720, 1280))
     else:
