@@ -26,12 +26,22 @@ Parity pinning status
 * EfficientNet-B0 ``.features`` (torchvision, third-party, absent from
   /root/reference and from this image; requirement ``torchvision>=0.22.0``
   un-pinned, Models/requirements.txt:16; call sites Models/model_components/
-  backbone.py:9,13-21): **parity unpinned** -- restated from the published
-  architecture, anchored only on the reference call sites and channel counts.
+  backbone.py:9,13-21): restated from the published architecture and **pinned
+  against an independent implementation** -- ``oracle/pin_backbone_hf.py`` loads
+  the same seeded weights into HuggingFace ``transformers``' EfficientNet (B0
+  scale, BatchNorm eps 1e-5; its TensorFlow-style one-sided stride-2 pads replaced
+  by torchvision's symmetric (k-1)//2) and compares the stem, all 16 MBConv blocks
+  and the top conv: max difference 0.0.  Fixture ``tests/golden/backbone_hf_pin.npz``;
+  the live comparison also runs in the CPU suite.  What stays unpinned is only
+  "torchvision itself was never executed here" (its published definition is what
+  both implementations follow).
 * resize (OpenCV ``cv::resize`` INTER_LINEAR u8 / Pillow): **parity unpinned** --
   third-party arithmetic, no reference test fixes it.  We define our own
   integer bilinear (modelled on OpenCV's 11-bit fixed-point scheme) and pin the
-  engine to *that* definition bit-exactly.
+  engine to *that* definition bit-exactly.  OpenCV's silent INTER_LINEAR ->
+  INTER_AREA switch at an exact 2x downscale (e.g. 1280x640 frames) needs no
+  branch: with half-pixel centres the exact-2x bilinear IS the 2x2 box average
+  with the same rounding (tests/test_oracle_golden.py).
 * decode (argmax / threshold / lane priority mask): pinned by construction --
   restated line by line from the reference's C++ loops and checked against
   ``torch.max`` here.

@@ -91,6 +91,9 @@ int main(int argc, char** argv) {
       if (quick && tile != 1) continue;
       bad |= conv(precision, 0, 96, 40, 7, 13, 1, 2, tile, tile == 2 ? 64 : 32, tile == 1 ? 2 : 1);
     }
+    if (precision == 1 || quick) {  // 8-wave fp16x3 kernel: 3 weight buffers, cross-tap fragment prefetch, 2 chunks
+      bad |= conv(1, 0, 64, 128, 17, 19, 3, 1, 106, -1, 1);
+    }
     bad |= conv(precision, 0, 32, 40, 5, 8, 3, 1, 1, 32, 1);                                                                                  // generic 3x3
     bad |= conv(precision, 1, 64, 48, 5, 6, 2, 0, -1, -1, -1);                                                                                // ConvTranspose GEMM
     bad |= conv(precision, 1, 128, 64, 4, 8, 2, 1, -1, -1, -1);                                                                               // short-K ConvTranspose GEMM

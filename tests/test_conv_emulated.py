@@ -77,6 +77,23 @@ def test_halo_3x3_kernel_every_tile(emu_lib, precision):
     _case(emu_lib, 40, 24, 16, 16, 3, 0, 0, 1, precision, [(103, -1, 1), (104, -1, 2)], seed=2)
 
 
+def test_x3w8_kernel(emu_lib):
+    """kernels_conv3x3_x3.hip (halo tile 6): the 8-wave fp16x3 kernel -- fragment prefetch across tap and chunk boundaries,
+    three weight buffers, register epilogue with both planes; one and several 32-channel chunks, GELU and no activation,
+    an image that is not a multiple of the 16x16 patch, two output-channel tiles; bit-identical to halo tile 1 (same K order)."""
+    _case(emu_lib, 32, 128, 16, 32, 3, 0, 1, 0, 1, [(106, -1, 1)], seed=21)
+    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 1, [(106, -1, 1)], seed=22)
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((64, 18, 33), dtype=np.float32)
+    wt = rng.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.float32(0.06)
+    b = rng.standard_normal((128,), dtype=np.float32) * np.float32(0.1)
+    a = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=106, nsplit=1)
+    c = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=101, nsplit=1)
+    assert np.array_equal(a, c)
+    with pytest.raises(emu_lib.VpError):
+        emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # fp16 engines have no tile 6
+
+
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
 def test_generic_gemm_kernel(emu_lib, precision):
     """kernels_conv.hip: implicit GEMM, all four tiles, both K blocks, split-K, 1x1 (K1 fast path incl. the register

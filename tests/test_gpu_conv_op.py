@@ -81,6 +81,25 @@ def test_conv_op_matches_torch(case, precision):
         assert err.max() <= tol, f"tile={tile} bk={bk} nsplit={nsplit}: max rel err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
 
 
+@pytest.mark.parametrize("cin,cout,h,w,act", [(128, 128, 64, 96, 1), (96, 256, 35, 50, 0), (512, 128, 32, 32, 1), (32, 384, 16, 16, 1)])
+def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
+    """kernels_conv3x3_x3.hip (halo tile 6, fp16x3 only): 8-wave workgroups, fragments prefetched across tap / chunk
+    boundaries, three weight buffers, register epilogue.  Same K order as halo tile 1 => bit-identical to it."""
+    from autoware_vision_pilot_amd import lib
+
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    wt = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+    ref = _reference(x, wt, b, 3, 0, act, None, 0, fp16=False)
+    got = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=106, nsplit=1)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= 2e-5, err.max()
+    assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=101, nsplit=1))
+    with pytest.raises(lib.VpError):
+        lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=106, nsplit=1)
+
+
 def test_conv_op_transpose_detecting():
     """Identity weights with an asymmetric input: catches a swapped output-channel/pixel mapping of the MFMA result."""
     from autoware_vision_pilot_amd import lib

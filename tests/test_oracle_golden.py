@@ -124,3 +124,50 @@ def test_decode_definitions():
     assert np.array_equal(pre_post.resize_nearest_u8(m, 17, 23), m)
     assert np.array_equal(pre_post.resize_nearest_u8(m, 34, 46), np.repeat(np.repeat(m, 2, 0), 2, 1))
     assert np.array_equal(pre_post.resize_bilinear_f32(lg[0], 17, 23), lg[0])
+
+
+def test_backbone_against_independent_implementation_fixture():
+    """a4 pin: the EfficientNet-B0 restatement vs values sampled from HuggingFace transformers' EfficientNet (an independent
+    implementation of the published network) carrying the SAME seeded weights, stride-2 pads made symmetric as torchvision's
+    (oracle/pin_backbone_hf.py wrote the fixture; measured difference 0.0 on all 16 MBConv blocks, stem and top conv)."""
+    from oracle import pin_backbone_hf as pin
+
+    g = np.load(pin.GOLDEN)
+    h, w = (int(v) for v in g["hw"])
+    prefix = weights.PREFIX["sceneseg"]["backbone"]
+    sd_t = nets.to_torch(weights.make_state_dict("sceneseg", int(g["seed"])))
+    image = torch.from_numpy(np.random.default_rng(int(g["image_seed"])).standard_normal((1, 3, h, w)).astype(np.float32))
+    outs = pin.oracle_blocks(sd_t, prefix, image)
+    assert len(outs) == 18
+    for i, y in enumerate(outs):
+        got = y.reshape(-1)[torch.from_numpy(g[f"idx{i}"])].numpy()
+        want = g[f"val{i}"]
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, float(np.abs(want).max())), i
+
+
+def test_backbone_against_transformers_live():
+    """The same comparison executed live where transformers is importable (this image): every block, bit for bit."""
+    pytest.importorskip("transformers")
+    from oracle import pin_backbone_hf as pin
+
+    prefix = weights.PREFIX["sceneseg"]["backbone"]
+    sd = weights.make_state_dict("sceneseg", 7)
+    m = pin.build_hf()
+    pin.load_oracle_weights(m, sd, prefix)
+    image = torch.from_numpy(np.random.default_rng(5).standard_normal((1, 3, 64, 96)).astype(np.float32))
+    a, b = pin.oracle_blocks(nets.to_torch(sd), prefix, image), pin.hf_blocks(m, image)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert float(((x - y).abs() / y.abs().clamp(min=1.0)).max()) <= 1e-5, i
+
+
+def test_exact_2x_downscale_is_the_box_average():
+    """cv::resize(INTER_LINEAR) switches to INTER_AREA when both scale factors are exactly 2 (e.g. a 1280x640 frame for the
+    640x320 network input; imgproc resize.cpp).  With half-pixel centres an exact 2x bilinear samples midway between two
+    source pixels per axis, i.e. it IS the 2x2 box average, and the integer bilinear's rounding ((sum + 2) >> 2) equals
+    INTER_AREA's rounding of that average: no special case is needed -- checked here against a direct 2x2 mean."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(640, 1280, 3), dtype=np.uint8)
+    got = pre_post.resize_bilinear_u8(img, 320, 640)
+    s = img.astype(np.int32)
+    box = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(got, box.astype(np.uint8))
