@@ -397,10 +397,10 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
-    if (ht == 6) {
-      if (!conv3x3_x3w8_supported(p)) throw std::invalid_argument("halo tile 6 (8-wave fp16x3 kernel): conv + bias + {GELU, none}, NHWC, 128-channel tiles, no split-K: " + name);
-      op.kernel = "conv3x3_x3w8<co128,px256>";
-      op.run = [p](hipStream_t st) { return launch_conv3x3_x3w8(p, st); };
+    if (ht == 6 || ht == 7) {
+      if (!conv3x3_x3_supported(p)) throw std::invalid_argument("halo tiles 6 / 7 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128-channel tiles, no split-K: " + name);
+      op.kernel = ht == 6 ? "conv3x3_x3w8<co128,px256>" : "conv3x3_x3w4<co128,px128>";
+      op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
     }
@@ -458,16 +458,21 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       }
     }
     if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
-    // parity mode, 128-channel tiles, enough 16x16 patches to need no split-K: the 8-wave pipelined kernel (halo tile 6)
+    // parity mode, 128-channel tiles, enough patches to need no split-K: the pipelined kernels of kernels_conv3x3_x3.hip --
+    // halo tile 7 (8x16 patches, two independent workgroups per CU) or 6 (16x16 patches, one 8-wave workgroup per CU)
     {
-      static const char* env8 = std::getenv("VP_X3W8");
+      static const char* envx = std::getenv("VP_X3_TILE");  // developer knob: 0 = halo kernel, 6 / 7 = force that shape
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
-      const long long wgs = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128);
-      if (split() && o.tile < 0 && !(env8 && env8[0] == '0') && (halo == 1 || halo == 3) && ncols % 128 == 0 && wgs >= 160 &&
+      const long long wgs16 = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128);
+      // measured per layer (profiles/r02_layers_*): the 4-wave shape wins where the K loop is short (Cin <= 128: prologue and
+      // epilogue weigh most and two independent workgroups per CU overlap them), the 8-wave shape elsewhere (half the weight
+      // staging per MFMA)
+      const int want = envx ? std::atoi(envx) : (cin_pad <= 128 ? 7 : 6);
+      if (split() && o.tile < 0 && want != 0 && (halo == 1 || halo == 3) && ncols % 128 == 0 && wgs16 >= 160 &&
           (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !o.logits_out && !o.in2)
-        halo = 6;
+        halo = want == 6 ? 6 : 7;
     }
-    if (halo == 6 && !split()) throw std::invalid_argument("halo tile 6 is the fp16x3 kernel: " + name);
+    if ((halo == 6 || halo == 7) && !split()) throw std::invalid_argument("halo tiles 6 / 7 are fp16x3 kernels: " + name);
   }
   // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
   // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
@@ -526,7 +531,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       ns = std::min(ns, std::max(1, KC / 2));
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
-    if (halo == 6) pc.nsplit = 1;  // one 512-thread workgroup per CU: >= 160 tiles already cover most of the machine
+    if (halo == 6 || halo == 7) pc.nsplit = 1;  // >= 160 (16x16) tiles already cover most of the machine; no split-K path
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }
@@ -536,7 +541,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       for (int t = 0; t < taps; ++t) {
         const float v = w[((size_t)co * cin + ci) * taps + t];
         // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
-        const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + (ci & 31))
+        // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
+        // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
+        const int ci_sw = (halo == 6 || halo == 7) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
+        const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;
         split_half(v, &h, &l);

@@ -274,11 +274,12 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
 }
 
 // halo tile ids: 0 = 128co x (16x16)px, 1 = 128co x (8x16)px, 2 = 64co x (16x16)px, 3 = 64co x (8x16)px, 4 = 32co x (8x16)px,
-//                5 = 32co x (16x16)px, 6 = 128co x (16x16)px with 8 waves, fp16x3 only (kernels_conv3x3_x3.hip)
+//                5 = 32co x (16x16)px; fp16x3 only (kernels_conv3x3_x3.hip): 6 = 128co x (16x16)px with 8 waves,
+//                7 = 128co x (8x16)px with 4 waves, two workgroups per CU
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st) {
 #define VP_HCASE(T, CO, TH, TW, WCO, WPX) \
   if (tile == T) return split ? launch_halo_cfg<CO, TH, TW, WCO, WPX, true>(p, st) : launch_halo_cfg<CO, TH, TW, WCO, WPX, false>(p, st);
-  if (tile == 6) return split ? launch_conv3x3_x3w8(p, st) : hipErrorInvalidValue;  // 8-wave parity-mode kernel (kernels_conv3x3_x3.hip)
+  if (tile == 6 || tile == 7) return split ? launch_conv3x3_x3(p, tile, st) : hipErrorInvalidValue;  // pipelined parity-mode kernels (kernels_conv3x3_x3.hip)
   if (tile == 3 && !split) return launch_halo_cfg<64, 8, 16, 1, 4, false>(p, st);
   VP_HCASE(1, 128, 8, 16, 2, 2)
   VP_HCASE(3, 64, 8, 16, 2, 2)
@@ -291,7 +292,7 @@ hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hi
   if (tile == 2) return split ? hipErrorInvalidValue : launch_halo_cfg<64, 16, 16, 1, 4, false>(p, st);
   return hipErrorInvalidValue;
 }
-int halo_tile_co(int tile) { return (tile <= 1 || tile == 6) ? 128 : (tile <= 3 ? 64 : 32); }
+int halo_tile_co(int tile) { return (tile <= 1 || tile == 6 || tile == 7) ? 128 : (tile <= 3 ? 64 : 32); }
 int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 256 : 128; }
 int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 16 : 8; }
 

@@ -1,40 +1,64 @@
-// 3x3 / stride 1 / pad 1 convolution of the PARITY mode (VP_FP16X3) on large maps: 8-wave workgroups, software-pipelined
-// MFMA fragments.
+// 3x3 / stride 1 / pad 1 convolution of the PARITY mode (VP_FP16X3) on large maps: software-pipelined MFMA fragments,
+// two waves per SIMD.
 //
 // In fp16x3 every tensor is a (hi, lo) fp16 pair and every product is three MFMAs, so the halo kernel's LDS plan
 // (kernels_conv3x3.hip) doubles: its 128-channel tile needs 90 KiB, ONE 4-wave workgroup per CU, one wave per SIMD --
 // and that lone wave alternates "ds_read fragments -> wait -> MFMA -> stage -> barrier", leaving the matrix pipe idle for
-// every LDS round trip (measured 265-290 TFLOP/s algorithmic = 32 % of the fp16 MFMA peak on the six big decoder layers,
-// which are 45 % of a SceneSeg + Scene3D frame).  This kernel keeps the data flow (halo tile resident in LDS, one weight
-// tile per tap, XCD-aware tile map, identical K order => bit-identical accumulation) and changes the execution shape:
-//   * 512 threads = 8 waves on a 16x16-pixel x 128-channel tile: two waves per SIMD share the matrix pipe, each wave owns
-//     64 channels x 64 pixels (2 x 2 MFMA tiles, 12 MFMAs per 16-channel K step);
-//   * fragments are prefetched ONE K SUB-STEP AHEAD (the 8 ds_read_b128 of sub-step k+1 are issued before the 12 MFMAs
-//     of sub-step k), across tap boundaries too: a THIRD weight buffer in LDS makes tap t+1's weights resident before
-//     tap t starts, the next tap's pixel operand is the same halo image at a shifted address, and the next chunk's halo
-//     is complete five taps before it is needed.  Only the barrier is left at a tap boundary;
-//   * weights and halo pieces travel global -> registers (3-deep rings, issued 3 taps ahead) -> LDS as before;
+// every LDS round trip (measured 265-290 TFLOP/s algorithmic = 32 % of the fp16 MFMA peak on the big decoder layers,
+// which are half of a SceneSeg + Scene3D frame).  The kernels here keep the data flow (halo tile resident in LDS, one weight
+// tile per tap, XCD-aware tile map, identical K order => bit-identical accumulation) and change the execution shape:
+//   * every wave owns 64 channels x 64 pixels (2 x 2 MFMA tiles, 12 MFMAs per 16-channel K sub-step) and TWO waves share
+//     each SIMD's matrix pipe;
+//   * fragments are prefetched ONE K SUB-STEP AHEAD (the 8 ds_read_b128 of sub-step k+1 are issued before the 12 MFMAs of
+//     sub-step k), across tap boundaries too: a THIRD weight buffer in LDS makes tap t+1's weights resident before tap t
+//     starts and the next tap's pixel operand is the same halo image at a shifted address.  The per-tap barrier sits
+//     BETWEEN the two K sub-steps of a tap, where no prefetch is in flight (a barrier drains the LDS queue);
+//   * weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no VGPRs, no
+//     ds_write): the host packs each (chunk, tap) tile in its LDS IMAGE order (XOR-swizzled 16-byte chunks), so a linear
+//     copy lands conflict-free; tile s+2 is requested when step s starts and awaited (vmcnt) before step s's barrier.
+//     With the register-staged version the 16 KiB of ds_write_b128 per tap (13 cycles each) plus their vmcnt waits cost
+//     47 of 189 us on decode_layer_4 (tools/x3_ablate.hip, profiles/r02_x3_ablate.txt);
+//   * halo pieces travel global -> registers (loaded three taps before their LDS store) -> LDS: border pixels are zeroed
+//     in registers, and the 80-byte halo pitch is not a linear copy;
 //   * register epilogue: bias + exact-erf GELU + (hi, lo) split on the accumulators, BOTH fp16 planes staged once in LDS
 //     and written as 256 contiguous bytes per pixel and plane.
-// LDS: 2 x 2 x 25 920 (halo, double-buffered, two planes) + 3 x 2 x 8 192 (weights) = 152 832 B: one workgroup per CU.
+// Two shapes (halo tile ids, kernels.hpp):
+//   6 "x3w8": 512 threads, 16x16 pixels x 128 channels, halo double-buffered (the next chunk's halo is complete five taps
+//             before it is needed, so the prefetch also crosses chunk boundaries).  152 832 B of LDS: one workgroup per CU,
+//             the two waves of a SIMD belong to the same workgroup and reach prologue / epilogue together.
+//   7 "x3w4": 256 threads, 8x16 pixels x 128 channels, halo SINGLE-buffered (the next chunk's halo waits in registers and
+//             is written between two barriers at the chunk boundary).  77 952 B: TWO INDEPENDENT workgroups per CU, one
+//             wave of each per SIMD -- they drift out of phase, so one workgroup's prologue / chunk hand-over / epilogue
+//             (exact GELU + split: ~1000 VALU instructions per wave, 64 KiB of stores) runs under the other's MFMAs.
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_epilogue.hpp"
 
+// LDS-DMA: every lane supplies a global address, the wave's 64 x 16 bytes land at (wave-uniform LDS address) + lane * 16.
+#ifndef VP_GLOBAL_LOAD_LDS16  // the CPU emulation shim (tests/emul) provides its own
+#define VP_GLOBAL_LOAD_LDS16(G, L)                                                                                          \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G), (__attribute__((address_space(3))) void*)(L), 16, 0, 0)
+#define VP_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (15 << 8))
+#endif
+
 namespace vp {
 
-template <int CO_TILE, int WCO, int WPX, int ACT>
-__global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams p) {
-  static_assert(WCO * WPX == 8, "8 waves");
-  constexpr int TH = 16, TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
+// ABL: ablation bits for tools/x3_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA, 4 = no LDS
+// fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores); always 0 in the library.
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0>
+__global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
+  constexpr int NTH = 64 * WCO * WPX;
+  constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
-  constexpr int HCHUNKS = HPX * 4, HP = (HCHUNKS + 511) / 512;
-  constexpr int WCHUNKS = CO_TILE * 4, WP = (WCHUNKS + 511) / 512;
+  constexpr int HCHUNKS = HPX * 4, HP = (HCHUNKS + NTH - 1) / NTH;
   constexpr int MT = CO_TILE / WCO / 32, NT = PX / WPX / 32;
-  static_assert(MT >= 1 && NT >= 1 && HP <= 3 && WP == 1, "tile shape");
+  constexpr int NHB = HDB ? 2 : 1;
+  static_assert(MT >= 1 && NT >= 1 && HP <= 3, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const halo_base = smem;                       // [2][2 planes][HALO_BYTES]
-  char* const w_base = smem + 4 * HALO_BYTES;         // [3][2 planes][W_BYTES]
+  char* const halo_base = smem;                               // [NHB][2 planes][HALO_BYTES]
+  char* const w_base = smem + NHB * 2 * HALO_BYTES;           // [3][2 planes][W_BYTES]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave / WPX, wpx = wave % WPX;
@@ -51,39 +75,36 @@ __global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams 
   const int co0 = tile_co * CO_TILE;
   const int KC = p.Cin >> 5;
 
-  // ---- staging assignment
-  int h_goff[HP], h_lds[HP];
+  // ---- staging assignment: thread t moves 16-byte piece t + NTH * pc of a tile (pieces of one thread sit NTH / 4 rows apart)
+  int h_goff[HP];
 #pragma unroll
   for (int pc = 0; pc < HP; ++pc) {
-    const int hidx = tid + 512 * pc;
+    const int hidx = tid + NTH * pc;
     const int hp = hidx >> 2, ch = hidx & 3;
     const int hy = hp / HWD, hx = hp - hy * HWD;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    const bool in_tile = hidx < HCHUNKS;
-    const bool ok = in_tile && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const bool ok = hidx < HCHUNKS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     h_goff[pc] = ok ? (gy * p.W + gx) * p.Cin + ch * 8 : -1;
-    h_lds[pc] = in_tile ? hp * ROWB + ch * 16 : -1;
   }
-  const bool w_ok = tid < WCHUNKS;
-  const int w_row = tid >> 2, w_ch = tid & 3;
-  const int w_goff = w_ok ? (co0 + w_row) * 32 + w_ch * 8 : 0;
-  const int w_lds = w_row * WROW + ((w_ch ^ ((w_row >> 2) & 3)) << 4);
+  const int h_lds0 = (tid >> 2) * ROWB + (tid & 3) * 16;
+  // weight tiles by LDS-DMA: a (chunk, tap) tile plane is CO_TILE x 64 B = W_BYTES contiguous bytes in global memory, already
+  // in LDS image order; wave v copies the 1 KiB pieces v, v + NW, ... of both planes
+  constexpr int NW = NTH / 64, WPIECES = W_BYTES / 1024 / NW;
+  static_assert(W_BYTES % (1024 * NW) == 0, "weight tile splits into 1 KiB pieces per wave");
   const size_t w_step = (size_t)p.CoutW * 32;
+  const int w_goff0 = co0 * 32 + wave * 512 + lane * 8;  // elements: this lane's 16 bytes of the wave's first piece
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // ---- fragment addressing (same LDS image and lane maps as the halo kernel)
-  int b_ofs[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int q = (wpx * NT + j) * 32 + (lane & 31);
+  int b_ofs0;  // pixel tile j of the wave sits two halo rows further: + j * 2 * HWD * ROWB
+  {
     int rowbit, px;
-    lane_to_px16(q & 31, rowbit, px);
-    b_ofs[j] = ((2 * (q >> 5) + rowbit) * HWD + px) * ROWB + (lane >> 5) * 16;
+    lane_to_px16(lane & 31, rowbit, px);
+    b_ofs0 = ((2 * (wpx * NT) + rowbit) * HWD + px) * ROWB + (lane >> 5) * 16;
   }
-  const int a_ofs = (wco * 32 + (lane & 31)) * WROW;
   const int a_swz = ((lane & 31) >> 2) & 3;
-  const int a_sw[2] = {(((lane >> 5)) ^ a_swz) << 4, ((2 + (lane >> 5)) ^ a_swz) << 4};
+  const int a_ofs0 = (wco * 32 + (lane & 31)) * WROW + (((lane >> 5) ^ a_swz) << 4);  // K sub-step 1: chunk index ^ 2 -> ^ 32 bytes
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -95,24 +116,22 @@ __global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams 
 
   // fragment sets [K sub-step parity]: set 0 = channels 0..15 of the tap's 32, set 1 = channels 16..31
   h8_t fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
-  // staging rings (compile-time slots)
-  u32x4 rw_hi[3], rw_lo[3], rh_hi[3], rh_lo[3];
+  // halo staging ring (compile-time slots): piece pc in slot pc
+  u32x4 rh_hi[3], rh_lo[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) rw_hi[r] = rw_lo[r] = rh_hi[r] = rh_lo[r] = zero4;
+  for (int r = 0; r < 3; ++r) rh_hi[r] = rh_lo[r] = zero4;
   const int s_last = KC * 9 - 1;
 
-#define VP_LOAD_W(SLOT, SIDX)                                                                \
-  if (w_ok) {                                                                                \
+  // weight tile SIDX (clamped to the last one: the tail requests are harmless re-reads) -> LDS buffer BUF, asynchronously
+#define VP_DMA_W(BUF, SIDX)                                                                  \
+  {                                                                                          \
     const int si_ = (SIDX) < s_last ? (SIDX) : s_last;                                       \
-    const size_t base_ = (size_t)si_ * w_step + w_goff;                                      \
-    rw_hi[SLOT] = *reinterpret_cast<const u32x4*>(p.w_hi + base_);                           \
-    rw_lo[SLOT] = *reinterpret_cast<const u32x4*>(p.w_lo + base_);                           \
-  }
-#define VP_STORE_W(SLOT, BUF)                                                                \
-  if (w_ok) {                                                                                \
-    char* dst_ = w_base + (BUF) * 2 * W_BYTES + w_lds;                                       \
-    *reinterpret_cast<u32x4*>(dst_) = rw_hi[SLOT];                                           \
-    *reinterpret_cast<u32x4*>(dst_ + W_BYTES) = rw_lo[SLOT];                                 \
+    const size_t base_ = (size_t)si_ * w_step + w_goff0;                                     \
+    char* dst_ = w_base + (BUF) * 2 * W_BYTES + wave * 1024;                                 \
+    _Pragma("unroll") for (int pc = 0; pc < WPIECES; ++pc) {                                 \
+      VP_GLOBAL_LOAD_LDS16(p.w_hi + base_ + pc * NW * 512, dst_ + pc * NW * 1024);           \
+      VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
+    }                                                                                        \
   }
 #define VP_LOAD_H(SLOT, PC, C)                                                               \
   {                                                                                          \
@@ -124,30 +143,37 @@ __global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams 
     rh_lo[SLOT] = g_ >= 0 ? l_ : zero4;                                                      \
   }
 #define VP_STORE_H(SLOT, PC, BUF)                                                            \
-  if (h_lds[PC] >= 0) {                                                                      \
-    char* dst_ = halo_base + (BUF) * 2 * HALO_BYTES + h_lds[PC];                             \
+  if (tid + NTH * (PC) < HCHUNKS) {                                                          \
+    char* dst_ = halo_base + (BUF) * 2 * HALO_BYTES + h_lds0 + (PC) * (NTH / 4) * ROWB;      \
     *reinterpret_cast<u32x4*>(dst_) = rh_hi[SLOT];                                           \
     *reinterpret_cast<u32x4*>(dst_ + HALO_BYTES) = rh_lo[SLOT];                              \
   }
 #define VP_READ_FRAGS(SET, WBUF, HBUF, TAPOFS)                                               \
   {                                                                                          \
-    const char* wsrc_ = (WBUF) + a_ofs + a_sw[SET];                                          \
+    const char* wsrc_ = (WBUF) + (a_ofs0 ^ ((SET) * 32));                                    \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
       fa[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + i * WCO * 32 * WROW);              \
       fal[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + W_BYTES + i * WCO * 32 * WROW);   \
     }                                                                                        \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
-      fb[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + b_ofs[j] + (TAPOFS) + (SET) * 32); \
-      fbl[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + HALO_BYTES + b_ofs[j] + (TAPOFS) + (SET) * 32); \
+      fb[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
+      fbl[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + HALO_BYTES + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
     }                                                                                        \
   }
-#define VP_MFMA(SET)                                                                         \
-  _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int j = 0; j < NT; ++j) { \
+#define VP_MFMA(SET) VP_MFMA_RANGE(SET, 0, MT * NT)
+  // accumulator tiles [Q0, Q1) of the wave (tile q = i * NT + j)
+#define VP_MFMA_RANGE(SET, Q0, Q1)                                                           \
+  _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
+    const int i = q_ / NT, j = q_ % NT;                                                      \
+    if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[SET][i][1] + (float)fb[SET][j][2] + (float)fbl[SET][j][3]; continue; } \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);  \
   }
   // One tap step.  On entry fragment set 0 of THIS step is in flight / in registers (read during the previous step).
+  // HDB: the next chunk's halo pieces are loaded at taps 0..HP-1 and written to the OTHER halo buffer two taps later, the
+  //      prefetch of tap 8 reads that buffer.  !HDB: the pieces stay in their ring slots until tap 8's barrier has passed,
+  //      are written over the single halo image, and a second barrier opens the next chunk (no prefetch across it).
 #define VP_TAP(T)                                                                            \
   {                                                                                          \
     constexpr int tap_ofs_ = (((T) / 3) * HWD + ((T) % 3)) * ROWB;                           \
@@ -155,61 +181,91 @@ __global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams 
     constexpr int tap_next_ = ((tn_ / 3) * HWD + (tn_ % 3)) * ROWB;                          \
     const char* wcur_ = w_base + ((T) % 3) * 2 * W_BYTES;                                    \
     const char* wnext_ = w_base + (((T) + 1) % 3) * 2 * W_BYTES;                             \
-    const char* hnext_ = (T) == 8 ? hbuf_other : hbuf;                                       \
-    /* ---- K sub-step 0: set 1 of this step is fetched while set 0 multiplies */           \
-    VP_READ_FRAGS(1, wcur_, hbuf, tap_ofs_)                                                  \
-    __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
-    if constexpr ((T) < HP) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c)   \
-    VP_MFMA(0)                                                                               \
-    /* ---- K sub-step 1: set 0 of the NEXT step is fetched while set 1 multiplies */       \
-    VP_READ_FRAGS(0, wnext_, hnext_, tap_next_)                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-    if (next_chunk || (T) < 7) VP_STORE_W(((T) + 2) % 3, ((T) + 2) % 3)                       \
-    VP_LOAD_W(((T) + 2) % 3, c * 9 + (T) + 5)                                                \
-    if constexpr ((T) >= 2 && (T) - 2 < HP) {                                                \
-      if (next_chunk) VP_STORE_H(((T) + 1) % 3 /* == (T - 2) % 3 */, (T) >= 2 ? (T) - 2 : 0, hb ^ 1) \
+    const char* hnext_ = ((T) == 8 && HDB) ? hbuf_other : hbuf;                              \
+    /* ---- K sub-step 0 (set 0 was fetched behind the previous barrier).  Half of its accumulator tiles go BEFORE set 1's */ \
+    /* reads are issued: the wait in front of it then sees only reads that are a whole MFMA group old                    */ \
+    /* weight tile of step s+2 -> the buffer step s-1 read last (its barrier has passed); must land before THIS step's barrier  */ \
+    /* (an L2 warm-up of tile s+5 -- every workgroup of an XCD asks for the same never-used tile at once -- was measured: -5 %) */ \
+    if constexpr (!(ABL & 1)) {                                                              \
+      if (next_chunk || (T) < 7) VP_DMA_W(((T) + 2) % 3, c * 9 + (T) + 2)                     \
     }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    VP_MFMA_RANGE(0, 0, MT * NT / 2)                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if constexpr (!(ABL & 4)) VP_READ_FRAGS(1, wcur_, hbuf, tap_ofs_)                        \
+    __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
+    if constexpr ((T) < HP && !(ABL & 1)) {                                                  \
+      if (HDB || next_chunk) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c)  \
+    }                                                                                        \
+    VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
+    if constexpr (!(ABL & 1)) {                                                              \
+      if constexpr (HDB && (T) >= 2 && (T) - 2 < HP) {                                       \
+        if (next_chunk) VP_STORE_H(((T) + 1) % 3 /* == (T - 2) % 3 */, (T) >= 2 ? (T) - 2 : 0, hb ^ 1) \
+      }                                                                                      \
+      /* the DMA of this step is the OLDEST outstanding memory operation but for the halo loads issued after it (none or */ \
+      /* one piece = two loads): in-order vmcnt accounting lets exactly those stay in flight across the barrier         */ \
+      if ((T) < HP && (HDB || next_chunk)) { VP_WAIT_VMCNT(2); } else { VP_WAIT_VMCNT(0); }  \
+    }                                                                                        \
+    /* THE BARRIER SITS BETWEEN THE TWO K SUB-STEPS: the only LDS operations outstanding here are set 1's reads (issued a    */ \
+    /* whole MFMA group ago) and, on three taps of nine, two halo stores.  With the next step's prefetch issued BEFORE the    */ \
+    /* barrier all eight waves drained 64 ds_read_b128 in lockstep at every step with the matrix pipe idle.                  */ \
+    if constexpr (!(ABL & 8)) __syncthreads();                                               \
+    if constexpr (!HDB && (T) == 8) {                                                        \
+      if (next_chunk && !(ABL & 1)) {                                                        \
+        _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_STORE_H(pc, pc, 0)              \
+        if constexpr (!(ABL & 8)) __syncthreads();                                           \
+      }                                                                                      \
+    }                                                                                        \
+    /* ---- K sub-step 1: set 0 of the NEXT step is fetched while set 1 multiplies */       \
+    if constexpr (!(ABL & 4)) VP_READ_FRAGS(0, wnext_, hnext_, tap_next_)                    \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
     VP_MFMA(1)                                                                               \
-    __syncthreads();                                                                         \
   }
 
-  // ---- prologue: halo(chunk 0) and weight tiles 0, 1 -> LDS; tiles 2, 3, 4 -> ring slots 2, 0, 1
+  // ---- prologue: halo(chunk 0) and weight tiles 0, 1 -> LDS
 #pragma unroll
   for (int pc = 0; pc < HP; ++pc) {
     VP_LOAD_H(0, pc, 0)
     VP_STORE_H(0, pc, 0)
   }
-  VP_LOAD_W(0, 0)
-  VP_LOAD_W(1, 1)
-  VP_STORE_W(0, 0)
-  VP_STORE_W(1, 1)
-  VP_LOAD_W(2, 2)
-  VP_LOAD_W(0, 3)
-  VP_LOAD_W(1, 4)
+  VP_DMA_W(0, 0)
+  VP_DMA_W(1, 1)
+  VP_WAIT_VMCNT(0);
   __syncthreads();
   VP_READ_FRAGS(0, w_base, halo_base, 0)
+  if constexpr ((ABL & 4) != 0) VP_READ_FRAGS(1, w_base, halo_base, 0)
 
   int hb = 0;
   for (int c = 0; c < KC; ++c) {
     const bool next_chunk = (c + 1 < KC);
-    const char* hbuf = halo_base + hb * 2 * HALO_BYTES;
-    const char* hbuf_other = halo_base + (hb ^ 1) * 2 * HALO_BYTES;
+    const char* hbuf = halo_base + (HDB ? hb : 0) * 2 * HALO_BYTES;
+    const char* hbuf_other = halo_base + (HDB ? (hb ^ 1) : 0) * 2 * HALO_BYTES;
     VP_TAP(0) VP_TAP(1) VP_TAP(2) VP_TAP(3) VP_TAP(4) VP_TAP(5) VP_TAP(6) VP_TAP(7) VP_TAP(8)
     hb ^= 1;
   }
 #undef VP_TAP
 #undef VP_MFMA
+#undef VP_MFMA_RANGE
 #undef VP_READ_FRAGS
 #undef VP_STORE_H
 #undef VP_LOAD_H
-#undef VP_STORE_W
-#undef VP_LOAD_W
+#undef VP_DMA_W
 
   // ---- register epilogue: bias + activation + (hi, lo) split, both planes staged as [pixel][CO_TILE] fp16, 16-byte stores.
-  // (the loop's last barrier has passed: no wave still reads the main buffers the stage aliases; the fragment prefetch
-  // issued in the last step is dead)
   constexpr int PITCH = CO_TILE * 2 + 16, STAGE_PLANE = PX * PITCH;
-  static_assert(2 * STAGE_PLANE <= 4 * HALO_BYTES + 6 * W_BYTES, "stage fits the main buffers");
+  static_assert(2 * STAGE_PLANE <= NHB * 2 * HALO_BYTES + 6 * W_BYTES, "stage fits the main buffers");
+  if constexpr ((ABL & 16) != 0) {  // ablation: keep the accumulators alive (a store no launch ever takes), skip arithmetic and stores
+    if (p.H == -12345) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.out_f32[(i * NT + j) * 16 + r + tid * 64] = acc[i][j][r];
+    }
+    return;
+  }
+  __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
   const PixPatch<TW> pix{y0, x0, p.H, p.W};
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -235,8 +291,8 @@ __global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams 
     }
   }
   __syncthreads();
-  constexpr int CPR = CO_TILE / 8, RPI = 512 / CPR;
-  static_assert(512 % CPR == 0 && PX % RPI == 0, "row loop shape");
+  constexpr int CPR = CO_TILE / 8, RPI = NTH / CPR;
+  static_assert(NTH % CPR == 0 && PX % RPI == 0, "row loop shape");
   const int c8 = tid % CPR, r0 = tid / CPR;
   const int co = co0 + c8 * 8;
   if (co >= p.Ncols) return;
@@ -250,22 +306,31 @@ __global__ __launch_bounds__(512) void conv3x3_x3w8_kernel(const ConvGemmParams 
   }
 }
 
-bool conv3x3_x3w8_supported(const ConvGemmParams& p) {
+bool conv3x3_x3_supported(const ConvGemmParams& p) {
   return p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.out_lo && p.nsplit == 1 && p.store_mode == STORE_NHWC &&
          p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE) && p.CoutW % 128 == 0 &&
          p.Cin % 32 == 0 && p.Cin2 == 0;
 }
 
-hipError_t launch_conv3x3_x3w8(const ConvGemmParams& p, hipStream_t st) {
-  if (!conv3x3_x3w8_supported(p)) return hipErrorInvalidValue;
-  constexpr int lds = 4 * (18 * 18 * 80) + 6 * (128 * 64);
+template <int TH, int WPX, bool HDB>
+static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = p.act == ACT_GELU ? conv3x3_x3w8_kernel<128, 2, 4, ACT_GELU> : conv3x3_x3w8_kernel<128, 2, 4, ACT_NONE>;
+  const bool gelu = p.act == ACT_GELU;
+  auto k = gelu ? conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU> : conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_NONE>;
   static LdsAttrOnce attr_once[2];
-  if (hipError_t e = set_max_dynamic_lds(attr_once[p.act == ACT_GELU], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
-  dim3 grid(((p.H + 15) / 16) * ((p.W + 15) / 16) * (p.CoutW / 128));
-  hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);
+  if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / 128));
+  hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, st, p);
   return hipGetLastError();
+}
+
+// shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU
+hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
+  if (!conv3x3_x3_supported(p)) return hipErrorInvalidValue;
+  if (shape == 6) return launch_x3_cfg<16, 4, true>(p, st);
+  if (shape == 7) return launch_x3_cfg<8, 2, false>(p, st);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace vp

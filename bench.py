@@ -62,8 +62,11 @@ def pmc_traffic(tag):
     """HBM-side bytes per launch of the kernel instantiation behind ``tag`` from the committed rocprofv3 PMC passes
     (profiles/r0N_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
     1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  None if not profiled."""
+    m8 = re.match(r"conv3x3_x3w(8|4)<", tag)
     m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
-    if m:
+    if m8:
+        pat = r"conv3x3_x3_kernel<128, 16, 2, 4, true" if m8.group(1) == "8" else r"conv3x3_x3_kernel<128, 8, 2, 2, false"
+    elif m:
         co, px, x, reg = int(m.group(1)), int(m.group(2)), m.group(3), m.group(4)
         pat = rf"conv3x3_halo_kernel<{co}, {px // 16}, 16, \d, \d, {'true' if x == '3' else 'false'}, 0, {'true' if reg else 'false'}>"
     else:

@@ -78,11 +78,12 @@ def test_halo_3x3_kernel_every_tile(emu_lib, precision):
 
 
 def test_x3w8_kernel(emu_lib):
-    """kernels_conv3x3_x3.hip (halo tile 6): the 8-wave fp16x3 kernel -- fragment prefetch across tap and chunk boundaries,
-    three weight buffers, register epilogue with both planes; one and several 32-channel chunks, GELU and no activation,
-    an image that is not a multiple of the 16x16 patch, two output-channel tiles; bit-identical to halo tile 1 (same K order)."""
-    _case(emu_lib, 32, 128, 16, 32, 3, 0, 1, 0, 1, [(106, -1, 1)], seed=21)
-    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 1, [(106, -1, 1)], seed=22)
+    """kernels_conv3x3_x3.hip (halo tiles 6 and 7): the pipelined fp16x3 kernels -- fragment prefetch across tap (and, tile 6,
+    chunk) boundaries, three weight buffers, single-buffered halo with the two-barrier chunk hand-over (tile 7), register
+    epilogue with both planes; one and several 32-channel chunks, GELU and no activation, an image that is not a multiple of
+    the patch, two output-channel tiles; bit-identical to halo tile 1 (same K order)."""
+    _case(emu_lib, 32, 128, 16, 32, 3, 0, 1, 0, 1, [(106, -1, 1), (107, -1, 1)], seed=21)
+    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 1, [(106, -1, 1), (107, -1, 1)], seed=22)
     rng = np.random.default_rng(23)
     x = rng.standard_normal((64, 18, 33), dtype=np.float32)
     wt = rng.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.float32(0.06)
@@ -90,6 +91,7 @@ def test_x3w8_kernel(emu_lib):
     a = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=106, nsplit=1)
     c = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=101, nsplit=1)
     assert np.array_equal(a, c)
+    assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1), c)
     with pytest.raises(emu_lib.VpError):
         emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # fp16 engines have no tile 6
 

@@ -83,8 +83,8 @@ def test_conv_op_matches_torch(case, precision):
 
 @pytest.mark.parametrize("cin,cout,h,w,act", [(128, 128, 64, 96, 1), (96, 256, 35, 50, 0), (512, 128, 32, 32, 1), (32, 384, 16, 16, 1)])
 def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
-    """kernels_conv3x3_x3.hip (halo tile 6, fp16x3 only): 8-wave workgroups, fragments prefetched across tap / chunk
-    boundaries, three weight buffers, register epilogue.  Same K order as halo tile 1 => bit-identical to it."""
+    """kernels_conv3x3_x3.hip (halo tiles 6 and 7, fp16x3 only): fragments prefetched across tap / chunk boundaries, three
+    weight buffers, register epilogue; 8-wave 16x16 shape and 4-wave 8x16 shape.  Same K order as halo tile 1 => bit-identical."""
     from autoware_vision_pilot_amd import lib
 
     rng = np.random.default_rng(cin * 1000 + cout)
@@ -96,6 +96,7 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
     err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
     assert err.max() <= 2e-5, err.max()
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=101, nsplit=1))
+    assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=1))   # 4-wave shape, single halo buffer
     with pytest.raises(lib.VpError):
         lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=106, nsplit=1)
 

@@ -1,0 +1,73 @@
+// Developer tool: ablation timing of the pipelined fp16x3 3x3 kernels (kernels_conv3x3_x3.hip) on decoder-layer shapes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x3_ablate.hip -o tools/_x3_ablate
+// ABL bits: 1 no global loads / LDS stores in the loop | 2 no MFMA | 4 no LDS fragment reads | 8 no barrier | 16 no epilogue.
+#include <cstdio>
+#include <vector>
+
+#include "../autoware_vision_pilot_amd/csrc/kernels_conv3x3_x3.hip"
+
+using namespace vp;
+
+template <int TH, int WPX, bool HDB, int ABL>
+static float time_variant(const ConvGemmParams& p, int iters) {
+  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
+  auto k = conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU, ABL>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / 128));
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, 0, p);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, 0, p);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  return ms * 1000.0f / iters;
+}
+
+template <int TH, int WPX, bool HDB>
+static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
+  const size_t in_n = (size_t)H * W * Cin, out_n = (size_t)H * W * Cout, w_n = (size_t)9 * Cout * Cin;
+  half_t *in, *inl, *out, *outl, *w, *wl;
+  float* bias;
+  hipMalloc(&in, in_n * 2); hipMalloc(&inl, in_n * 2); hipMalloc(&out, out_n * 2); hipMalloc(&outl, out_n * 2);
+  hipMalloc(&w, w_n * 2); hipMalloc(&wl, w_n * 2); hipMalloc(&bias, Cout * 4);
+  std::vector<half_t> h(in_n > w_n ? in_n : w_n);
+  unsigned s = 12345;
+  for (auto& v : h) {
+    s = s * 1664525u + 1013904223u;
+    v = (half_t)(((int)(s >> 9) % 2001 - 1000) * 0.001f);
+  }
+  hipMemcpy(in, h.data(), in_n * 2, hipMemcpyHostToDevice);
+  hipMemcpy(w, h.data(), w_n * 2, hipMemcpyHostToDevice);
+  for (auto& v : h) v = (half_t)((float)v * 0.0004f);
+  hipMemcpy(inl, h.data(), in_n * 2, hipMemcpyHostToDevice);
+  hipMemcpy(wl, h.data(), w_n * 2, hipMemcpyHostToDevice);
+  hipMemset(bias, 0, Cout * 4);
+  ConvGemmParams p{};
+  p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.act = ACT_GELU; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout; p.Creal = Cout; p.nsplit = 1;
+  const double gflop = 2.0 * H * W * (double)Cout * Cin * 9 / 1e9;
+  const int it = 20;
+  const float t0 = time_variant<TH, WPX, HDB, 0>(p, it), t16 = time_variant<TH, WPX, HDB, 16>(p, it), t1 = time_variant<TH, WPX, HDB, 1>(p, it),
+              t4 = time_variant<TH, WPX, HDB, 4>(p, it), t8 = time_variant<TH, WPX, HDB, 8>(p, it), t2 = time_variant<TH, WPX, HDB, 2>(p, it),
+              t29 = time_variant<TH, WPX, HDB, 1 | 4 | 8 | 16>(p, it), t21 = time_variant<TH, WPX, HDB, 1 | 4 | 16>(p, it),
+              t17 = time_variant<TH, WPX, HDB, 1 | 16>(p, it), t20 = time_variant<TH, WPX, HDB, 4 | 16>(p, it);
+  std::printf("%-30s %5.1f GF | full %6.1f us (%5.1f TF alg) | noEpi %6.1f | noGlobal %6.1f | noLdsRead %6.1f | noBarrier %6.1f | noMFMA %6.1f | "
+              "noEpi+noGlobal %6.1f | noEpi+noLdsRead %6.1f | noEpi+noGlobal+noLdsRead %6.1f | MFMA+loop only %6.1f\n",
+              name, gflop, t0, gflop / t0 * 1e3, t16, t1, t4, t8, t2, t17, t20, t21, t29);
+  hipFree(in); hipFree(inl); hipFree(out); hipFree(outl); hipFree(w); hipFree(wl); hipFree(bias);
+  return 0;
+}
+
+int main() {
+  run_shape<16, 4, true>("w8 dec4 512->512 80x160", 80, 160, 512, 512);
+  run_shape<8, 2, false>("w4 dec4 512->512 80x160", 80, 160, 512, 512);
+  run_shape<16, 4, true>("w8 dec6 256->256 160x320", 160, 320, 256, 256);
+  run_shape<8, 2, false>("w4 dec6 256->256 160x320", 160, 320, 256, 256);
+  run_shape<16, 4, true>("w8 dec8 128->128 320x640", 320, 640, 128, 128);
+  run_shape<8, 2, false>("w4 dec8 128->128 320x640", 320, 640, 128, 128);
+  return 0;
+}
