@@ -399,7 +399,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     }
     if (ht == 6 || ht == 7) {
       if (!conv3x3_x3_supported(p)) throw std::invalid_argument("halo tiles 6 / 7 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128-channel tiles, no split-K: " + name);
-      op.kernel = ht == 6 ? "conv3x3_x3w8<co128,px256>" : "conv3x3_x3w4<co128,px128>";
+      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : "conv3x3_x3w4<co128,px128>") + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -458,19 +458,24 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       }
     }
     if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
-    // parity mode, 128-channel tiles, enough patches to need no split-K: the pipelined kernels of kernels_conv3x3_x3.hip --
-    // halo tile 7 (8x16 patches, two independent workgroups per CU) or 6 (16x16 patches, one 8-wave workgroup per CU)
+    // parity mode, 128-channel tiles: the pipelined kernels of kernels_conv3x3_x3.hip -- halo tile 7 (8x16 patches, two
+    // independent workgroups per CU; also the split-K shape of the small-map layers) or 6 (16x16 patches, one 8-wave workgroup)
     {
       static const char* envx = std::getenv("VP_X3_TILE");  // developer knob: 0 = halo kernel, 6 / 7 = force that shape
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
-      const long long wgs16 = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128);
+      const long long wgs16 = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128), wgs8 = cdiv(in->H, 8) * cdiv(in->W, 16) * (ncols / 128);
       // measured per layer (profiles/r02_layers_*): the 4-wave shape wins where the K loop is short (Cin <= 128: prologue and
       // epilogue weigh most and two independent workgroups per CU overlap them), the 8-wave shape elsewhere (half the weight
       // staging per MFMA)
       const int want = envx ? std::atoi(envx) : (cin_pad <= 128 ? 7 : 6);
-      if (split() && o.tile < 0 && want != 0 && (halo == 1 || halo == 3) && ncols % 128 == 0 && wgs16 >= 160 &&
-          (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !o.logits_out && !o.in2)
-        halo = want == 6 ? 6 : 7;
+      const bool plain = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
+      if (split() && o.tile < 0 && want != 0 && (halo == 1 || halo == 3) && ncols % 128 == 0 && !o.logits_out && !o.in2) {
+        // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured
+        // on MI355X, the 4-wave shape without split-K took 139 vs 100 us on decode_layer_5 (200 patches) and its split-K form
+        // (kernel support kept, tile 107 + nsplit) 63 vs 47 / 79 vs 70 us on decode_layer_1 / 3 (profiles/r02_splitk_x3w4.txt)
+        if (plain && wgs16 >= 160) halo = want == 6 ? 6 : 7;
+        (void)wgs8;
+      }
     }
     if ((halo == 6 || halo == 7) && !split()) throw std::invalid_argument("halo tiles 6 / 7 are fp16x3 kernels: " + name);
   }
@@ -531,7 +536,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       ns = std::min(ns, std::max(1, KC / 2));
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
-    if (halo == 6 || halo == 7) pc.nsplit = 1;  // >= 160 (16x16) tiles already cover most of the machine; no split-K path
+    if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
+    if (halo == 7 && blocks >= 160 && o.nsplit <= 0) pc.nsplit = 1;
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }

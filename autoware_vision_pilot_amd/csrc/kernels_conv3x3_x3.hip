@@ -47,7 +47,10 @@ namespace vp {
 
 // ABL: ablation bits for tools/x3_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA, 4 = no LDS
 // fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores); always 0 in the library.
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0>
+// SPLITK: grid carries p.nsplit K slices per tile; a slice covers the input chunks [KC * z / nsplit, KC * (z + 1) / nsplit) and
+// writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
+// fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false>
 __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
@@ -69,11 +72,15 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
   const int n_px_tiles = tiles_x * ((p.H + TH - 1) / TH);
-  const int tile_px = vid % n_px_tiles, tile_co = vid / n_px_tiles;
+  const int n_co_tiles = p.CoutW / CO_TILE;
+  const int tile_px = vid % n_px_tiles, tile_rest = vid / n_px_tiles;
+  const int tile_co = SPLITK ? tile_rest % n_co_tiles : tile_rest, zsplit = SPLITK ? tile_rest / n_co_tiles : 0;
   const int tyi = tile_px / tiles_x, txi = tile_px - tyi * tiles_x;
   const int y0 = tyi * TH, x0 = txi * TW;
   const int co0 = tile_co * CO_TILE;
-  const int KC = p.Cin >> 5;
+  const int KC_all = p.Cin >> 5;
+  const int c_first = SPLITK ? (int)(((long long)KC_all * zsplit) / p.nsplit) : 0;
+  const int KC = (SPLITK ? (int)(((long long)KC_all * (zsplit + 1)) / p.nsplit) : KC_all) - c_first;  // chunks of THIS slice; c below is slice-relative
 
   // ---- staging assignment: thread t moves 16-byte piece t + NTH * pc of a tile (pieces of one thread sit NTH / 4 rows apart)
   int h_goff[HP];
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
   constexpr int NW = NTH / 64, WPIECES = W_BYTES / 1024 / NW;
   static_assert(W_BYTES % (1024 * NW) == 0, "weight tile splits into 1 KiB pieces per wave");
   const size_t w_step = (size_t)p.CoutW * 32;
-  const int w_goff0 = co0 * 32 + wave * 512 + lane * 8;  // elements: this lane's 16 bytes of the wave's first piece
+  const size_t w_goff0 = (size_t)c_first * 9 * w_step + co0 * 32 + wave * 512 + lane * 8;  // elements: this lane's 16 bytes of the wave's first piece (of the slice's first tile)
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
 #define VP_LOAD_H(SLOT, PC, C)                                                               \
   {                                                                                          \
     const int g_ = h_goff[PC];                                                               \
-    const int o_ = (g_ >= 0 ? g_ : 0) + (C) * 32;                                            \
+    const int o_ = (g_ >= 0 ? g_ : 0) + (c_first + (C)) * 32;                                \
     const u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in_hi + o_);                          \
     const u32x4 l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                          \
     rh_hi[SLOT] = g_ >= 0 ? v_ : zero4;                                                      \
@@ -265,6 +272,26 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     }
     return;
   }
+  if constexpr (SPLITK) {
+    // fp32 partial sums straight from the accumulators: lanes l and l + 32 hold channels 8g + 0..3 / 8g + 4..7 of pixel l & 31,
+    // together 32 contiguous bytes per register group
+    const PixPatch<TW> pixs{y0, x0, p.H, p.W};
+    const int M = p.H * p.W;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int m = pixs((wpx * NT + j) * 32 + (lane & 31));
+      if (m < 0) continue;
+      float* row = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co0 + 4 * (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_t v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          *reinterpret_cast<f32x4_t*>(row + (i * WCO + wco) * 32 + 8 * g) = v;
+        }
+    }
+    return;
+  }
   __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
   const PixPatch<TW> pix{y0, x0, p.H, p.W};
 #pragma unroll
@@ -307,22 +334,25 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
 }
 
 bool conv3x3_x3_supported(const ConvGemmParams& p) {
-  return p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.out_lo && p.nsplit == 1 && p.store_mode == STORE_NHWC &&
-         p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE) && p.CoutW % 128 == 0 &&
-         p.Cin % 32 == 0 && p.Cin2 == 0;
+  if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % 128 == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
+  if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
+  return p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
 }
 
 template <int TH, int WPX, bool HDB>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  const bool gelu = p.act == ACT_GELU;
-  auto k = gelu ? conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU> : conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_NONE>;
-  static LdsAttrOnce attr_once[2];
-  if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
-  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / 128));
+  const bool gelu = p.act == ACT_GELU, sk = p.nsplit > 1;
+  auto k = sk ? conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_NONE, 0, true>
+              : (gelu ? conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU> : conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_NONE>);
+  static LdsAttrOnce attr_once[3];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[sk ? 2 : gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / 128) * p.nsplit);
   hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, st, p);
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return sk ? launch_splitk_finish(p, st) : hipSuccess;
 }
 
 // shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU

@@ -93,7 +93,8 @@ int main(int argc, char** argv) {
     }
     if (precision == 1 || quick) {  // 8-wave fp16x3 kernel: 3 weight buffers, cross-tap fragment prefetch, 2 chunks
       bad |= conv(1, 0, 64, 128, 17, 19, 3, 1, 106, -1, 1);
-      bad |= conv(1, 0, 96, 128, 11, 19, 3, 1, 107, -1, 1);  // 4-wave shape: single halo buffer rewritten between two barriers, 3 chunks
+      bad |= conv(1, 0, 96, 128, 11, 19, 3, 1, 107, -1, 1);
+      bad |= conv(1, 0, 160, 128, 10, 20, 3, 1, 107, -1, 2);  // split-K slices  // 4-wave shape: single halo buffer rewritten between two barriers, 3 chunks
     }
     bad |= conv(precision, 0, 32, 40, 5, 8, 3, 1, 1, 32, 1);                                                                                  // generic 3x3
     bad |= conv(precision, 1, 64, 48, 5, 6, 2, 0, -1, -1, -1);                                                                                // ConvTranspose GEMM

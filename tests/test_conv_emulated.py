@@ -92,6 +92,9 @@ def test_x3w8_kernel(emu_lib):
     c = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=101, nsplit=1)
     assert np.array_equal(a, c)
     assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1), c)
+    # split-K slices of the 4-wave shape (fp32 partials + finish kernel), incl. a mul-add residual (context_layer_6's epilogue)
+    _case(emu_lib, 160, 128, 10, 20, 3, 0, 1, 0, 1, [(107, -1, 2), (107, -1, 5)], seed=24)
+    _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3)], seed=25)
     with pytest.raises(emu_lib.VpError):
         emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # fp16 engines have no tile 6
 

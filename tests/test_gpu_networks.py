@@ -4,8 +4,10 @@ Tolerances (BASELINE.json north_star: "class-index maps bit-exact, float tensors
   * fp16x3 (parity mode): |a-b| <= 1e-3 * max(1,|b|) on every checked tensor; class maps must agree on every
     pixel whose oracle top-2 margin is >= 2e-3 (pixels inside the float tolerance band can legitimately flip and
     are counted and bounded).
-  * fp16 (the reference's "fp16" configuration, fp16 tensors in HBM): measured-and-bounded: max |a-b| <=
-    FP16_TOL * max|b| per tensor; class-map agreement >= 99.5 %, every flip inside the fp16 error band.
+  * fp16 (the reference's "fp16" configuration, fp16 tensors in HBM) is a labelled NON-PARITY option: it does not meet the
+    1e-3 bar on these weights (measured 2.2e-2, 154 class flips of 204 800) and no parity claim rests on it -- bench.py reports
+    it beside the parity-mode value, never as it.  What is checked here is a REGRESSION bound on what plain fp16 delivers:
+    max |a-b| <= FP16_TOL * max|b| per tensor; class-map agreement >= 99.5 %, every flip inside the fp16 error band.
 Integer/byte stages (preprocess, decode, nearest resize) are compared bit-exactly.
 """
 import numpy as np
