@@ -277,8 +277,17 @@ void Engine::upload_act(Act* a, const float* chw) {
 void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc) {
   auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
   int tile;
+  // small 1x1 GEMMs (the encoder's expand / project / top convolutions): the LDS-free pointwise kernel (kernels_pw.hip)
+  static const char* env_pw = std::getenv("VP_PW");
+  const bool pw_ok = ks == 1 && o.stride <= 1 && !o.in2 && !o.logits_out && !o.pixel_shuffle && o.post_act == ACT_NONE &&
+                     (o.res_mode == RES_NONE || o.res_mode == RES_ADD) && (o.act == ACT_NONE || o.act == ACT_SILU) && o.nsplit <= 1;
   if (o.tile >= 0) {
     tile = o.tile;
+  } else if (pw_ok && env_pw && env_pw[0] == '1' && 2.0 * M * ncols * cin_pad < 0.6e9) {
+    // OPT-IN only (VP_PW=1).  Measured on MI355X (round 2): the 32 encoder GEMMs take 662 us (fp16x3) / 390 us (fp16) through it
+    // against 474 / 330 us through the LDS-pipelined kernel: a fragment load touches 64 different rows (16 B each), which the
+    // texture path serialises, and the long-K projections (K = 1152 on 200 pixels) leave 24 waves on the whole GPU walking K alone
+    tile = 4;
   } else if (ncols <= 32) {
     tile = 3;
   } else if (ncols % 128 == 0 && (cdiv(M, 128) * (ncols / 128) >= 192 || (M <= 256 && ncols >= 2048))) {
@@ -302,6 +311,7 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
     ns = std::max(1, std::min(ns, 32));
   }
   pc->nsplit = std::min(ns, std::max(1, S));
+  if (tile == 4) pc->nsplit = 1;
 }
 
 void Engine::push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
@@ -409,6 +419,10 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
                 (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
+  } else if (tile == 4) {
+    if (!pw_gemm_supported(p)) throw std::invalid_argument("pointwise kernel (tile 4): 1x1, stride 1, bias + {none, SiLU} + optional residual add, NHWC: " + name);
+    op.kernel = std::string("pw_gemm<") + (sp ? "x3>" : "x1>");
+    op.run = [p, sp](hipStream_t st) { return launch_pw_gemm(p, sp, st); };
   } else if (!(std::getenv("VP_CONVT_STREAM") && std::getenv("VP_CONVT_STREAM")[0] == '0') && convt_stream_supported(p, sp)) {
     op.kernel = "convt_stream<k" + std::to_string(p.Cin + p.Cin2) + ">";
     op.run = [p](hipStream_t st) { return launch_convt_stream(p, st); };
@@ -583,6 +597,7 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
   const int ncols = 4 * cpad;
   PackedConv pc;
   ConvOpts oo = o;
+  oo.pixel_shuffle = true;
   if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
   if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
   choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, oo, &pc);

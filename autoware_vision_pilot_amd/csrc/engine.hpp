@@ -67,6 +67,7 @@ struct ConvOpts {
   const Act* in2 = nullptr;     // K-extension tensor of the fused ConvTranspose + skip-link GEMM (add_convT_skip)
   int stride = 1;               // 3x3 stride-2 convs of AutoDrive (generic GEMM kernel only)
   int post_act = ACT_NONE;      // activation after the residual (CTX: SiLU(c4*x + x))
+  bool pixel_shuffle = false;   // set by add_convT*: the GEMM stores with STORE_SHUFFLE2 (never the pointwise kernel)
 };
 
 class Engine {

@@ -99,7 +99,10 @@ struct FusionParams {
   int Creal_out;
 };
 
-// tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px ; bk = 32 | 64
+// pointwise 1x1 for the small encoder GEMMs (kernels_pw.hip): fragments straight from global memory, no LDS operand path
+bool pw_gemm_supported(const ConvGemmParams& p);
+hipError_t launch_pw_gemm(const ConvGemmParams& p, bool split, hipStream_t st);
+// tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px, 4 = pointwise kernel (64co x 128px) ; bk = 32 | 64
 hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st);
 int conv_tile_co(int tile);
 int conv_tile_px(int tile);

@@ -103,8 +103,13 @@ def test_x3w8_kernel(emu_lib):
 def test_generic_gemm_kernel(emu_lib, precision):
     """kernels_conv.hip: implicit GEMM, all four tiles, both K blocks, split-K, 1x1 (K1 fast path incl. the register
     epilogues) and 3x3, residual add / mul-add, fewer input channels than one K block."""
-    _case(emu_lib, 96, 24, 7, 13, 1, 0, 2, 0, precision, [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 64, 1), (3, 32, 1)], seed=3)
-    _case(emu_lib, 48, 80, 6, 10, 1, 0, 0, 1, precision, [(-1, -1, -1), (2, 32, 2)], seed=4)
+    _case(emu_lib, 96, 24, 7, 13, 1, 0, 2, 0, precision, [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 64, 1), (3, 32, 1), (4, -1, 1)], seed=3)
+    _case(emu_lib, 48, 80, 6, 10, 1, 0, 0, 1, precision, [(-1, -1, -1), (2, 32, 2), (4, -1, 1)], seed=4)
+    # kernels_pw.hip (tile 4): fragments straight from global memory; one, two (even) and five (odd) 32-channel blocks,
+    # ragged pixel count (last wave partly / wholly beyond the image), channel count that is not a multiple of the 64-wide tile
+    _case(emu_lib, 16, 96, 9, 15, 1, 0, 2, 0, precision, [(4, -1, 1)], seed=31)
+    _case(emu_lib, 160, 40, 10, 20, 1, 0, 0, 1, precision, [(4, -1, 1)], seed=32)
+    _case(emu_lib, 64, 200, 3, 43, 1, 0, 2, 0, precision, [(4, -1, 1)], seed=33)
     _case(emu_lib, 32, 40, 5, 8, 3, 0, 1, 2, precision, [(1, 32, 1), (2, 64, 2)], seed=5)
     _case(emu_lib, 3, 32, 8, 8, 3, 0, 0, 0, precision, [(-1, -1, -1)], seed=6)
 

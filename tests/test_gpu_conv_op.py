@@ -46,6 +46,9 @@ CASES = [
     (64, 40, 40, 80, 3, 0, 0, 0),      # eight 10x40 regions, ragged channel tile
     (160, 33, 16, 32, 3, 0, 1, 0),     # one 16x32 region (AutoDrive P5 maps)
     (64, 32, 32, 64, 3, 0, 0, 0),      # four 16x32 regions
+    (16, 96, 40, 64, 1, 0, 2, 0),      # MBConv expand, one 32-channel K block (pointwise kernel)
+    (672, 112, 20, 40, 1, 0, 0, 1),    # MBConv project with residual, 21 K blocks (odd), ragged channel tile
+    (320, 1280, 10, 20, 1, 0, 2, 0),   # features[8]
 ]
 
 
@@ -66,6 +69,8 @@ def test_conv_op_matches_torch(case, precision):
     ref = _reference(x, wt, b, ks, mode, act, res, res_mode, fp16=(precision == 0))
     tol = 1.5e-3 if precision == 0 else 2e-5  # fp16: one output rounding (2^-11) + accumulation order
     cfgs = [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 32, 3), (3, 32, 1), (0, 64, 1), (2, 64, 2)]
+    if ks == 1 and mode == 0 and act in (0, 2) and res_mode in (0, 1):  # LDS-free pointwise kernel (kernels_pw.hip)
+        cfgs += [(4, -1, 1)]
     if ks == 3 and mode == 0 and h >= 8 and w >= 16:  # LDS-halo 3x3 kernel tiles (kernels_conv3x3.hip)
         cfgs += [(100, -1, 1), (101, -1, 2), (102, -1, 1), (103, -1, 3), (104, -1, 1)]
     if ks == 3 and mode == 0 and res_mode == 0 and precision == 0:  # region kernel: fp16 engines, maps that tile into regions
