@@ -63,6 +63,10 @@ struct ConvGemmParams {
   // activation applied AFTER the residual (CTX: SiLU(c4*x + x), common_layers.py:222-224); 0 = none
   int post_act;
   float* partial;      // [nsplit][M][CoutW] fp32 scratch
+  // STORE_NCHW_F32 (the logits convolution of a head): the lane that stores a pixel's first 8 channels also decodes them
+  // (argmax / threshold / lane priority, kernels_misc.hip decode_mask_kernel's rules) into mask_out[pixel]; nullptr = off
+  uint8_t* mask_out;
+  int decode_mode;
 };
 
 // nn.GELU() (exact erf form, scene_neck.py:8).  ~300 M activations per frame: libm's erff (~45 VALU ops, branchy)

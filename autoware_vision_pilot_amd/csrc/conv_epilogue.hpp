@@ -36,6 +36,28 @@ __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, 
 #pragma unroll
     for (int r = 0; r < 8; ++r)
       if (co + r < p.Creal) p.out_f32[(size_t)(co + r) * M + m] = v[r];
+    // fused decode (RunModelNode::onImage argmax / threshold loops, run_model_node.cpp:144-171; createMaskFromTensor{CUDA,HIP};
+    // createEgoLanesMaskFromTensorCUDA): this lane holds ALL of the pixel's logits (the heads have <= 3 channels), exactly the
+    // values it just stored -- same rules, same bits as decode_mask_kernel on the stored tensor
+    if (p.mask_out != nullptr && co == 0 && p.Creal <= 8) {
+      uint8_t r8;
+      if (p.decode_mode == 1) {
+        r8 = v[2] > 0.0f ? 2 : (v[1] > 0.0f ? 1 : (v[0] > 0.0f ? 0 : 255));
+      } else if (p.Creal > 1) {
+        float best = -1e9f;
+        int cls = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < p.Creal && v[c] > best) {
+            best = v[c];
+            cls = c;
+          }
+        r8 = p.decode_mode == 2 ? (uint8_t)cls : (cls == 1 ? 255 : 0);
+      } else {
+        r8 = v[0] > 0.0f ? 255 : 0;
+      }
+      p.mask_out[m] = r8;
+    }
     return;
   }
   size_t o;

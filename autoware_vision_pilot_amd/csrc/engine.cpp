@@ -343,6 +343,13 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.Cstore = out ? out->C : 0;
   p.out_f32 = o.logits_out;
   p.Creal = cout_real;
+  // the head's logits convolution decodes the mask in its epilogue (one launch and a 2.4 MB re-read less per network)
+  const bool fuse_decode = store_mode == STORE_NCHW_F32 && o.logits_out == d_logits_ && d_mask_ && cout_real <= 8 && ncols <= 32 && kind_ >= 0 &&
+                           kind_ != 4 && !(std::getenv("VP_FUSE_DECODE") && std::getenv("VP_FUSE_DECODE")[0] == '0');
+  if (fuse_decode) {
+    p.mask_out = d_mask_;
+    decode_fused_ = true;
+  }
   p.nsplit = pc.nsplit;
   if (o.in2) {
     p.Cin2 = o.in2->C;
@@ -418,7 +425,16 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1;
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
                 (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
-    op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
+    if (fuse_decode) {
+      op.kernel += "+decode";
+      op.run = [this, p, ht, sp](hipStream_t st) {
+        ConvGemmParams q = p;
+        q.decode_mode = decode_mode_;  // vp_set_decode_mode may change it between frames (it invalidates the graph)
+        return launch_conv3x3_halo(q, ht, sp, st);
+      };
+    } else {
+      op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
+    }
   } else if (tile == 4) {
     if (!pw_gemm_supported(p)) throw std::invalid_argument("pointwise kernel (tile 4): 1x1, stride 1, bias + {none, SiLU} + optional residual add, NHWC: " + name);
     op.kernel = std::string("pw_gemm<") + (sp ? "x3>" : "x1>");
@@ -431,7 +447,16 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
                 std::to_string(conv_tile_px(tile)) + (sp ? ",x3" : ",x1") + (epi ? ",regepi" + std::to_string(epi) + ">" : ">") +
                 (pc.nsplit > 1 ? "+splitk" : "");
-    op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
+    if (fuse_decode) {
+      op.kernel += "+decode";
+      op.run = [this, p, tile, bk, sp](hipStream_t st) {
+        ConvGemmParams q = p;
+        q.decode_mode = decode_mode_;
+        return launch_conv_gemm(q, tile, bk, sp, st);
+      };
+    } else {
+      op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
+    }
   }
   ops_.push_back(std::move(op));
 }
@@ -542,12 +567,25 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     int ns = 1;
     if (o.nsplit > 0) {
       ns = o.nsplit;
+    } else if (blocks < 256 && split()) {
+      // parity mode (measured per layer with VP_NSPLIT_FORCE = 1..16, profiles/r02_splitk_sweep_fp16x3.txt): ONE full round of
+      // workgroups at two per CU -- ns = floor(512 / blocks), at most one slice per input chunk.  A little past 512 (the fp16
+      // rule gave 540 / 600 workgroups on the 20x40 / 40x80 layers) a second, nearly empty round costs 10-20 % of the layer.
+      ns = (int)std::max<long long>(1, 512 / blocks);
+      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
+      while (ns > 2 && ns * slice_mb > 24.0) --ns;
     } else if (blocks < 256) {
       ns = (int)((256 + blocks - 1) / blocks);
       while (KC / ns > 6 && blocks * ns < 512) ++ns;
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
       while (ns > 2 && ns * slice_mb > 24.0) --ns;
       ns = std::min(ns, std::max(1, KC / 2));
+    }
+    if (const char* e = std::getenv("VP_NSPLIT_PCT")) {  // developer knob (split-K sweeps): percentage applied to the heuristic's factor
+      if (o.nsplit <= 0 && ns > 1) ns = std::max(1, (int)(ns * std::atoi(e) / 100.0 + 0.5));
+    }
+    if (const char* e = std::getenv("VP_NSPLIT_FORCE")) {  // developer knob: one factor for every layer the heuristic splits
+      if (o.nsplit <= 0 && ns > 1) ns = std::max(1, std::atoi(e));
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
     if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
@@ -598,6 +636,12 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
   PackedConv pc;
   ConvOpts oo = o;
   oo.pixel_shuffle = true;
+  // parity mode: 128-channel tiles with 32-channel K blocks (measured with VP_CONVT_TILE / VP_CONVT_BK over all tiles:
+  // upsample_layer_4 80.9 -> 62.5 us, upsample_layer_1 + skip 54.7 -> 41.6 us, the others unchanged)
+  if (split() && oo.tile < 0 && ncols % 128 == 0) {
+    oo.tile = 0;
+    if (oo.bk < 0) oo.bk = 32;
+  }
   if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
   if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
   choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, oo, &pc);
@@ -640,6 +684,10 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
   ConvOpts o;
   o.in2 = skip_in;
   if ((cin_pad | cs_pad) % 64 != 0) o.bk = 32;  // K steps must not straddle the two tensors
+  if (split() && ncols % 128 == 0) {  // parity mode: see add_convT
+    o.tile = 0;
+    o.bk = 32;
+  }
   if (const char* e = std::getenv("VP_CONVT_TILE")) o.tile = std::atoi(e);
   PackedConv pc;
   choose_conv_cfg(in->H * in->W, ncols, cin_pad + cs_pad, 1, o, &pc);
@@ -1383,7 +1431,7 @@ void Engine::finish_plan() {
   if (d_logits_ && !h_logits_) {
     VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_logits_), (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipHostMallocDefault));
     VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_mask_), (size_t)out_h_ * out_w_, hipHostMallocDefault));
-    if (kind_ != 4) {  // AutoDrive returns three scalars: no mask to decode
+    if (kind_ != 4 && !decode_fused_) {  // AutoDrive returns three scalars: no mask to decode; else the logits conv already decoded
       Op op;
       op.name = "decode";
       op.bytes = 4.0 * out_c_ * out_h_ * out_w_ + out_h_ * out_w_;

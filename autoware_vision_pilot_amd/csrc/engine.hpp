@@ -212,6 +212,7 @@ class Engine {
   float* h_logits_ = nullptr;
   uint8_t* h_mask_ = nullptr;
   bool have_outputs_ = false;
+  bool decode_fused_ = false;  // the logits convolution writes d_mask_ in its epilogue: no separate decode launch
   int outputs_ = 3;  // vp_set_outputs: bit 0 logits, bit 1 mask copied to the host by vp_infer*
   bool host_logits_valid_ = false, host_mask_valid_ = false;
   // pinned staging of the caller's (pageable) frame: two slots
