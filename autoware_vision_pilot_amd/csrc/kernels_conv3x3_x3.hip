@@ -46,7 +46,8 @@
 namespace vp {
 
 // ABL: ablation bits for tools/x3_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA, 4 = no LDS
-// fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores); always 0 in the library.
+// fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores, 32 = clock probe: workgroup 0
+// writes {shader-clock ticks, 100 MHz wall ticks} of its K loop to p.partial[0..1] as raw 64-bit counters); always 0 in the library.
 // SPLITK: grid carries p.nsplit K slices per tile; a slice covers the input chunks [KC * z / nsplit, KC * (z + 1) / nsplit) and
 // writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
 // fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     const char* hnext_ = ((T) == 8 && HDB) ? hbuf_other : hbuf;                              \
     /* ---- K sub-step 0 (set 0 was fetched behind the previous barrier).  Half of its accumulator tiles go BEFORE set 1's */ \
     /* reads are issued: the wait in front of it then sees only reads that are a whole MFMA group old                    */ \
-    /* weight tile of step s+2 -> the buffer step s-1 read last (its barrier has passed); must land before THIS step's barrier  */ \
+    /* weight tile of step s+2 -> the buffer step s-1 read last (its barrier has passed); must land before the NEXT step's barrier */ \
     /* (an L2 warm-up of tile s+5 -- every workgroup of an XCD asks for the same never-used tile at once -- was measured: -5 %) */ \
     if constexpr (!(ABL & 1)) {                                                              \
       if (next_chunk || (T) < 7) VP_DMA_W(((T) + 2) % 3, c * 9 + (T) + 2)                     \
@@ -209,9 +210,20 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
       if constexpr (HDB && (T) >= 2 && (T) - 2 < HP) {                                       \
         if (next_chunk) VP_STORE_H(((T) + 1) % 3 /* == (T - 2) % 3 */, (T) >= 2 ? (T) - 2 : 0, hb ^ 1) \
       }                                                                                      \
-      /* the DMA of this step is the OLDEST outstanding memory operation but for the halo loads issued after it (none or */ \
-      /* one piece = two loads): in-order vmcnt accounting lets exactly those stay in flight across the barrier         */ \
-      if ((T) < HP && (HDB || next_chunk)) { VP_WAIT_VMCNT(2); } else { VP_WAIT_VMCNT(0); }  \
+      /* What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s+1: its first read follows this      */ \
+      /* barrier); the tile requested in this step (s+2) is first read behind the NEXT barrier and stays in flight -- two taps */ \
+      /* of lead for the L2 / Infinity-Cache round trip instead of one.  vmcnt counts in issue order, so "the previous step's  */ \
+      /* DMA has landed" = at most {previous step's halo loads, this step's DMA, this step's halo loads} still outstanding.    */ \
+      {                                                                                      \
+        const bool hl_ = HDB || next_chunk;                                                  \
+        const int newer_ = ((next_chunk || (T) < 7) ? 2 * WPIECES : 0) + (((T) < HP && hl_) ? 2 : 0) + (((T) >= 1 && (T) <= HP && hl_) ? 2 : 0); \
+        if (newer_ >= 2 * WPIECES + 4) { VP_WAIT_VMCNT(2 * WPIECES + 4); }                   \
+        else if (newer_ == 2 * WPIECES + 2) { VP_WAIT_VMCNT(2 * WPIECES + 2); }              \
+        else if (newer_ == 2 * WPIECES) { VP_WAIT_VMCNT(2 * WPIECES); }                      \
+        else if (newer_ == 4) { VP_WAIT_VMCNT(4); }                                          \
+        else if (newer_ == 2) { VP_WAIT_VMCNT(2); }                                          \
+        else { VP_WAIT_VMCNT(0); }                                                           \
+      }                                                                                      \
     }                                                                                        \
     /* THE BARRIER SITS BETWEEN THE TWO K SUB-STEPS: the only LDS operations outstanding here are set 1's reads (issued a    */ \
     /* whole MFMA group ago) and, on three taps of nine, two halo stores.  With the next step's prefetch issued BEFORE the    */ \
@@ -242,6 +254,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
   VP_READ_FRAGS(0, w_base, halo_base, 0)
   if constexpr ((ABL & 4) != 0) VP_READ_FRAGS(1, w_base, halo_base, 0)
 
+  unsigned long long probe_c0 = 0, probe_w0 = 0;
+  if constexpr ((ABL & 32) != 0) {
+    probe_c0 = __builtin_readcyclecounter();   // s_memtime: shader clock
+    probe_w0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+  }
   int hb = 0;
   for (int c = 0; c < KC; ++c) {
     const bool next_chunk = (c + 1 < KC);
@@ -249,6 +266,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     const char* hbuf_other = halo_base + (HDB ? (hb ^ 1) : 0) * 2 * HALO_BYTES;
     VP_TAP(0) VP_TAP(1) VP_TAP(2) VP_TAP(3) VP_TAP(4) VP_TAP(5) VP_TAP(6) VP_TAP(7) VP_TAP(8)
     hb ^= 1;
+  }
+  if constexpr ((ABL & 32) != 0) {
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.partial);
+      dst[0] = __builtin_readcyclecounter() - probe_c0;
+      dst[1] = __builtin_amdgcn_s_memrealtime() - probe_w0;
+    }
   }
 #undef VP_TAP
 #undef VP_MFMA

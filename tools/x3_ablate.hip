@@ -7,6 +7,7 @@
 #include "../autoware_vision_pilot_amd/csrc/kernels_conv3x3_x3.hip"
 
 using namespace vp;
+namespace vp { hipError_t launch_splitk_finish(const ConvGemmParams&, hipStream_t) { return hipErrorInvalidValue; } }  // the tool never splits K
 
 template <int TH, int WPX, bool HDB, int ABL>
 static float time_variant(const ConvGemmParams& p, int iters) {
@@ -62,7 +63,56 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   return 0;
 }
 
-int main() {
+// sustained-load clock probe: 200 back-to-back launches, the last one's workgroup 0 reports shader-clock vs 100 MHz wall ticks of its K loop
+template <int TH, int WPX, bool HDB, int ABL>
+static void clock_probe(const char* name, int H, int W, int Cin, int Cout) {
+  const size_t in_n = (size_t)H * W * Cin, out_n = (size_t)H * W * Cout, w_n = (size_t)9 * Cout * Cin;
+  half_t *in, *inl, *out, *outl, *w, *wl;
+  float* bias;
+  unsigned long long* probe;
+  hipMalloc(&in, in_n * 2); hipMalloc(&inl, in_n * 2); hipMalloc(&out, out_n * 2); hipMalloc(&outl, out_n * 2);
+  hipMalloc(&w, w_n * 2); hipMalloc(&wl, w_n * 2); hipMalloc(&bias, Cout * 4); hipMalloc(&probe, 64);
+  std::vector<half_t> h(in_n > w_n ? in_n : w_n);
+  unsigned s = 777;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (half_t)(((int)(s >> 9) % 2001 - 1000) * 0.001f); }
+  hipMemcpy(in, h.data(), in_n * 2, hipMemcpyHostToDevice); hipMemcpy(w, h.data(), w_n * 2, hipMemcpyHostToDevice);
+  for (auto& v : h) v = (half_t)((float)v * 0.0004f);
+  hipMemcpy(inl, h.data(), in_n * 2, hipMemcpyHostToDevice); hipMemcpy(wl, h.data(), w_n * 2, hipMemcpyHostToDevice);
+  hipMemset(bias, 0, Cout * 4);
+  ConvGemmParams p{};
+  p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.act = ACT_GELU; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout; p.Creal = Cout; p.nsplit = 1; p.partial = reinterpret_cast<float*>(probe);
+  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
+  auto k = conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU, ABL>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  dim3 grid(((H + TH - 1) / TH) * ((W + 15) / 16) * (Cout / 128));
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, 0, p);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, 0, p);
+  hipEventRecord(b, 0);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  unsigned long long r[2] = {0, 0};
+  hipMemcpy(r, probe, 16, hipMemcpyDeviceToHost);
+  const double steps = (Cin / 32) * 9.0, mfma_cycles = steps * 2 * 24 * 32;  // two waves per SIMD, 24 MFMAs of 32 cycles per tap each
+  std::printf("%-40s %6.1f us/launch sustained | K loop of workgroup 0: %llu shader ticks in %.2f us -> %.0f MHz; MFMA issue needs %.0f cycles = %.0f %% of them\n",
+              name, ms * 1000.0f / 200, r[0], r[1] / 100.0, r[1] ? r[0] / (r[1] / 100.0) : 0.0, mfma_cycles, r[0] ? 100.0 * mfma_cycles / r[0] : 0.0);
+  hipFree(in); hipFree(inl); hipFree(out); hipFree(outl); hipFree(w); hipFree(wl); hipFree(bias); hipFree(probe);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'c') {
+    clock_probe<16, 4, true, 32>("w8 dec4 full", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 1 | 4 | 8 | 16>("w8 dec4 MFMA + loop only", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 1>("w8 dec4 no global->LDS traffic", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 4>("w8 dec4 no LDS fragment reads", 80, 160, 512, 512);
+    clock_probe<8, 2, false, 32>("w4 dec8 full", 320, 640, 128, 128);
+    clock_probe<8, 2, false, 32 | 1 | 4 | 8 | 16>("w4 dec8 MFMA + loop only", 320, 640, 128, 128);
+    return 0;
+  }
   run_shape<16, 4, true>("w8 dec4 512->512 80x160", 80, 160, 512, 512);
   run_shape<8, 2, false>("w4 dec4 512->512 80x160", 80, 160, 512, 512);
   run_shape<16, 4, true>("w8 dec6 256->256 160x320", 160, 320, 256, 256);
