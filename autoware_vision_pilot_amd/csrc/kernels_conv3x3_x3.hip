@@ -47,7 +47,13 @@ namespace vp {
 
 // ABL: ablation bits for tools/x3_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA, 4 = no LDS
 // fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores, 32 = clock probe: workgroup 0
-// writes {shader-clock ticks, 100 MHz wall ticks} of its K loop to p.partial[0..1] as raw 64-bit counters); always 0 in the library.
+// writes {shader-clock ticks, 100 MHz wall ticks} of its K loop to p.partial[0..1] as raw 64-bit counters, 64 = no halo staging
+// in the loop (weights still stream), 128 = no weight DMA in the loop (halo still streams)); always 0 in the library.
+// Measured with them (profiles/r02_x3_clock_probe.txt): either stream alone is free (255 k cycles of the 8-wave K loop on
+// decode_layer_4 = 87 % matrix-pipe busy), both together cost 290 k (76 %): s_waitcnt vmcnt retires in issue order, so a wait
+// for a weight tile (L2 hit) also waits for the older halo loads (HBM).  Splitting the roles between waves (waves 0-3 DMA,
+// waves 4-7 halo, one of each per SIMD) was tried and is WORSE (348 k cycles, 64 %): the halo waves, with twice the pieces
+// each, become the stragglers of every barrier.
 // SPLITK: grid carries p.nsplit K slices per tile; a slice covers the input chunks [KC * z / nsplit, KC * (z + 1) / nsplit) and
 // writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
 // fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     /* reads are issued: the wait in front of it then sees only reads that are a whole MFMA group old                    */ \
     /* weight tile of step s+2 -> the buffer step s-1 read last (its barrier has passed); must land before the NEXT step's barrier */ \
     /* (an L2 warm-up of tile s+5 -- every workgroup of an XCD asks for the same never-used tile at once -- was measured: -5 %) */ \
-    if constexpr (!(ABL & 1)) {                                                              \
+    if constexpr (!(ABL & 1) && !(ABL & 128)) {                                              \
       if (next_chunk || (T) < 7) VP_DMA_W(((T) + 2) % 3, c * 9 + (T) + 2)                     \
     }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -202,12 +208,12 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     __builtin_amdgcn_sched_barrier(0);                                                       \
     if constexpr (!(ABL & 4)) VP_READ_FRAGS(1, wcur_, hbuf, tap_ofs_)                        \
     __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
-    if constexpr ((T) < HP && !(ABL & 1)) {                                                  \
+    if constexpr ((T) < HP && !(ABL & 1) && !(ABL & 64)) {                                   \
       if (HDB || next_chunk) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c)  \
     }                                                                                        \
     VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
     if constexpr (!(ABL & 1)) {                                                              \
-      if constexpr (HDB && (T) >= 2 && (T) - 2 < HP) {                                       \
+      if constexpr (HDB && (T) >= 2 && (T) - 2 < HP && !(ABL & 64)) {                        \
         if (next_chunk) VP_STORE_H(((T) + 1) % 3 /* == (T - 2) % 3 */, (T) >= 2 ? (T) - 2 : 0, hb ^ 1) \
       }                                                                                      \
       /* What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s+1: its first read follows this      */ \
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     /* barrier all eight waves drained 64 ds_read_b128 in lockstep at every step with the matrix pipe idle.                  */ \
     if constexpr (!(ABL & 8)) __syncthreads();                                               \
     if constexpr (!HDB && (T) == 8) {                                                        \
-      if (next_chunk && !(ABL & 1)) {                                                        \
+      if (next_chunk && !(ABL & 1) && !(ABL & 64)) {                                         \
         _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_STORE_H(pc, pc, 0)              \
         if constexpr (!(ABL & 8)) __syncthreads();                                           \
       }                                                                                      \

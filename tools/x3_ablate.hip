@@ -109,6 +109,11 @@ int main(int argc, char** argv) {
     clock_probe<16, 4, true, 32 | 1 | 4 | 8 | 16>("w8 dec4 MFMA + loop only", 80, 160, 512, 512);
     clock_probe<16, 4, true, 32 | 1>("w8 dec4 no global->LDS traffic", 80, 160, 512, 512);
     clock_probe<16, 4, true, 32 | 4>("w8 dec4 no LDS fragment reads", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 64>("w8 dec4 no halo staging (weights stream)", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 128>("w8 dec4 no weight DMA (halo streams)", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 16>("w8 dec4 no epilogue", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32>("w8 dec6 full", 160, 320, 256, 256);
+    clock_probe<8, 2, false, 32>("w4 dec6 full", 160, 320, 256, 256);
     clock_probe<8, 2, false, 32>("w4 dec8 full", 320, 640, 128, 128);
     clock_probe<8, 2, false, 32 | 1 | 4 | 8 | 16>("w4 dec8 MFMA + loop only", 320, 640, 128, 128);
     return 0;
