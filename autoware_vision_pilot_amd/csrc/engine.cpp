@@ -439,6 +439,11 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     if (!pw_gemm_supported(p)) throw std::invalid_argument("pointwise kernel (tile 4): 1x1, stride 1, bias + {none, SiLU} + optional residual add, NHWC: " + name);
     op.kernel = std::string("pw_gemm<") + (sp ? "x3>" : "x1>");
     op.run = [p, sp](hipStream_t st) { return launch_pw_gemm(p, sp, st); };
+  } else if (tile == 5 || (!(std::getenv("VP_CONVT_RS") && std::getenv("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
+    if (!convt_rs_supported(p, sp))
+      throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
+    op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
+    op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
   } else if (!(std::getenv("VP_CONVT_STREAM") && std::getenv("VP_CONVT_STREAM")[0] == '0') && convt_stream_supported(p, sp)) {
     op.kernel = "convt_stream<k" + std::to_string(p.Cin + p.Cin2) + ">";
     op.run = [p](hipStream_t st) { return launch_convt_stream(p, st); };
@@ -832,6 +837,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       // squeeze-excite -> per-frame scaled projection weights
       float* s1 = static_cast<float*>(dalloc((size_t)N * sq * sizeof(float)));  // [N][sq]
       SeParams se{};
+      std::string se_name;
       {
         const std::string sp = bp + std::to_string(j);
         const HostTensor& w1 = blob.get(sp + ".fc1.weight");
@@ -861,11 +867,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         se.scale = nullptr;
         se.s1 = s1;
         se.frames = N;
-        Op op2;
-        op2.name = sp + ".fc";
-        op2.flops = 2.0 * sq * cexp;
-        op2.run = [se](hipStream_t st) { return launch_se_fc1(se, st); };
-        ops_.push_back(std::move(op2));
+        se_name = sp;
         ++j;
       }
       // project 1x1 (+BN folded) with SE scale folded into K, optional residual
@@ -898,11 +900,29 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         sw.out_hi = static_cast<half_t*>(dalloc((size_t)N * wf.size() * sizeof(half_t)));  // [N][CoutW][C]
         sw.out_lo = split() ? static_cast<half_t*>(dalloc((size_t)N * wf.size() * sizeof(half_t))) : nullptr;
         sw.frames = N;
-        Op op;
-        op.name = bp + std::to_string(j) + ".se_scale_w";
-        op.bytes = 6.0 * wf.size() * N;
-        op.run = [sw](hipStream_t st) { return launch_se_scale_weights(sw, st); };
-        ops_.push_back(std::move(op));
+        // squeeze FC + excite FC + weight scaling: one launch (kernels_backbone.hip se_gate_scale_kernel); VP_SE_FUSED=0 keeps the
+        // two-launch form (bit-identical, 16 more launches per frame)
+        static const char* se_env = std::getenv("VP_SE_FUSED");
+        if (!(se_env && se_env[0] == '0')) {
+          Op op;
+          op.name = se_name + ".se";
+          op.flops = 4.0 * sq * cexp;
+          op.bytes = 6.0 * wf.size() * N;
+          op.kernel = "se_gate_scale";
+          op.run = [se, sw](hipStream_t st) { return launch_se_gate_scale(se, sw, st); };
+          ops_.push_back(std::move(op));
+        } else {
+          Op op2;
+          op2.name = se_name + ".fc";
+          op2.flops = 2.0 * sq * cexp;
+          op2.run = [se](hipStream_t st) { return launch_se_fc1(se, st); };
+          ops_.push_back(std::move(op2));
+          Op op;
+          op.name = bp + std::to_string(j) + ".se_scale_w";
+          op.bytes = 6.0 * wf.size() * N;
+          op.run = [sw](hipStream_t st) { return launch_se_scale_weights(sw, st); };
+          ops_.push_back(std::move(op));
+        }
         pc.bias = dupload(bias);
         Act* out = new_act(bp + std::to_string(j), S.cout, z->H, z->W);
         out->frames = N;

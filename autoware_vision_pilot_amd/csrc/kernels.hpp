@@ -124,6 +124,9 @@ int region_co(int shape, int CoutW);
 // persistent streaming ConvTranspose (+skip) for large maps with short K (kernels_convt_stream.hip)
 bool convt_stream_supported(const ConvGemmParams& p, bool split);
 hipError_t launch_convt_stream(const ConvGemmParams& p, hipStream_t st);
+// register-stationary weights, pixel tiles by LDS-DMA (kernels_convt_rs.hip): K = 128, or 256 + 32 with the skip link; both precisions
+bool convt_rs_supported(const ConvGemmParams& p, bool split);
+hipError_t launch_convt_rs(const ConvGemmParams& p, hipStream_t st);
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
@@ -134,6 +137,8 @@ hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st);
 // 100+ per address cost 30 us on the 80x160 layers), so layers with many workgroups get up to 64 rows.
 constexpr int kSeMaxReplicas = 64;
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st);
+// squeeze FC + excite FC + weight scaling in one launch (bit-identical to launch_se_fc1 followed by launch_se_scale_weights)
+hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipStream_t st);
 hipError_t launch_fc(const FcParams& p, hipStream_t st);
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st);
 hipError_t launch_fusion(const FusionParams& p, hipStream_t st);

@@ -6,8 +6,8 @@
 //   dwconv_pool     depthwise k x k (+BN folded) + SiLU, FUSED with the squeeze-excite average pool: each
 //                   workgroup owns a pixel slab x channel group and emits its per-channel partial sums
 //                   (deterministic two-level reduction, no atomics, the tensor is not re-read)
-//   se_fc1          squeeze FC + SiLU (one wave per unit)
-//   se_scale_w      excite FC + sigmoid fused into the per-frame scaling of the projection weights
+//   se_gate_scale   the squeeze-excite tail in one launch: means -> squeeze FC + SiLU -> excite FC + sigmoid -> per-frame
+//                   scaling of the projection weights (se_fc1 / se_scale_w: the same in two launches, VP_SE_FUSED=0)
 //   pool_partial    stand-alone channel sums (context block's global average pool)
 //   fc              dense layer of the context MLP, one wave per two outputs, input vector staged in LDS
 #include "act_io.hpp"
@@ -195,16 +195,8 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
 }
 
 // ------------------------------------------------------------------------------------- squeeze-excite FCs
-// Squeeze FC: the workgroup rebuilds the channel means from the slab partials into LDS once, then one wave per
-// squeeze unit does a 16-byte-wide dot product (all loads of a row in flight).
-template <bool BATCH>
-__global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams pin) {
-  SeParams p = pin;
-  if constexpr (BATCH) {  // grid.y = camera frame
-    p.sums += (size_t)blockIdx.y * p.replicas * p.C;
-    p.s1 += (size_t)blockIdx.y * p.sq;
-  }
-  extern __shared__ __attribute__((aligned(16))) float mean[];
+// Channel means from the replica rows of the fused pool (or from slab partials) into LDS, all 256 threads.
+__device__ __forceinline__ void se_means(const SeParams& p, float* mean) {
   for (int c = threadIdx.x; c < p.C; c += 256) {
     float s = 0.f;
     if (p.sums) {
@@ -218,10 +210,10 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams pin) {
     }
     mean[c] = s * p.inv_hw;
   }
-  __syncthreads();
+}
+// One squeeze unit by one wave: 16-byte-wide dot product (all loads of a row in flight), SiLU; the value is valid on every lane.
+__device__ __forceinline__ float se_fc1_unit(const SeParams& p, const float* mean, int j) {
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= p.sq) return;
   const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)j * p.C);
   const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(mean);
   const int C4 = p.C >> 2;
@@ -233,29 +225,19 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams pin) {
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) p.s1[j] = silu_f(s + p.b1[j]);
+  return silu_f(s + p.b1[j]);
 }
-
-// Excite FC fused into the per-frame projection-weight scaling: batch is 1, so the SE channel gate commutes into
-// the K axis of the following 1x1 projection (W'[n][k] = W[n][k] * gate[k]) and the activation tensor is never
-// re-written.  A workgroup owns 32 input channels: computes their sigmoid gates once, then scales that 32-wide
-// column slice of every weight row.
-template <bool BATCH>
-__global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams pin) {
-  ScaleWParams p = pin;
-  if constexpr (BATCH) {  // grid.y = camera frame: its own gate, its own copy of the scaled projection weights
-    p.s1 += (size_t)blockIdx.y * p.sq;
-    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
-    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
-  }
-  __shared__ float gate[32];
-  __shared__ float part[8][32];
+// Excite FC of the workgroup's 32 input channels (8 partial dot products per channel in a fixed order, one lane per channel
+// finishes: sigmoid gate), then that 32-wide column slice of every projection-weight row is scaled: W'[n][k] = W[n][k] * gate[k]
+// (batch is 1, so the SE channel gate commutes into the K axis of the following 1x1 projection and the activation tensor is
+// never re-written).  s1: the squeeze outputs, global or LDS.  All 256 threads; contains barriers.
+__device__ __forceinline__ void se_gate_scale_slice(const ScaleWParams& p, const float* s1, float* gate /*[32]*/, float (*part)[32] /*[8][32]*/) {
   const int c0 = blockIdx.x * 32;
-  {  // 8 partial dot products per channel (fixed summation order), then one lane per channel finishes
+  {
     const int cl = threadIdx.x & 31, jp = threadIdx.x >> 5, c = c0 + cl;
     const float* wr = p.w2 + (size_t)c * p.sq;
     float s = 0.f;
-    for (int j = jp; j < p.sq; j += 8) s = fmaf(wr[j], p.s1[j], s);
+    for (int j = jp; j < p.sq; j += 8) s = fmaf(wr[j], s1[j], s);
     part[jp][cl] = s;
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -283,6 +265,64 @@ __global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParam
     *reinterpret_cast<h8_t*>(p.out_hi + off) = h;
     if (p.out_lo) *reinterpret_cast<h8_t*>(p.out_lo + off) = l;
   }
+}
+
+// Squeeze FC alone (the two-launch form, VP_SE_FUSED=0): the workgroup rebuilds the channel means, one wave per squeeze unit.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams pin) {
+  SeParams p = pin;
+  if constexpr (BATCH) {  // grid.y = camera frame
+    p.sums += (size_t)blockIdx.y * p.replicas * p.C;
+    p.s1 += (size_t)blockIdx.y * p.sq;
+  }
+  extern __shared__ __attribute__((aligned(16))) float mean[];
+  se_means(p, mean);
+  __syncthreads();
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= p.sq) return;
+  const float v = se_fc1_unit(p, mean, j);
+  if ((threadIdx.x & 63) == 0) p.s1[j] = v;
+}
+
+// Excite FC + weight scaling alone (the two-launch form): a workgroup owns 32 input channels.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams pin) {
+  ScaleWParams p = pin;
+  if constexpr (BATCH) {  // grid.y = camera frame: its own gate, its own copy of the scaled projection weights
+    p.s1 += (size_t)blockIdx.y * p.sq;
+    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
+    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
+  }
+  __shared__ float gate[32];
+  __shared__ float part[8][32];
+  se_gate_scale_slice(p, p.s1, gate, part);
+}
+
+// The whole squeeze-excite tail of an MBConv block in ONE launch (the engine's form): every workgroup (32 input channels of
+// the projection) rebuilds the means and ALL squeeze units itself -- sq x C multiply-adds (<= 48 x 1152) and one pass over the
+// L2-resident fc1 matrix per workgroup cost 2-3 us, a dependent launch costs 7-10 us of the single-stream frame; 16 launches
+// fewer per frame.  Same arithmetic, same order as the two kernels above: bit-identical.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void se_gate_scale_kernel(const SeParams sein, const ScaleWParams swin) {
+  SeParams se = sein;
+  ScaleWParams p = swin;
+  if constexpr (BATCH) {
+    se.sums += (size_t)blockIdx.y * se.replicas * se.C;
+    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
+    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
+  }
+  extern __shared__ __attribute__((aligned(16))) float mean[];  // [C] means, then [sq] squeeze outputs
+  float* const s1 = mean + se.C;
+  __shared__ float gate[32];
+  __shared__ float part[8][32];
+  se_means(se, mean);
+  __syncthreads();
+  for (int j = threadIdx.x >> 6; j < se.sq; j += 4) {
+    const float v = se_fc1_unit(se, mean, j);
+    if ((threadIdx.x & 63) == 0) s1[j] = v;
+  }
+  __syncthreads();
+  se_gate_scale_slice(p, s1, gate, part);
 }
 
 // ------------------------------------------------------------------------------------------ context MLP
@@ -370,6 +410,12 @@ hipError_t launch_se_fc1(const SeParams& p, hipStream_t st) {
 hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st) {
   if (p.frames > 1) VP_LAUNCH(se_scale_weights_kernel<true>, dim3(p.C / 32, p.frames), dim3(256), 0, st, p);
   VP_LAUNCH(se_scale_weights_kernel<false>, dim3(p.C / 32), dim3(256), 0, st, p);
+}
+hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipStream_t st) {
+  if (!se.sums || se.C != sw.C || se.sq != sw.sq || se.frames != sw.frames) return hipErrorInvalidValue;
+  const size_t lds = (size_t)(se.C + se.sq) * sizeof(float);
+  if (se.frames > 1) VP_LAUNCH(se_gate_scale_kernel<true>, dim3(sw.C / 32, se.frames), dim3(256), lds, st, se, sw);
+  VP_LAUNCH(se_gate_scale_kernel<false>, dim3(sw.C / 32), dim3(256), lds, st, se, sw);
 }
 hipError_t launch_fc(const FcParams& p, hipStream_t st) {
   VP_LAUNCH(fc_kernel, dim3((p.N + 7) / 8), dim3(256), p.K * sizeof(float), st, p);

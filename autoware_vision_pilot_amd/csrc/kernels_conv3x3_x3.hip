@@ -35,20 +35,15 @@
 #include <type_traits>
 
 #include "conv_epilogue.hpp"
-
-// LDS-DMA: every lane supplies a global address, the wave's 64 x 16 bytes land at (wave-uniform LDS address) + lane * 16.
-#ifndef VP_GLOBAL_LOAD_LDS16  // the CPU emulation shim (tests/emul) provides its own
-#define VP_GLOBAL_LOAD_LDS16(G, L)                                                                                          \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G), (__attribute__((address_space(3))) void*)(L), 16, 0, 0)
-#define VP_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (15 << 8))
-#endif
+#include "lds_dma.hpp"
 
 namespace vp {
 
 // ABL: ablation bits for tools/x3_ablate.hip only (1 = no global loads / LDS stores in the loop, 2 = no MFMA, 4 = no LDS
 // fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores, 32 = clock probe: workgroup 0
 // writes {shader-clock ticks, 100 MHz wall ticks} of its K loop to p.partial[0..1] as raw 64-bit counters, 64 = no halo staging
-// in the loop (weights still stream), 128 = no weight DMA in the loop (halo still streams)); always 0 in the library.
+// in the loop (weights still stream), 128 = no weight DMA in the loop (halo still streams), 256 = __syncthreads() instead of
+// VP_LDS_BARRIER in the loop: every barrier drains vmcnt(0), lds_dma.hpp); always 0 in the library.
 // Measured with them (profiles/r02_x3_clock_probe.txt): either stream alone is free (255 k cycles of the 8-wave K loop on
 // decode_layer_4 = 87 % matrix-pipe busy), both together cost 290 k (76 %): s_waitcnt vmcnt retires in issue order, so a wait
 // for a weight tile (L2 hit) also waits for the older halo loads (HBM).  Splitting the roles between waves (waves 0-3 DMA,
@@ -234,11 +229,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     /* THE BARRIER SITS BETWEEN THE TWO K SUB-STEPS: the only LDS operations outstanding here are set 1's reads (issued a    */ \
     /* whole MFMA group ago) and, on three taps of nine, two halo stores.  With the next step's prefetch issued BEFORE the    */ \
     /* barrier all eight waves drained 64 ds_read_b128 in lockstep at every step with the matrix pipe idle.                  */ \
-    if constexpr (!(ABL & 8)) __syncthreads();                                               \
+    if constexpr ((ABL & 256) != 0) __syncthreads(); else if constexpr (!(ABL & 8)) VP_LDS_BARRIER();  \
     if constexpr (!HDB && (T) == 8) {                                                        \
       if (next_chunk && !(ABL & 1) && !(ABL & 64)) {                                         \
         _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_STORE_H(pc, pc, 0)              \
-        if constexpr (!(ABL & 8)) __syncthreads();                                           \
+        if constexpr ((ABL & 256) != 0) __syncthreads(); else if constexpr (!(ABL & 8)) VP_LDS_BARRIER();  \
       }                                                                                      \
     }                                                                                        \
     /* ---- K sub-step 1: set 0 of the NEXT step is fetched while set 1 multiplies */       \

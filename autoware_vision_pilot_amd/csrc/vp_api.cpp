@@ -438,7 +438,22 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
     vp::Engine g(-1, nullptr, precision, gpu_id);
     vp::Act* a = g.new_act("in", cin, h, w);
     g.upload_act(a, in);
-    const int oh = mode == 1 ? 2 * h : h, ow = mode == 1 ? 2 * w : w;
+    const int oh = mode >= 1 ? 2 * h : h, ow = mode >= 1 ? 2 * w : w;
+    if (mode == 2) {  // ConvTranspose2d(k2, s2)(in) + Conv2d 1x1(skip): `res` is the skip INPUT [res_mode channels][2h][2w]
+      const int cs = res_mode;
+      if (!res || cs < 1) throw std::invalid_argument("mode 2: res = skip tensor, res_mode = its channel count");
+      vp::Act* sk = g.new_act("skip", cs, oh, ow);
+      g.upload_act(sk, res);
+      const size_t wt_n = (size_t)cin * cout * 4;
+      std::vector<float> wt(weight, weight + wt_n), ws(weight + wt_n, weight + wt_n + (size_t)cout * cs), bt(bias, bias + cout),
+          bs(bias + cout, bias + 2 * cout);
+      vp::Act* y = g.add_convT_skip("op", "op.skip", a, sk, wt, bt, ws, bs, cout);
+      g.run_eager();
+      g.sync();
+      for (size_t i = 0; i < g.acts().size(); ++i)
+        if (g.acts()[i].get() == y) g.read_act((int)i, out);
+      return VP_OK;
+    }
     vp::ConvOpts o;
     o.act = act;
     o.tile = tile;

@@ -222,6 +222,9 @@ int vp_tensor_read(vp_engine* e, int i, float* dst_chw);                       /
 /* ---- single-operator entry (unit parity tests of the MFMA conv kernel; not used by callers) -------------- */
 /* mode 0: Conv2d k=ks stride 1 pad ks/2, weight [Cout][Cin][ks][ks]; mode 1: ConvTranspose2d k2 s2, weight
  * [Cin][Cout][2][2].  act: 0 none 1 GELU 2 SiLU.  res_mode: 0 none 1 add 2 mul-add; res has the output shape.
+ * mode 2: ConvTranspose2d k2 s2 of `in` + Conv2d 1x1 of a skip tensor in ONE launch (the decoders' up-sample + skip-link
+ * pairs): `res` is the skip INPUT [res_mode channels][2h][2w], weight = ConvTranspose weight followed by the 1x1 weight
+ * [Cout][res_mode], bias = the two bias vectors one after the other; act / tile / bk / nsplit are ignored.
  * tile/bk/nsplit: -1 = engine heuristic.  in/res/out are fp32 CHW host buffers. */
 int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,

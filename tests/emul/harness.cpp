@@ -91,6 +91,15 @@ int emu_se_batched(const unsigned long long* sums, int replicas, int C, int Crea
   q.sq = sq; q.Creal = Creal; q.frames = frames;
   return launch_se_scale_weights(q, nullptr);
 }
+int emu_se_gate_scale(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1,
+                      const float* w, void* out_hi, void* out_lo, int rows, const float* w2, const float* b2, int frames) {
+  SeParams p{};
+  p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.frames = frames;
+  ScaleWParams q{};
+  q.w = w; q.out_hi = static_cast<half_t*>(out_hi); q.out_lo = static_cast<half_t*>(out_lo); q.rows = rows; q.C = C; q.w2 = w2; q.b2 = b2;
+  q.sq = sq; q.Creal = Creal; q.frames = frames;
+  return launch_se_gate_scale(p, q, nullptr);
+}
 int emu_se_fc1(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1, float* s1) {
   SeParams p{};
   p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.s1 = s1;

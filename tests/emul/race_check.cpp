@@ -22,6 +22,7 @@ int emu_stem(const float*, int, int, const float*, const float*, void*, void*);
 int emu_dwconv(void*, void*, int, int, int, void*, void*, int, int, const float*, const float*, int, int, unsigned long long*, int);
 int emu_se_fc1(const unsigned long long*, int, int, int, int, float, const float*, const float*, float*);
 int emu_se_scale_weights(const float*, void*, void*, int, int, const float*, const float*, const float*, int, int);
+int emu_se_gate_scale(const unsigned long long*, int, int, int, int, float, const float*, const float*, const float*, void*, void*, int, const float*, const float*, int);
 int emu_fc(const float*, const float*, const float*, float*, int, int, int);
 int emu_pool_partial(void*, void*, int, int, int, float*, int);
 int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
@@ -100,6 +101,11 @@ int main(int argc, char** argv) {
     bad |= conv(precision, 1, 64, 48, 5, 6, 2, 0, -1, -1, -1);                                                                                // ConvTranspose GEMM
     bad |= conv(precision, 1, 128, 64, 4, 8, 2, 1, -1, -1, -1);                                                                               // short-K ConvTranspose GEMM
     if (precision == 0 && !quick) bad |= conv(0, 1, 128, 64, 32, 64, 2, 0, -1, -1, -1);  // >= 2048 px, fp16: the persistent streaming ConvTranspose kernel
+    // register-stationary ConvTranspose (kernels_convt_rs.hip): three DMA tile buffers, one barrier per tile, wave-private patches; 7-8 tiles per workgroup
+    setenv("VP_CONVT_RS_GROUPS", "9", 1);
+    if (precision == 1 || quick) bad |= conv(1, 1, 128, 128, 32, 64, 2, 0, 5, -1, 1);
+    if (!quick) bad |= conv(precision, 1, 128, 128, 32, 64, 2, 0, 5, -1, 1);
+    unsetenv("VP_CONVT_RS_GROUPS");
   }
   if (!skip_conv && !quick) {
     bad |= conv(0, 0, 64, 40, 10, 40, 3, 1, 200, -1, 2);  // region kernel
@@ -123,6 +129,7 @@ int main(int argc, char** argv) {
         bad |= emu_se_fc1(sums.data(), 8, C, C, 6, 1.0f / (oh * ow), w1.data(), b1.data(), s1.data());
         std::vector<half_t> ph((size_t)64 * C), pl(ph.size());
         bad |= emu_se_scale_weights(pw.data(), ph.data(), split ? pl.data() : nullptr, 64, C, s1.data(), w2.data(), b2.data(), 6, C);
+        bad |= emu_se_gate_scale(sums.data(), 8, C, C, 6, 1.0f / (oh * ow), w1.data(), b1.data(), pw.data(), ph.data(), split ? pl.data() : nullptr, 64, C, w2.data(), b2.data(), 1);
       }
     std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
     bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);

@@ -124,6 +124,44 @@ def test_conv_transpose_pixel_shuffle(emu_lib, precision):
     _case(emu_lib, 128, 128, 40, 64, 2, 1, 0, 0, precision, [(-1, -1, -1)], seed=11)
 
 
+def _skip_case(lib, cin, cs, cout, h, w, precision, seed):
+    """ConvTranspose2d(k2, s2)(x) + Conv2d 1x1(skip) through vp_op_conv2d mode 2 against torch (fp64)."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    sk = rng.standard_normal((cs, 2 * h, 2 * w), dtype=np.float32)
+    wt = rng.standard_normal((cin, cout, 2, 2), dtype=np.float32) * np.float32(np.sqrt(2.0 / cin))
+    ws = rng.standard_normal((cout, cs), dtype=np.float32) * np.float32(np.sqrt(2.0 / cs))
+    bt, bs = (rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1) for _ in range(2))
+    q = (lambda a: a) if precision == 1 else _h
+    y = F.conv_transpose2d(torch.from_numpy(q(x)).double()[None], torch.from_numpy(q(wt)).double(), torch.from_numpy(bt).double(), stride=2)
+    y = y + F.conv2d(torch.from_numpy(q(sk)).double()[None], torch.from_numpy(q(ws)).double()[:, :, None, None], torch.from_numpy(bs).double())
+    ref = y[0].float().numpy()
+    got = lib.op_conv2d(x, np.concatenate([wt.ravel(), ws.ravel()]), np.concatenate([bt, bs]), mode=2, res=sk, res_mode=cs, precision=precision)
+    err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+    assert got.shape == ref.shape and err <= (1.5e-3 if precision == 0 else 2e-5), err
+    return got
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_convt_register_stationary_kernel(emu_lib, precision, monkeypatch):
+    """kernels_convt_rs.hip (tile 5): weights stationary in registers, pixel tiles by LDS-DMA three deep, permuted weight rows +
+    wave-private patch epilogue.  K = 128 (every workgroup covers the four quadrants) with one and with many tiles per workgroup
+    (the prologue / steady-state / tail wait counts), K = 256 + 32 with the fused skip link (one quadrant per workgroup; ragged
+    real channel counts below the padded ones), and the refusal of shapes it does not cover."""
+    _case(emu_lib, 128, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=41)                  # 64 tiles, one per workgroup
+    monkeypatch.setenv("VP_CONVT_RS_GROUPS", "5")
+    _case(emu_lib, 128, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=42)                  # 12-13 tiles per workgroup
+    _case(emu_lib, 100, 120, 34, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=43)                  # channels padded to 128 / 128
+    monkeypatch.setenv("VP_CONVT_RS_GROUPS", "3")
+    a = _skip_case(emu_lib, 256, 24, 256, 16, 128, precision, seed=44)                              # 64 tiles x 4 quadrant slices, 21-22 per workgroup
+    monkeypatch.setenv("VP_CONVT_RS", "0")
+    b = _skip_case(emu_lib, 256, 24, 256, 16, 128, precision, seed=44)                              # same layer through the GEMM kernel
+    assert float(np.abs(a - b).max()) <= (4e-3 if precision == 0 else 2e-5)
+    monkeypatch.delenv("VP_CONVT_RS")
+    with pytest.raises(emu_lib.VpError):
+        _case(emu_lib, 64, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=45)               # K = 64: not covered
+
+
 def test_region_kernel(emu_lib):
     """kernels_conv3x3_region.hip (opt-in in the engine, fp16 engines only): 10x40 and 16x32 regions."""
     _case(emu_lib, 64, 40, 10, 40, 3, 0, 1, 0, 0, [(200, -1, 1), (200, -1, 2)], seed=9)

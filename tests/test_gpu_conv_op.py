@@ -122,3 +122,46 @@ def test_conv_op_transpose_detecting():
     got = lib.op_conv2d(x, w, np.zeros(cout, np.float32), ks=1, precision=1)
     ref = x[[(c * 7 + 3) % cin for c in range(cout)]]
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_convt_register_stationary_kernel(precision, monkeypatch):
+    """kernels_convt_rs.hip (tile 5; the engine's choice for the two large-map up-sampling stages of every head): weights
+    stationary in registers, pixel tiles by LDS-DMA, LDS-only barriers with explicit vmcnt waits.  K = 128 at the head's real
+    size (160x320 -> 320x640: 6-7 tiles per workgroup) and with one tile per workgroup; K = 256 + 32 with the fused skip link
+    against torch and against the GEMM kernel on the same layer."""
+    from autoware_vision_pilot_amd import lib
+
+    tol = 1.5e-3 if precision == 0 else 2e-5
+    rng = np.random.default_rng(77 + precision)
+    for cin, cout, h, w in ((128, 128, 160, 320), (128, 128, 32, 64), (100, 120, 34, 64)):
+        x = rng.standard_normal((cin, h, w), dtype=np.float32)
+        wt = rng.standard_normal((cin, cout, 2, 2), dtype=np.float32) * np.float32(np.sqrt(2.0 / cin))
+        b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+        ref = _reference(x, wt, b, 2, 1, 0, None, 0, fp16=(precision == 0))
+        got = lib.op_conv2d(x, wt, b, ks=2, mode=1, precision=precision, tile=5)
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert err.max() <= tol, (cin, cout, h, w, err.max())
+        for _ in range(3):  # the tile stream is asynchronous (DMA three deep, stores in flight): same bits every run
+            assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=2, mode=1, precision=precision, tile=5))
+    with pytest.raises(lib.VpError):
+        lib.op_conv2d(x[:64], wt[:64], b, ks=2, mode=1, precision=precision, tile=5)   # K = 64: not covered
+    # fused skip link, the head's real size (80x160 -> 160x320, 256 + 32 channels)
+    cin, cs, cout, h, w = 256, 24, 256, 80, 160
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    sk = rng.standard_normal((cs, 2 * h, 2 * w), dtype=np.float32)
+    wt = rng.standard_normal((cin, cout, 2, 2), dtype=np.float32) * np.float32(np.sqrt(2.0 / cin))
+    ws = rng.standard_normal((cout, cs), dtype=np.float32) * np.float32(np.sqrt(2.0 / cs))
+    bt, bs = (rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1) for _ in range(2))
+    q = (lambda a: a) if precision == 1 else _h
+    y = F.conv_transpose2d(torch.from_numpy(q(x)).double()[None], torch.from_numpy(q(wt)).double(), torch.from_numpy(bt).double(), stride=2)
+    y = y + F.conv2d(torch.from_numpy(q(sk)).double()[None], torch.from_numpy(q(ws)).double()[:, :, None, None], torch.from_numpy(bs).double())
+    ref = y[0].float().numpy()
+    wcat, bcat = np.concatenate([wt.ravel(), ws.ravel()]), np.concatenate([bt, bs])
+    got = lib.op_conv2d(x, wcat, bcat, mode=2, res=sk, res_mode=cs, precision=precision)
+    assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
+    for _ in range(3):
+        assert np.array_equal(got, lib.op_conv2d(x, wcat, bcat, mode=2, res=sk, res_mode=cs, precision=precision))
+    monkeypatch.setenv("VP_CONVT_RS", "0")
+    gemm = lib.op_conv2d(x, wcat, bcat, mode=2, res=sk, res_mode=cs, precision=precision)
+    assert (np.abs(gemm - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol

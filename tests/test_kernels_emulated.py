@@ -216,6 +216,11 @@ def test_squeeze_excite_kernels(emu):
     hi2 = np.zeros((rows, C), np.float16)
     assert emu.emu_se_scale_weights(ptr(w), ptr(hi2), None, rows, C, ptr(s1), ptr(w2), ptr(b2), sq, Creal) == 0
     assert np.array_equal(hi2, hi)
+    # the engine's form: both FCs and the scaling in ONE launch (se_gate_scale_kernel) -- same bits as the two launches
+    emu.emu_se_gate_scale.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 5 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
+    hi3, lo3 = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
+    assert emu.emu_se_gate_scale(ptr(sums.view(np.uint64)), replicas, C, Creal, sq, 1.0 / hw, ptr(w1), ptr(b1), ptr(w), ptr(hi3), ptr(lo3), rows, ptr(w2), ptr(b2), 1) == 0
+    assert np.array_equal(hi3, hi) and np.array_equal(lo3, lo)
 
 
 def test_fc_kernel(emu):
@@ -390,4 +395,8 @@ def test_batched_depthwise_and_se_kernels_equal_per_frame_launches(emu, split):
         q1, q2 = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
         assert emu.emu_se_scale_weights(ptr(pw), ptr(q1), lo_or_none(q2), rows, C, ptr(t1), ptr(w2), ptr(b2), sq, C) == 0
         assert np.array_equal(s1[f], t1) and np.array_equal(ph[f], q1) and np.array_equal(pl[f], q2), f
+    emu.emu_se_gate_scale.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 5 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
+    gh, gl = np.zeros((frames, rows, C), np.float16), np.zeros((frames, rows, C), np.float16)
+    assert emu.emu_se_gate_scale(ptr(sums), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(pw), ptr(gh), lo_or_none(gl), rows, ptr(w2), ptr(b2), frames) == 0
+    assert np.array_equal(gh, ph) and np.array_equal(gl, pl)                    # one-launch form, batched: same bits
     assert len({sums[f].tobytes() for f in range(frames)}) == frames            # the frames really differ

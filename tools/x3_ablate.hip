@@ -1,6 +1,7 @@
 // Developer tool: ablation timing of the pipelined fp16x3 3x3 kernels (kernels_conv3x3_x3.hip) on decoder-layer shapes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x3_ablate.hip -o tools/_x3_ablate
-// ABL bits: 1 no global loads / LDS stores in the loop | 2 no MFMA | 4 no LDS fragment reads | 8 no barrier | 16 no epilogue.
+// ABL bits: 1 no global loads / LDS stores in the loop | 2 no MFMA | 4 no LDS fragment reads | 8 no barrier | 16 no epilogue | 256 __syncthreads().
+//   _x3_ablate        ablation table;  _x3_ablate c   clock probe;  _x3_ablate b   barrier A/B (lds_dma.hpp)
 #include <cstdio>
 #include <vector>
 
@@ -116,6 +117,19 @@ int main(int argc, char** argv) {
     clock_probe<8, 2, false, 32>("w4 dec6 full", 160, 320, 256, 256);
     clock_probe<8, 2, false, 32>("w4 dec8 full", 320, 640, 128, 128);
     clock_probe<8, 2, false, 32 | 1 | 4 | 8 | 16>("w4 dec8 MFMA + loop only", 320, 640, 128, 128);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'b') {  // barrier A/B: VP_LDS_BARRIER (library) vs __syncthreads() (drains vmcnt(0) at every tap, ABL bit 256)
+    clock_probe<16, 4, true, 32>("w8 dec4 lds barrier", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 256>("w8 dec4 __syncthreads", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32>("w8 dec6 lds barrier", 160, 320, 256, 256);
+    clock_probe<16, 4, true, 32 | 256>("w8 dec6 __syncthreads", 160, 320, 256, 256);
+    clock_probe<8, 2, false, 32>("w4 dec8 lds barrier", 320, 640, 128, 128);
+    clock_probe<8, 2, false, 32 | 256>("w4 dec8 __syncthreads", 320, 640, 128, 128);
+    clock_probe<8, 2, false, 32>("w4 dec6 lds barrier", 160, 320, 256, 256);
+    clock_probe<8, 2, false, 32 | 256>("w4 dec6 __syncthreads", 160, 320, 256, 256);
+    clock_probe<16, 4, true, 32 | 64>("w8 dec4 lds barrier, no halo staging", 80, 160, 512, 512);
+    clock_probe<16, 4, true, 32 | 128>("w8 dec4 lds barrier, no weight DMA", 80, 160, 512, 512);
     return 0;
   }
   run_shape<16, 4, true>("w8 dec4 512->512 80x160", 80, 160, 512, 512);
