@@ -19,6 +19,27 @@
 
 namespace vp {
 
+// Class map of one pixel from its logits v[0..Creal) (RunModelNode::onImage argmax / threshold loops, run_model_node.cpp:144-171;
+// createMaskFromTensor{CUDA,HIP}; createEgoLanesMaskFromTensorCUDA) -- decode_mask_kernel's rules (kernels_misc.hip), same bits.
+// NV: how many entries of v exist (compile-time bound of the argmax loop).
+template <int NV>
+__device__ __forceinline__ uint8_t decode_pixel_n(const float* v, int Creal, int mode) {
+  if (mode == 1) return v[2 < NV ? 2 : 0] > 0.0f ? 2 : (v[1 < NV ? 1 : 0] > 0.0f ? 1 : (v[0] > 0.0f ? 0 : 255));
+  if (Creal > 1) {
+    float best = -1e9f;
+    int cls = 0;
+#pragma unroll
+    for (int c = 0; c < NV; ++c)
+      if (c < Creal && v[c] > best) {
+        best = v[c];
+        cls = c;
+      }
+    return mode == 2 ? (uint8_t)cls : (cls == 1 ? 255 : 0);
+  }
+  return v[0] > 0.0f ? 255 : 0;
+}
+__device__ __forceinline__ uint8_t decode_pixel(const float (&v)[4], int Creal, int mode) { return decode_pixel_n<4>(v, Creal, mode); }
+
 // bias + activation + residual + split + store for 8 consecutive output channels of pixel m.
 // STORE / RES / ACT >= 0 fix the mode at compile time; -1 reads it from the parameter block.
 template <int STORE = -1, int RES = -1, int ACT = -1>
@@ -39,25 +60,7 @@ __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, 
     // fused decode (RunModelNode::onImage argmax / threshold loops, run_model_node.cpp:144-171; createMaskFromTensor{CUDA,HIP};
     // createEgoLanesMaskFromTensorCUDA): this lane holds ALL of the pixel's logits (the heads have <= 3 channels), exactly the
     // values it just stored -- same rules, same bits as decode_mask_kernel on the stored tensor
-    if (p.mask_out != nullptr && co == 0 && p.Creal <= 8) {
-      uint8_t r8;
-      if (p.decode_mode == 1) {
-        r8 = v[2] > 0.0f ? 2 : (v[1] > 0.0f ? 1 : (v[0] > 0.0f ? 0 : 255));
-      } else if (p.Creal > 1) {
-        float best = -1e9f;
-        int cls = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (c < p.Creal && v[c] > best) {
-            best = v[c];
-            cls = c;
-          }
-        r8 = p.decode_mode == 2 ? (uint8_t)cls : (cls == 1 ? 255 : 0);
-      } else {
-        r8 = v[0] > 0.0f ? 255 : 0;
-      }
-      p.mask_out[m] = r8;
-    }
+    if (p.mask_out != nullptr && co == 0 && p.Creal <= 8) p.mask_out[m] = decode_pixel_n<8>(v, p.Creal, p.decode_mode);
     return;
   }
   size_t o;

@@ -170,6 +170,7 @@ void Engine::release() {
   graph_ = nullptr;
   for (void* p : allocs_) hipFree(p);
   allocs_.clear();
+  d_zero_ = nullptr;
   if (h_logits_) hipHostFree(h_logits_);
   if (h_mask_) hipHostFree(h_mask_);
   if (h_frame_) hipHostFree(h_frame_);
@@ -233,6 +234,11 @@ void* Engine::dalloc(size_t bytes, bool zero) {
   if (zero) VP_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
   return p;
 }
+const void* Engine::zero_page() {
+  if (!d_zero_) d_zero_ = dalloc(256, true);
+  return d_zero_;
+}
+
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
@@ -421,6 +427,19 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       ops_.push_back(std::move(op));
       return;
     }
+    // the heads' logits convolution: weights stationary in registers, 16x16x32 MFMA, LDS-DMA halo (kernels_head.hip); same weight
+    // packing as halo tile 4.  VP_HEAD_CONV=0 keeps the halo kernel.
+    if (ht == 4 && o.tile < 0 && head_conv_supported(p) && !(std::getenv("VP_HEAD_CONV") && std::getenv("VP_HEAD_CONV")[0] == '0')) {
+      const void* zeros = zero_page();
+      op.kernel = std::string("head_conv3x3<c") + std::to_string(p.Cin) + (sp ? ",x3>" : ",x1>") + (fuse_decode ? "+decode" : "");
+      op.run = [this, p, zeros, fuse_decode](hipStream_t st) {
+        ConvGemmParams q = p;
+        if (fuse_decode) q.decode_mode = decode_mode_;  // vp_set_decode_mode may change it between frames (it invalidates the graph)
+        return launch_head_conv(q, zeros, st);
+      };
+      ops_.push_back(std::move(op));
+      return;
+    }
     // ",regepi": the register-GELU single-pass epilogue instantiation (same condition as launch_halo_cfg)
     const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1;
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
@@ -444,9 +463,6 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
     op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
     op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
-  } else if (!(std::getenv("VP_CONVT_STREAM") && std::getenv("VP_CONVT_STREAM")[0] == '0') && convt_stream_supported(p, sp)) {
-    op.kernel = "convt_stream<k" + std::to_string(p.Cin + p.Cin2) + ">";
-    op.run = [p](hipStream_t st) { return launch_convt_stream(p, st); };
   } else {
     const int epi = (ks == 1 && !sp) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
     op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
@@ -835,8 +851,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         ++j;
       }
       // squeeze-excite -> per-frame scaled projection weights
-      float* s1 = static_cast<float*>(dalloc((size_t)N * sq * sizeof(float)));  // [N][sq]
       SeParams se{};
+      const float *se_w2 = nullptr, *se_b2 = nullptr;
       std::string se_name;
       {
         const std::string sp = bp + std::to_string(j);
@@ -854,18 +870,14 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         }
         se.sums = sums;
         se.replicas = se_rep;
-        se.partial = nullptr;
-        se.nslab = 0;
         se.C = z->C;
         se.Creal = cexp;
         se.sq = sq;
         se.inv_hw = 1.0f / (float)HWz;
         se.w1 = dupload(w1p);
         se.b1 = dupload(b1.data);
-        se.w2 = dupload(w2p);
-        se.b2 = dupload(b2p);
-        se.scale = nullptr;
-        se.s1 = s1;
+        se_w2 = dupload(w2p);
+        se_b2 = dupload(b2p);
         se.frames = N;
         se_name = sp;
         ++j;
@@ -889,38 +901,22 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         }
         ScaleWParams sw{};
         sw.w = dupload(wf);
-        sw.scale = nullptr;
         sw.rows = pc.CoutW;
         sw.C = z->C;
-        sw.s1 = s1;
-        sw.w2 = se.w2;
-        sw.b2 = se.b2;
+        sw.w2 = se_w2;
+        sw.b2 = se_b2;
         sw.sq = sq;
         sw.Creal = cexp;
         sw.out_hi = static_cast<half_t*>(dalloc((size_t)N * wf.size() * sizeof(half_t)));  // [N][CoutW][C]
         sw.out_lo = split() ? static_cast<half_t*>(dalloc((size_t)N * wf.size() * sizeof(half_t))) : nullptr;
         sw.frames = N;
-        // squeeze FC + excite FC + weight scaling: one launch (kernels_backbone.hip se_gate_scale_kernel); VP_SE_FUSED=0 keeps the
-        // two-launch form (bit-identical, 16 more launches per frame)
-        static const char* se_env = std::getenv("VP_SE_FUSED");
-        if (!(se_env && se_env[0] == '0')) {
+        {
           Op op;
           op.name = se_name + ".se";
           op.flops = 4.0 * sq * cexp;
           op.bytes = 6.0 * wf.size() * N;
           op.kernel = "se_gate_scale";
           op.run = [se, sw](hipStream_t st) { return launch_se_gate_scale(se, sw, st); };
-          ops_.push_back(std::move(op));
-        } else {
-          Op op2;
-          op2.name = se_name + ".fc";
-          op2.flops = 2.0 * sq * cexp;
-          op2.run = [se](hipStream_t st) { return launch_se_fc1(se, st); };
-          ops_.push_back(std::move(op2));
-          Op op;
-          op.name = bp + std::to_string(j) + ".se_scale_w";
-          op.bytes = 6.0 * wf.size() * N;
-          op.run = [sw](hipStream_t st) { return launch_se_scale_weights(sw, st); };
           ops_.push_back(std::move(op));
         }
         pc.bias = dupload(bias);
@@ -1471,8 +1467,6 @@ void Engine::finish_plan() {
     else if (n == "decode") op.kernel = "decode_mask";
     else if (n == "BackboneFeatureFusion") op.kernel = "fusion";
     else if (ends_with(n, ".avgpool") || ends_with(n, "avgpool")) op.kernel = "pool_partial";
-    else if (ends_with(n, ".fc")) op.kernel = "se_fc";
-    else if (ends_with(n, ".se_scale_w")) op.kernel = "scale_weights";
     else if (ends_with(n, "context_layer_3")) op.kernel = "ctx_conv1";
     else if (n.find("context_layer_") != std::string::npos) op.kernel = "fc";
     else if (ends_with(n, "encoder.0")) op.kernel = "stem";

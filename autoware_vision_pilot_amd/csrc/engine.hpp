@@ -119,6 +119,7 @@ class Engine {
   int frame_w() const { return frame_w_; }
   void* dev_logits() const { return d_logits_; }
   void* dev_mask() const { return d_mask_; }
+  float* alloc_f32(size_t n) { return static_cast<float*>(dalloc(n * sizeof(float))); }  // test operator entry: a logits buffer
   int out_c() const { return out_c_; }
   int out_h() const { return out_h_; }
   int out_w() const { return out_w_; }
@@ -162,6 +163,7 @@ class Engine {
   void construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base);
   void release();  // frees every device / host resource; idempotent (destructor and failed construction)
   void* dalloc(size_t bytes, bool zero = true);
+  const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)
   template <class T>
   T* dupload(const std::vector<T>& v);
   void choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc);
@@ -209,6 +211,7 @@ class Engine {
   int out_c_ = 0, out_h_ = 0, out_w_ = 0;
   float* d_logits_ = nullptr;
   uint8_t* d_mask_ = nullptr;
+  void* d_zero_ = nullptr;
   float* h_logits_ = nullptr;
   uint8_t* h_mask_ = nullptr;
   bool have_outputs_ = false;

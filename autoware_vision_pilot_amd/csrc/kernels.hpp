@@ -43,32 +43,24 @@ struct PoolParams {
 };
 
 struct SeParams {
-  const unsigned long long* sums;  // [replicas][C] fixed-point channel sums (see DwParams); null -> use `partial`
+  const unsigned long long* sums;  // [replicas][C] fixed-point channel sums of the fused pool (see DwParams)
   int replicas;
-  const float* partial;  // [nslab][C]
-  int nslab, C, Creal, sq;
+  int C, Creal, sq;
   float inv_hw;
   const float* w1;  // [sq][C]   (zero in pad columns)
   const float* b1;  // [sq]
-  const float* w2;  // [C][sq]
-  const float* b2;  // [C]
-  float* scale;     // [C]   (single-workgroup variant only)
-  float* s1;        // [sq]  output of the squeeze FC (multi-workgroup variant)
-  int frames;       // batched encoder: grid.y = frame; sums [frames][replicas][C], s1 [frames][sq]
+  int frames;       // batched encoder: grid.y = frame; sums [frames][replicas][C]
 };
 
 struct ScaleWParams {
-  const float* w;  // [rows][C] fp32 (BN folded)
-  const float* scale;
-  half_t* out_hi;
-  half_t* out_lo;  // may be null
+  const float* w;   // [rows][C] fp32 projection weights (BN folded)
+  half_t* out_hi;   // [rows][C] = w * gate[c], (hi, lo) split
+  half_t* out_lo;   // may be null
   int rows, C;
-  // fused excite FC (se_scale_weights_kernel): scale[c] = sigmoid(b2[c] + w2[c][:] . s1)
-  const float* s1;
-  const float* w2;  // [C][sq]
+  const float* w2;  // [C][sq]  excite FC: gate[c] = sigmoid(b2[c] + w2[c][:] . s1)
   const float* b2;  // [C]
   int sq, Creal;
-  int frames;       // batched encoder: grid.y = frame; s1 [frames][sq], out_hi / out_lo [frames][rows][C]
+  int frames;       // batched encoder: grid.y = frame; out_hi / out_lo [frames][rows][C]
 };
 
 struct FcParams {
@@ -121,9 +113,10 @@ hipError_t launch_conv3x3_region(const ConvGemmParams& p, int shape, bool split,
 bool region_shape_fits(int shape, int H, int W);
 int region_count(int shape, int H, int W);
 int region_co(int shape, int CoutW);
-// persistent streaming ConvTranspose (+skip) for large maps with short K (kernels_convt_stream.hip)
-bool convt_stream_supported(const ConvGemmParams& p, bool split);
-hipError_t launch_convt_stream(const ConvGemmParams& p, hipStream_t st);
+// last convolution of a head: 3x3, 64 / 128 channels -> <= 4 logit channels, fp32 NCHW + fused decode (kernels_head.hip); weights packed
+// as for halo tile 4; zeros = the engine's zero page (>= 16 bytes of zeros in device memory)
+bool head_conv_supported(const ConvGemmParams& p);
+hipError_t launch_head_conv(const ConvGemmParams& p, const void* zeros, hipStream_t st);
 // register-stationary weights, pixel tiles by LDS-DMA (kernels_convt_rs.hip): K = 128, or 256 + 32 with the skip link; both precisions
 bool convt_rs_supported(const ConvGemmParams& p, bool split);
 hipError_t launch_convt_rs(const ConvGemmParams& p, hipStream_t st);
@@ -131,13 +124,11 @@ hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
-hipError_t launch_se_fc1(const SeParams& p, hipStream_t st);
 hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st);
 // The fused average pool spreads its atomics over `replicas` rows: same-address atomics serialise in L2 (measured:
 // 100+ per address cost 30 us on the 80x160 layers), so layers with many workgroups get up to 64 rows.
 constexpr int kSeMaxReplicas = 64;
-hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st);
-// squeeze FC + excite FC + weight scaling in one launch (bit-identical to launch_se_fc1 followed by launch_se_scale_weights)
+// squeeze-excite tail of an MBConv block in one launch: means, squeeze FC, excite FC, gate folded into the projection weights
 hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipStream_t st);
 hipError_t launch_fc(const FcParams& p, hipStream_t st);
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st);

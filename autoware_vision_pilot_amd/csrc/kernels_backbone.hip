@@ -7,7 +7,7 @@
 //                   workgroup owns a pixel slab x channel group and emits its per-channel partial sums
 //                   (deterministic two-level reduction, no atomics, the tensor is not re-read)
 //   se_gate_scale   the squeeze-excite tail in one launch: means -> squeeze FC + SiLU -> excite FC + sigmoid -> per-frame
-//                   scaling of the projection weights (se_fc1 / se_scale_w: the same in two launches, VP_SE_FUSED=0)
+//                   scaling of the projection weights
 //   pool_partial    stand-alone channel sums (context block's global average pool)
 //   fc              dense layer of the context MLP, one wave per two outputs, input vector staged in LDS
 #include "act_io.hpp"
@@ -194,53 +194,112 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------------- squeeze-excite FCs
-// Channel means from the replica rows of the fused pool (or from slab partials) into LDS, all 256 threads.
-__device__ __forceinline__ void se_means(const SeParams& p, float* mean) {
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    float s = 0.f;
-    if (p.sums) {
-      long long t = 0;
-#pragma unroll 8
-      for (int r = 0; r < p.replicas; ++r) t += (long long)p.sums[(size_t)r * p.C + c];
-      s = (float)((double)t * (1.0 / 16777216.0));
-    } else {
-#pragma unroll 4
-      for (int q = 0; q < p.nslab; ++q) s += p.partial[(size_t)q * p.C + c];
-    }
-    mean[c] = s * p.inv_hw;
+// ------------------------------------------------------------------------------------- squeeze-excite tail
+// The whole squeeze-excite tail of an MBConv block in ONE launch: channel means from the replica rows of the fused pool ->
+// squeeze FC + SiLU -> excite FC + sigmoid -> the gate folded into the K axis of the following 1x1 projection (batch is 1, so
+// W'[n][k] = W[n][k] * gate[k] and the activation tensor is never re-written).  A workgroup owns 32 input channels of the
+// projection and REBUILDS the means and all squeeze units itself (<= 48 x 1152 multiply-adds, one pass over the L2-resident fc1
+// matrix): cheaper than a dependent launch (7-10 us of the single-stream frame; this used to be two launches per block).
+// The kernel is a chain of dependent global round trips, so every phase is laid out for as few of them as possible:
+//   1 means    the replicas x C 64-bit sums are read as 16-byte pairs, eight independent loads per thread in flight, and added
+//              into LDS with 64-bit integer atomics (any order gives the same bits; a thread summing its channel's 8..64 rows
+//              one after the other was 8 serial round trips)
+//   2 squeeze  thread = (unit, K segment): all units at once, each thread a 16-byte-wide dot product over its segment, the
+//              segments of a unit summed in a fixed order (one wave per unit walking the units in turn: 12 serial round trips)
+//   3 excite   8 partial dot products per channel in a fixed order, one lane per channel finishes: sigmoid gate
+//   4 scale    that 32-wide column slice of every projection-weight row, (hi, lo) split
+template <bool BATCH>
+__global__ __launch_bounds__(256) void se_gate_scale_kernel(const SeParams sein, const ScaleWParams swin) {
+  SeParams se = sein;
+  ScaleWParams p = swin;
+  if constexpr (BATCH) {  // grid.y = camera frame: its own sums, its own gate, its own copy of the scaled projection weights
+    se.sums += (size_t)blockIdx.y * se.replicas * se.C;
+    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
+    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
   }
-}
-// One squeeze unit by one wave: 16-byte-wide dot product (all loads of a row in flight), SiLU; the value is valid on every lane.
-__device__ __forceinline__ float se_fc1_unit(const SeParams& p, const float* mean, int j) {
-  const int lane = threadIdx.x & 63;
-  const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)j * p.C);
-  const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(mean);
-  const int C4 = p.C >> 2;
-  float s = 0.f;
-#pragma unroll 6
-  for (int c = lane; c < C4; c += 64) {
-    const f32x4_t a = wr[c], m = m4[c];
-    s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
-  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char se_smem[];
+  unsigned long long* const acc = reinterpret_cast<unsigned long long*>(se_smem);   // [C]
+  float* const mean = reinterpret_cast<float*>(se_smem + (size_t)se.C * 8);          // [C]
+  __shared__ float red[256];
+  __shared__ float s1[64];
+  __shared__ float gate[32];
+  __shared__ float part[8][32];
+  const int tid = threadIdx.x, C = se.C;
+  // ---- 1: means
+  for (int c = tid; c < C; c += 256) acc[c] = 0ull;
+  __syncthreads();
+  {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int CP = C >> 1, n = se.replicas * CP;  // 16-byte pairs; row r, pair cp sits at sums[r * C + 2 cp]: linear index = pair index
+    const u64x2* src = reinterpret_cast<const u64x2*>(se.sums);
+    for (int base = 0; base < n; base += 256 * 8) {
+      u64x2 v[8];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  return silu_f(s + p.b1[j]);
-}
-// Excite FC of the workgroup's 32 input channels (8 partial dot products per channel in a fixed order, one lane per channel
-// finishes: sigmoid gate), then that 32-wide column slice of every projection-weight row is scaled: W'[n][k] = W[n][k] * gate[k]
-// (batch is 1, so the SE channel gate commutes into the K axis of the following 1x1 projection and the activation tensor is
-// never re-written).  s1: the squeeze outputs, global or LDS.  All 256 threads; contains barriers.
-__device__ __forceinline__ void se_gate_scale_slice(const ScaleWParams& p, const float* s1, float* gate /*[32]*/, float (*part)[32] /*[8][32]*/) {
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        v[u] = idx < n ? src[idx] : u64x2{0ull, 0ull};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + tid;
+        if (idx < n) {
+          const int cp = idx % CP;
+          if (v[u][0]) atomicAdd(&acc[2 * cp], v[u][0]);
+          if (v[u][1]) atomicAdd(&acc[2 * cp + 1], v[u][1]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) mean[c] = (float)((double)(long long)acc[c] * (1.0 / 16777216.0)) * se.inv_hw;
+  __syncthreads();
+  // ---- 2: squeeze FC
+  {
+    const int nseg = 256 / se.sq;                      // >= 4 (sq <= 64)
+    const int j = tid / nseg, sg = tid - j * nseg;
+    const int C4 = C >> 2, per = (C4 + nseg - 1) / nseg;
+    float s = 0.f;
+    if (j < se.sq) {
+      const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(se.w1 + (size_t)j * C);
+      const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(mean);
+      const int q1 = min(C4, (sg + 1) * per);
+      // up to 58 16-byte loads per thread (sq = 48, C = 1152): 16 in flight at a time -- at 4 the phase was 15 serial round trips
+      int q = sg * per;
+      for (; q + 16 <= q1; q += 16) {
+        f32x4_t a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = wr[q + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const f32x4_t m = m4[q + u];
+          s += (a[u][0] * m[0] + a[u][1] * m[1]) + (a[u][2] * m[2] + a[u][3] * m[3]);
+        }
+      }
+#pragma unroll 4
+      for (; q < q1; ++q) {
+        const f32x4_t a = wr[q], m = m4[q];
+        s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+      }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < se.sq) {
+      float t = 0.f;
+      for (int g = 0; g < nseg; ++g) t += red[tid * nseg + g];
+      s1[tid] = silu_f(t + se.b1[tid]);
+    }
+  }
+  __syncthreads();
+  // ---- 3: excite FC of this workgroup's 32 channels
   const int c0 = blockIdx.x * 32;
   {
-    const int cl = threadIdx.x & 31, jp = threadIdx.x >> 5, c = c0 + cl;
+    const int cl = tid & 31, jp = tid >> 5, c = c0 + cl;
     const float* wr = p.w2 + (size_t)c * p.sq;
     float s = 0.f;
     for (int j = jp; j < p.sq; j += 8) s = fmaf(wr[j], s1[j], s);
     part[jp][cl] = s;
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if (tid < 32) {
       float t = p.b2[c];
 #pragma unroll
       for (int q = 0; q < 8; ++q) t += part[q][cl];
@@ -248,11 +307,13 @@ __device__ __forceinline__ void se_gate_scale_slice(const ScaleWParams& p, const
     }
   }
   __syncthreads();
-  const int oct = threadIdx.x & 3;
+  // ---- 4: scale the column slice
+  const int oct = tid & 3;
   float g[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) g[i] = gate[oct * 8 + i];
-  for (int row = threadIdx.x >> 2; row < p.rows; row += 64) {
+#pragma unroll 2
+  for (int row = tid >> 2; row < p.rows; row += 64) {
     const size_t off = (size_t)row * p.C + c0 + oct * 8;
     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p.w + off), b = *reinterpret_cast<const f32x4_t*>(p.w + off + 4);
     h8_t h, l;
@@ -265,64 +326,6 @@ __device__ __forceinline__ void se_gate_scale_slice(const ScaleWParams& p, const
     *reinterpret_cast<h8_t*>(p.out_hi + off) = h;
     if (p.out_lo) *reinterpret_cast<h8_t*>(p.out_lo + off) = l;
   }
-}
-
-// Squeeze FC alone (the two-launch form, VP_SE_FUSED=0): the workgroup rebuilds the channel means, one wave per squeeze unit.
-template <bool BATCH>
-__global__ __launch_bounds__(256) void se_fc1_kernel(const SeParams pin) {
-  SeParams p = pin;
-  if constexpr (BATCH) {  // grid.y = camera frame
-    p.sums += (size_t)blockIdx.y * p.replicas * p.C;
-    p.s1 += (size_t)blockIdx.y * p.sq;
-  }
-  extern __shared__ __attribute__((aligned(16))) float mean[];
-  se_means(p, mean);
-  __syncthreads();
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= p.sq) return;
-  const float v = se_fc1_unit(p, mean, j);
-  if ((threadIdx.x & 63) == 0) p.s1[j] = v;
-}
-
-// Excite FC + weight scaling alone (the two-launch form): a workgroup owns 32 input channels.
-template <bool BATCH>
-__global__ __launch_bounds__(256) void se_scale_weights_kernel(const ScaleWParams pin) {
-  ScaleWParams p = pin;
-  if constexpr (BATCH) {  // grid.y = camera frame: its own gate, its own copy of the scaled projection weights
-    p.s1 += (size_t)blockIdx.y * p.sq;
-    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
-    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
-  }
-  __shared__ float gate[32];
-  __shared__ float part[8][32];
-  se_gate_scale_slice(p, p.s1, gate, part);
-}
-
-// The whole squeeze-excite tail of an MBConv block in ONE launch (the engine's form): every workgroup (32 input channels of
-// the projection) rebuilds the means and ALL squeeze units itself -- sq x C multiply-adds (<= 48 x 1152) and one pass over the
-// L2-resident fc1 matrix per workgroup cost 2-3 us, a dependent launch costs 7-10 us of the single-stream frame; 16 launches
-// fewer per frame.  Same arithmetic, same order as the two kernels above: bit-identical.
-template <bool BATCH>
-__global__ __launch_bounds__(256) void se_gate_scale_kernel(const SeParams sein, const ScaleWParams swin) {
-  SeParams se = sein;
-  ScaleWParams p = swin;
-  if constexpr (BATCH) {
-    se.sums += (size_t)blockIdx.y * se.replicas * se.C;
-    p.out_hi += (size_t)blockIdx.y * p.rows * p.C;
-    if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
-  }
-  extern __shared__ __attribute__((aligned(16))) float mean[];  // [C] means, then [sq] squeeze outputs
-  float* const s1 = mean + se.C;
-  __shared__ float gate[32];
-  __shared__ float part[8][32];
-  se_means(se, mean);
-  __syncthreads();
-  for (int j = threadIdx.x >> 6; j < se.sq; j += 4) {
-    const float v = se_fc1_unit(se, mean, j);
-    if ((threadIdx.x & 63) == 0) s1[j] = v;
-  }
-  __syncthreads();
-  se_gate_scale_slice(p, s1, gate, part);
 }
 
 // ------------------------------------------------------------------------------------------ context MLP
@@ -400,20 +403,9 @@ hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
   const int CG = p.in.C >> 3, CGL = slab_cgl(p.in.C);
   VP_LAUNCH(pool_partial_kernel, dim3(p.nslab, (CG + CGL - 1) / CGL), dim3(256), 0, st, p);
 }
-hipError_t launch_se_fc1(const SeParams& p, hipStream_t st) {
-  if (p.frames > 1) {
-    if (!p.sums) return hipErrorInvalidValue;
-    VP_LAUNCH(se_fc1_kernel<true>, dim3((p.sq + 3) / 4, p.frames), dim3(256), p.C * sizeof(float), st, p);
-  }
-  VP_LAUNCH(se_fc1_kernel<false>, dim3((p.sq + 3) / 4), dim3(256), p.C * sizeof(float), st, p);
-}
-hipError_t launch_se_scale_weights(const ScaleWParams& p, hipStream_t st) {
-  if (p.frames > 1) VP_LAUNCH(se_scale_weights_kernel<true>, dim3(p.C / 32, p.frames), dim3(256), 0, st, p);
-  VP_LAUNCH(se_scale_weights_kernel<false>, dim3(p.C / 32), dim3(256), 0, st, p);
-}
 hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipStream_t st) {
-  if (!se.sums || se.C != sw.C || se.sq != sw.sq || se.frames != sw.frames) return hipErrorInvalidValue;
-  const size_t lds = (size_t)(se.C + se.sq) * sizeof(float);
+  if (!se.sums || se.C != sw.C || se.sq != sw.sq || se.frames != sw.frames || se.sq < 1 || se.sq > 64 || (se.C & 31)) return hipErrorInvalidValue;
+  const size_t lds = (size_t)se.C * 12;
   if (se.frames > 1) VP_LAUNCH(se_gate_scale_kernel<true>, dim3(sw.C / 32, se.frames), dim3(256), lds, st, se, sw);
   VP_LAUNCH(se_gate_scale_kernel<false>, dim3(sw.C / 32), dim3(256), lds, st, se, sw);
 }

@@ -195,6 +195,15 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     /* reads are issued: the wait in front of it then sees only reads that are a whole MFMA group old                    */ \
     /* weight tile of step s+2 -> the buffer step s-1 read last (its barrier has passed); must land before the NEXT step's barrier */ \
     /* (an L2 warm-up of tile s+5 -- every workgroup of an XCD asks for the same never-used tile at once -- was measured: -5 %) */ \
+    /* HDB: the next chunk's halo pieces (ALL loaded at tap 0) go to the other halo image HERE, at the start of tap 3 and    */ \
+    /* BEFORE this step's DMA is issued: the compiler guards the registers with s_waitcnt vmcnt(0) (LDS-DMA and plain loads   */ \
+    /* in flight together make its counter model give up on partial counts), and at this point the only thing still in flight */ \
+    /* is the weight tile requested one step ago, which this step's barrier needs anyway.  With the stores spread over taps    */ \
+    /* 2..4 behind the DMA issue, each of those waits drained the just-requested tile (an L2 round trip) with the matrix pipe  */ \
+    /* idle: 74 % busy in the K loop against 85 % with either stream alone (profiles/r02_x3_clock_probe.txt).                  */ \
+    if constexpr (HDB && (T) == 3 && !(ABL & 1) && !(ABL & 64)) {                            \
+      if (next_chunk) { _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_STORE_H(pc, pc, hb ^ 1) } \
+    }                                                                                        \
     if constexpr (!(ABL & 1) && !(ABL & 128)) {                                              \
       if (next_chunk || (T) < 7) VP_DMA_W(((T) + 2) % 3, c * 9 + (T) + 2)                     \
     }                                                                                        \
@@ -203,26 +212,30 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
     __builtin_amdgcn_sched_barrier(0);                                                       \
     if constexpr (!(ABL & 4)) VP_READ_FRAGS(1, wcur_, hbuf, tap_ofs_)                        \
     __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
-    if constexpr ((T) < HP && !(ABL & 1) && !(ABL & 64)) {                                   \
-      if (HDB || next_chunk) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, next_chunk ? c + 1 : c)  \
+    if constexpr (HDB && (T) == 0 && !(ABL & 1) && !(ABL & 64)) {                            \
+      _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_LOAD_H(pc, pc, next_chunk ? c + 1 : c) \
+    }                                                                                        \
+    if constexpr (!HDB && (T) < HP && !(ABL & 1) && !(ABL & 64)) {                           \
+      if (next_chunk) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, c + 1)                          \
     }                                                                                        \
     VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
     if constexpr (!(ABL & 1)) {                                                              \
-      if constexpr (HDB && (T) >= 2 && (T) - 2 < HP && !(ABL & 64)) {                        \
-        if (next_chunk) VP_STORE_H(((T) + 1) % 3 /* == (T - 2) % 3 */, (T) >= 2 ? (T) - 2 : 0, hb ^ 1) \
-      }                                                                                      \
       /* What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s+1: its first read follows this      */ \
       /* barrier); the tile requested in this step (s+2) is first read behind the NEXT barrier and stays in flight -- two taps */ \
       /* of lead for the L2 / Infinity-Cache round trip instead of one.  vmcnt counts in issue order, so "the previous step's  */ \
       /* DMA has landed" = at most {previous step's halo loads, this step's DMA, this step's halo loads} still outstanding.    */ \
       {                                                                                      \
-        const bool hl_ = HDB || next_chunk;                                                  \
-        const int newer_ = ((next_chunk || (T) < 7) ? 2 * WPIECES : 0) + (((T) < HP && hl_) ? 2 : 0) + (((T) >= 1 && (T) <= HP && hl_) ? 2 : 0); \
-        if (newer_ >= 2 * WPIECES + 4) { VP_WAIT_VMCNT(2 * WPIECES + 4); }                   \
-        else if (newer_ == 2 * WPIECES + 2) { VP_WAIT_VMCNT(2 * WPIECES + 2); }              \
-        else if (newer_ == 2 * WPIECES) { VP_WAIT_VMCNT(2 * WPIECES); }                      \
-        else if (newer_ == 4) { VP_WAIT_VMCNT(4); }                                          \
-        else if (newer_ == 2) { VP_WAIT_VMCNT(2); }                                          \
+        /* halo loads (2 per piece) issued in this step / in the previous step behind its DMA */ \
+        constexpr int hon_ = (ABL & 64) ? 0 : 1;                                             \
+        const int hthis_ = hon_ * (HDB ? ((T) == 0 ? 2 * HP : 0) : (((T) < HP && next_chunk) ? 2 : 0)); \
+        const int hprev_ = hon_ * (HDB ? ((T) == 1 ? 2 * HP : 0) : (((T) >= 1 && (T) <= HP && next_chunk) ? 2 : 0)); \
+        const int newer_ = ((next_chunk || (T) < 7) ? 2 * WPIECES : 0) + hthis_ + hprev_;     \
+        if (newer_ >= 2 * WPIECES + 2 * HP && HDB) { VP_WAIT_VMCNT(2 * WPIECES + 2 * HP); }  \
+        else if (newer_ >= 2 * WPIECES + 4) { VP_WAIT_VMCNT(2 * WPIECES + 4); }              \
+        else if (newer_ >= 2 * WPIECES + 2) { VP_WAIT_VMCNT(2 * WPIECES + 2); }              \
+        else if (newer_ >= 2 * WPIECES) { VP_WAIT_VMCNT(2 * WPIECES); }                      \
+        else if (newer_ >= 4) { VP_WAIT_VMCNT(4); }                                          \
+        else if (newer_ >= 2) { VP_WAIT_VMCNT(2); }                                          \
         else { VP_WAIT_VMCNT(0); }                                                           \
       }                                                                                      \
     }                                                                                        \

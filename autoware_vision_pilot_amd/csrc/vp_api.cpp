@@ -454,6 +454,19 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
         if (g.acts()[i].get() == y) g.read_act((int)i, out);
       return VP_OK;
     }
+    if (mode == 3) {  // a head's logits convolution: 3x3, fp32 NCHW output straight from the kernel (STORE_NCHW_F32)
+      if (ks != 3 || act != 0 || res_mode != 0) throw std::invalid_argument("mode 3: 3x3, no activation, no residual");
+      float* d_out = g.alloc_f32((size_t)cout * h * w);
+      vp::ConvOpts lo;
+      lo.tile = tile;
+      lo.logits_out = d_out;
+      const size_t wn3 = (size_t)cin * cout * 9;
+      g.add_conv("op", a, std::vector<float>(weight, weight + wn3), std::vector<float>(bias, bias + cout), cout, 3, lo);
+      g.run_eager();
+      g.sync();
+      if (hipMemcpy(out, d_out, (size_t)cout * h * w * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("mode 3: copy back failed");
+      return VP_OK;
+    }
     vp::ConvOpts o;
     o.act = act;
     o.tile = tile;

@@ -458,7 +458,7 @@ def op_conv2d(x, weight, bias, ks=3, mode=0, act=0, res=None, res_mode=0, precis
     cout = weight.shape[1] if mode == 1 else weight.shape[0]
     if mode == 2:  # (ConvTranspose weight [cin][cout][2][2], skip 1x1 weight [cout][cs]) and the two biases, concatenated
         cout = len(bias) // 2
-    oh, ow = (2 * h, 2 * w) if mode >= 1 else (h, w)
+    oh, ow = (2 * h, 2 * w) if mode in (1, 2) else (h, w)
     out = np.empty((cout, oh, ow), dtype=np.float32)
     r = np.ascontiguousarray(res, dtype=np.float32) if res is not None else None
     err = C.create_string_buffer(512)

@@ -225,6 +225,7 @@ int vp_tensor_read(vp_engine* e, int i, float* dst_chw);                       /
  * mode 2: ConvTranspose2d k2 s2 of `in` + Conv2d 1x1 of a skip tensor in ONE launch (the decoders' up-sample + skip-link
  * pairs): `res` is the skip INPUT [res_mode channels][2h][2w], weight = ConvTranspose weight followed by the 1x1 weight
  * [Cout][res_mode], bias = the two bias vectors one after the other; act / tile / bk / nsplit are ignored.
+ * mode 3: a head's last convolution (3x3, no activation): the kernel writes fp32 NCHW logits itself.
  * tile/bk/nsplit: -1 = engine heuristic.  in/res/out are fp32 CHW host buffers. */
 int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,

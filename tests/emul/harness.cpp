@@ -6,7 +6,7 @@
 namespace vp {  // dynamic-LDS arrays of the kernels (per worker thread = per running workgroup): 160 KiB, the size of a CU's LDS
 alignas(16) VP_EMU_LDS char smem[160 << 10];
 alignas(16) VP_EMU_LDS unsigned char dw_smem[160 << 10];
-alignas(16) VP_EMU_LDS float mean[40 << 10];
+alignas(16) VP_EMU_LDS unsigned char se_smem[64 << 10];
 alignas(16) VP_EMU_LDS float xs[40 << 10];
 alignas(16) VP_EMU_LDS float sh[40 << 10];
 }  // namespace vp
@@ -81,16 +81,6 @@ int emu_dwconv_batched(void* in_hi, void* in_lo, int H, int W, int C, void* out_
   DwParams p{view(in_hi, in_lo, H, W, C), view(out_hi, out_lo, OH, OW, C), w, b, k, stride, sums, replicas, frames};
   return launch_dwconv(p, nullptr);
 }
-int emu_se_batched(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1, float* s1,
-                   const float* w, void* out_hi, void* out_lo, int rows, const float* w2, const float* b2, int frames) {
-  SeParams p{};
-  p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.s1 = s1; p.frames = frames;
-  if (launch_se_fc1(p, nullptr)) return 1;
-  ScaleWParams q{};
-  q.w = w; q.out_hi = static_cast<half_t*>(out_hi); q.out_lo = static_cast<half_t*>(out_lo); q.rows = rows; q.C = C; q.s1 = s1; q.w2 = w2; q.b2 = b2;
-  q.sq = sq; q.Creal = Creal; q.frames = frames;
-  return launch_se_scale_weights(q, nullptr);
-}
 int emu_se_gate_scale(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1,
                       const float* w, void* out_hi, void* out_lo, int rows, const float* w2, const float* b2, int frames) {
   SeParams p{};
@@ -99,18 +89,6 @@ int emu_se_gate_scale(const unsigned long long* sums, int replicas, int C, int C
   q.w = w; q.out_hi = static_cast<half_t*>(out_hi); q.out_lo = static_cast<half_t*>(out_lo); q.rows = rows; q.C = C; q.w2 = w2; q.b2 = b2;
   q.sq = sq; q.Creal = Creal; q.frames = frames;
   return launch_se_gate_scale(p, q, nullptr);
-}
-int emu_se_fc1(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1, float* s1) {
-  SeParams p{};
-  p.sums = sums; p.replicas = replicas; p.C = C; p.Creal = Creal; p.sq = sq; p.inv_hw = inv_hw; p.w1 = w1; p.b1 = b1; p.s1 = s1;
-  return launch_se_fc1(p, nullptr);
-}
-int emu_se_scale_weights(const float* w, void* out_hi, void* out_lo, int rows, int C, const float* s1, const float* w2, const float* b2, int sq,
-                         int Creal) {
-  ScaleWParams p{};
-  p.w = w; p.out_hi = static_cast<half_t*>(out_hi); p.out_lo = static_cast<half_t*>(out_lo); p.rows = rows; p.C = C; p.s1 = s1; p.w2 = w2; p.b2 = b2;
-  p.sq = sq; p.Creal = Creal;
-  return launch_se_scale_weights(p, nullptr);
 }
 int emu_fc(const float* x, const float* w, const float* b, float* out, int N, int K, int act) {
   FcParams p{};

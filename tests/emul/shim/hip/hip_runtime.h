@@ -415,9 +415,34 @@ F16 mfma_32x32x16_f16(H8 a, H8 b, F16 c) {
   return c;
 }
 
+// v_mfma_f32_16x16x32_f16 (gfx950): D[16x16] = A[16x32] * B[32x16] + C over one wave.  Register layout:
+//   A: lane l holds row m = l % 16, columns k = 8 * (l / 16) + 0..7;   B: lane l holds column n = l % 16, rows k = 8 * (l / 16) + 0..7;
+//   C / D: lane l holds column n = l % 16; element r (0..3) is row m = 4 * (l / 16) + r.
+template <class H8, class F4>
+F4 mfma_16x16x32_f16(H8 a, H8 b, F4 c) {
+  const int i = lin(), wv = i / 64, lane = i % 64;
+  const unsigned op = next_wave_op();
+  float* A = mfma_buf_a(wv, op);
+  float* B = mfma_buf_b(wv, op);
+  for (int e = 0; e < 8; ++e) {
+    A[lane * 8 + e] = (float)a[e];
+    B[lane * 8 + e] = (float)b[e];
+  }
+  sync_wave();
+  const int n = lane % 16;
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * (lane / 16) + r;
+    float acc = 0.0f;
+    for (int k = 0; k < 32; ++k) acc += A[(m + 16 * (k / 8)) * 8 + (k % 8)] * B[(n + 16 * (k / 8)) * 8 + (k % 8)];
+    c[r] += acc;
+  }
+  return c;
+}
+
 }  // namespace emu
 
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma_32x32x16_f16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu::mfma_16x16x32_f16(a, b, c)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 // LDS-DMA (global_load_lds_dwordx4): lane i's 16 bytes land at the wave-uniform LDS address + 16 * i.  Performed at issue.
 #define VP_GLOBAL_LOAD_LDS16(G, L) std::memcpy(reinterpret_cast<char*>(L) + 16 * (threadIdx.x & 63), reinterpret_cast<const char*>(G), 16)

@@ -1,5 +1,5 @@
 """The MFMA convolution kernels (csrc/kernels_conv.hip, kernels_conv3x3.hip, kernels_conv3x3_region.hip,
-kernels_convt_stream.hip) and the engine code that packs weights and plans them, executed on the CPU: every csrc/ source
+kernels_convt_rs.hip) and the engine code that packs weights and plans them, executed on the CPU: every csrc/ source
 is compiled for the host on the HIP-on-CPU shim of tests/emul, whose `v_mfma_f32_32x32x16_f16` is a wave-level rendezvous
 with the ISA's register layout.  Same entry point (vp_op_conv2d), reference (PyTorch) and tolerances as the GPU op tests
 (tests/test_gpu_conv_op.py), on maps small enough for thread-per-work-item emulation: tile shapes, K blocks, split-K,
@@ -116,11 +116,10 @@ def test_generic_gemm_kernel(emu_lib, precision):
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
 def test_conv_transpose_pixel_shuffle(emu_lib, precision):
-    """ConvTranspose2d(k2, s2) as a GEMM with the pixel-shuffle store; K = 128 takes the persistent streaming kernel."""
+    """ConvTranspose2d(k2, s2) as a GEMM with the pixel-shuffle store; K = 128 on >= 2048 pixels takes the register-stationary kernel."""
     _case(emu_lib, 64, 48, 5, 6, 2, 1, 0, 0, precision, [(-1, -1, -1), (1, 32, 1), (2, 64, 1)], seed=7)
     _case(emu_lib, 128, 64, 4, 8, 2, 1, 1, 0, precision, [(-1, -1, -1)], seed=8)
-    # >= 2048 pixels, no activation: the fp16 engine takes the persistent streaming kernel (several tiles per workgroup, deep
-    # register ring, wave-private epilogue patch); the fp16x3 engine the GEMM kernel
+    # >= 2048 pixels, K = 128, map width a multiple of 32: both engines take kernels_convt_rs.hip on their own
     _case(emu_lib, 128, 128, 40, 64, 2, 1, 0, 0, precision, [(-1, -1, -1)], seed=11)
 
 
@@ -160,6 +159,29 @@ def test_convt_register_stationary_kernel(emu_lib, precision, monkeypatch):
     monkeypatch.delenv("VP_CONVT_RS")
     with pytest.raises(emu_lib.VpError):
         _case(emu_lib, 64, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=45)               # K = 64: not covered
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_head_logits_conv_kernel(emu_lib, precision, monkeypatch):
+    """kernels_head.hip through vp_op_conv2d mode 3 (fp32 NCHW logits written by the kernel): 16x16x32 MFMA with the weights
+    stationary in registers, LDS-DMA halo with the zero page for the border and the pad slots, persistent workgroups; 64 channels
+    (one slab, 8x16 tiles) and 128 channels (two slabs meeting in LDS, 4x16 tiles), 1 and 3 logit channels, maps that are not a
+    multiple of the tile; the same layers through the halo kernel's 32-channel tile."""
+    tol = 1.5e-3 if precision == 0 else 2e-5
+    for seed, (cin, cout, h, w) in enumerate([(64, 3, 19, 37), (128, 1, 10, 33), (128, 3, 16, 48), (64, 1, 8, 16)]):
+        rng = np.random.default_rng(60 + seed)
+        x = rng.standard_normal((cin, h, w), dtype=np.float32)
+        wt = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9)))
+        b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+        q = (lambda a: a) if precision == 1 else _h
+        ref = F.conv2d(torch.from_numpy(q(x)).double()[None], torch.from_numpy(q(wt)).double(), torch.from_numpy(b).double(), padding=1)[0].float().numpy()
+        got = emu_lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
+        err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+        assert got.shape == ref.shape and err <= tol, (cin, cout, h, w, err)
+        monkeypatch.setenv("VP_HEAD_CONV", "0")                          # same layer through the halo kernel's 32-channel tile
+        halo = emu_lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
+        monkeypatch.delenv("VP_HEAD_CONV")
+        assert float((np.abs(halo - ref) / np.maximum(1.0, np.abs(ref))).max()) <= tol
 
 
 def test_region_kernel(emu_lib):

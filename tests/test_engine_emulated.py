@@ -155,7 +155,7 @@ def test_scene_network_end_to_end_on_cpu(emu_lib, kind, seed):
 
 def test_sceneseg_fp16_benchmark_mode_on_cpu(emu_lib):
     """The precision bench.py reports (VP_FP16: single fp16 plane, fp16 activation variants, register epilogues, the
-    persistent streaming ConvTranspose) through the whole SceneSeg network on the CPU; the GPU test's bar: max |error| within
+    register-stationary ConvTranspose) through the whole SceneSeg network on the CPU; the GPU test's bar: max |error| within
     3e-2 of the largest logit, >= 99.5 % class agreement."""
     import torch
 
@@ -173,7 +173,7 @@ def test_sceneseg_fp16_benchmark_mode_on_cpu(emu_lib):
         assert float(np.abs(got - ref).max() / np.abs(ref).max()) <= 3e-2
         assert float((got.argmax(0) == ref.argmax(0)).mean()) >= 0.995
         kernels = {eng_k for eng_k in _layer_kernels(eng)}
-        assert any(k.startswith("convt_stream") for k in kernels) and any("regepi" in k for k in kernels)   # the fp16-only paths ran
+        assert any(k.startswith("convt_rs") for k in kernels) and any("regepi" in k for k in kernels) and any(k.startswith("head_conv3x3") for k in kernels)   # the fp16-only paths ran
     finally:
         eng.close()
 

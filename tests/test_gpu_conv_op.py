@@ -165,3 +165,27 @@ def test_convt_register_stationary_kernel(precision, monkeypatch):
     monkeypatch.setenv("VP_CONVT_RS", "0")
     gemm = lib.op_conv2d(x, wcat, bcat, mode=2, res=sk, res_mode=cs, precision=precision)
     assert (np.abs(gemm - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_head_logits_conv_kernel(precision, monkeypatch):
+    """kernels_head.hip (vp_op_conv2d mode 3: the kernel writes fp32 NCHW logits): 16x16x32 MFMA, weights stationary in registers,
+    LDS-DMA halo with the zero page; the heads' real shapes (64 -> 3 and 128 -> 1 on 320x640: 12 / 25 tiles per persistent
+    workgroup) and ragged maps, against torch and against the halo kernel's 32-channel tile; same bits run to run."""
+    from autoware_vision_pilot_amd import lib
+
+    tol = 1.5e-3 if precision == 0 else 2e-5
+    for seed, (cin, cout, h, w) in enumerate([(64, 3, 320, 640), (128, 1, 320, 640), (128, 3, 80, 160), (64, 2, 19, 37), (128, 1, 10, 33)]):
+        rng = np.random.default_rng(90 + seed)
+        x = rng.standard_normal((cin, h, w), dtype=np.float32)
+        wt = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9)))
+        b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+        ref = _reference(x, wt, b, 3, 0, 0, None, 0, fp16=(precision == 0))
+        got = lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert got.shape == ref.shape and err.max() <= tol, (cin, cout, h, w, err.max(), np.unravel_index(err.argmax(), err.shape))
+        assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision))
+        monkeypatch.setenv("VP_HEAD_CONV", "0")
+        halo = lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
+        monkeypatch.delenv("VP_HEAD_CONV")
+        assert (np.abs(halo - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol

@@ -178,49 +178,41 @@ def test_depthwise_pool_kernel(emu, C, k, stride, H, W):
     assert _rel(o16.astype(np.float32).transpose(2, 0, 1), want16) <= 2e-3
 
 
-def test_squeeze_excite_kernels(emu):
-    """se_fc1 (means from the replica rows -> squeeze FC -> SiLU) and se_scale_weights (excite FC -> sigmoid gate folded into
-    the projection weights' K axis, pad channels gated to 0)."""
-    rng = np.random.default_rng(7)
-    C, Creal, sq, rows, hw, replicas = 160, 144, 6, 64, 35, 16
-    act = np.zeros((hw, C), dtype=np.float32)
-    act[:, :Creal] = rng.standard_normal((hw, Creal)).astype(np.float32)
-    fixed = np.rint(act.astype(np.float64) * 2.0 ** 24).astype(np.int64)
-    sums = np.zeros((replicas, C), dtype=np.int64)
-    for i in range(hw):
-        sums[i % replicas] += fixed[i]
-    w1 = np.zeros((sq, C), np.float32)
-    w1[:, :Creal] = rng.standard_normal((sq, Creal)).astype(np.float32) * 0.2
-    b1 = rng.standard_normal(sq).astype(np.float32) * 0.1
-    s1 = np.zeros(sq, np.float32)
-    emu.emu_se_fc1.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float, ct.c_void_p, ct.c_void_p, ct.c_void_p]
-    assert emu.emu_se_fc1(ptr(sums.view(np.uint64)), replicas, C, Creal, sq, 1.0 / hw, ptr(w1), ptr(b1), ptr(s1)) == 0
-    mean = (fixed.sum(axis=0).astype(np.float64) / 2.0 ** 24 / hw).astype(np.float32)
-    z = w1 @ mean + b1
-    want_s1 = z / (1.0 + np.exp(-z))
-    assert np.abs(s1 - want_s1).max() <= 1e-5
-
-    w2 = np.zeros((C, sq), np.float32)
-    w2[:Creal] = rng.standard_normal((Creal, sq)).astype(np.float32) * 0.5
-    b2 = np.zeros(C, np.float32)
-    b2[:Creal] = rng.standard_normal(Creal).astype(np.float32) * 0.2
-    w = rng.standard_normal((rows, C)).astype(np.float32)
-    hi, lo = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
-    assert emu.emu_se_scale_weights(ptr(w), ptr(hi), ptr(lo), rows, C, ptr(s1), ptr(w2), ptr(b2), sq, Creal) == 0
-    gate = 1.0 / (1.0 + np.exp(-(w2 @ s1 + b2)))
-    gate[Creal:] = 0.0
-    want = w * gate[None, :]
-    got = hi.astype(np.float32) + lo.astype(np.float32)
-    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
-    assert np.all(got[:, Creal:] == 0)
-    hi2 = np.zeros((rows, C), np.float16)
-    assert emu.emu_se_scale_weights(ptr(w), ptr(hi2), None, rows, C, ptr(s1), ptr(w2), ptr(b2), sq, Creal) == 0
-    assert np.array_equal(hi2, hi)
-    # the engine's form: both FCs and the scaling in ONE launch (se_gate_scale_kernel) -- same bits as the two launches
+def test_squeeze_excite_kernel(emu):
+    """se_gate_scale: means from the replica rows -> squeeze FC -> SiLU -> excite FC -> sigmoid gate folded into the projection
+    weights' K axis (pad channels gated to 0), one launch; wide (sq = 48, C = 1152: 5 K segments per unit) and narrow (sq = 4:
+    64 segments) shapes; the fp16 engine's single-plane output equals the hi plane."""
     emu.emu_se_gate_scale.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 5 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
-    hi3, lo3 = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
-    assert emu.emu_se_gate_scale(ptr(sums.view(np.uint64)), replicas, C, Creal, sq, 1.0 / hw, ptr(w1), ptr(b1), ptr(w), ptr(hi3), ptr(lo3), rows, ptr(w2), ptr(b2), 1) == 0
-    assert np.array_equal(hi3, hi) and np.array_equal(lo3, lo)
+    for seed, (C, Creal, sq, rows, hw, replicas) in enumerate([(160, 144, 6, 64, 35, 16), (1152, 1152, 48, 192, 200, 8), (96, 96, 4, 32, 900, 64)]):
+        rng = np.random.default_rng(7 + seed)
+        act = np.zeros((hw, C), dtype=np.float32)
+        act[:, :Creal] = rng.standard_normal((hw, Creal)).astype(np.float32)
+        fixed = np.rint(act.astype(np.float64) * 2.0 ** 24).astype(np.int64)
+        sums = np.zeros((replicas, C), dtype=np.int64)
+        for i in range(hw):
+            sums[i % replicas] += fixed[i]
+        w1 = np.zeros((sq, C), np.float32)
+        w1[:, :Creal] = rng.standard_normal((sq, Creal)).astype(np.float32) * 0.2
+        b1 = rng.standard_normal(sq).astype(np.float32) * 0.1
+        w2 = np.zeros((C, sq), np.float32)
+        w2[:Creal] = rng.standard_normal((Creal, sq)).astype(np.float32) * 0.5
+        b2 = np.zeros(C, np.float32)
+        b2[:Creal] = rng.standard_normal(Creal).astype(np.float32) * 0.2
+        w = rng.standard_normal((rows, C)).astype(np.float32)
+        hi, lo = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
+        assert emu.emu_se_gate_scale(ptr(sums.view(np.uint64)), replicas, C, Creal, sq, 1.0 / hw, ptr(w1), ptr(b1), ptr(w), ptr(hi), ptr(lo), rows, ptr(w2), ptr(b2), 1) == 0
+        mean = (fixed.sum(axis=0).astype(np.float64) / 2.0 ** 24 / hw)
+        z = w1.astype(np.float64) @ mean + b1
+        s1 = z / (1.0 + np.exp(-z))
+        gate = 1.0 / (1.0 + np.exp(-(w2.astype(np.float64) @ s1 + b2)))
+        gate[Creal:] = 0.0
+        want = w * gate[None, :]
+        got = hi.astype(np.float32) + lo.astype(np.float32)
+        assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max(), (C, sq)
+        assert np.all(got[:, Creal:] == 0)
+        hi2 = np.zeros((rows, C), np.float16)
+        assert emu.emu_se_gate_scale(ptr(sums.view(np.uint64)), replicas, C, Creal, sq, 1.0 / hw, ptr(w1), ptr(b1), ptr(w), ptr(hi2), None, rows, ptr(w2), ptr(b2), 1) == 0
+        assert np.array_equal(hi2, hi)
 
 
 def test_fc_kernel(emu):
@@ -363,9 +355,9 @@ def test_autodrive_glue_kernels(emu):
 @pytest.mark.parametrize("split", [True, False])
 def test_batched_depthwise_and_se_kernels_equal_per_frame_launches(emu, split):
     """Batched encoder (grid.z / grid.y = camera frame): the BATCH instantiations of the depthwise + pool kernel and of the
-    two squeeze-excite kernels must produce, per frame, exactly what the single-frame launches produce."""
+    squeeze-excite kernel must produce, per frame, exactly what the single-frame launches produce."""
     rng = np.random.default_rng(29)
-    frames, C, k, stride, H, W, replicas, sq, rows = 3, 56, 5, 2, 9, 13, 8, 6, 40
+    frames, C, k, stride, H, W, replicas, sq, rows = 3, 64, 5, 2, 9, 13, 8, 6, 40
     OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
     xh, xl = split16(rng.standard_normal((frames, H, W, C)).astype(np.float32))
     wk = (rng.standard_normal((k * k, C)) * 0.3).astype(np.float32)
@@ -378,25 +370,17 @@ def test_batched_depthwise_and_se_kernels_equal_per_frame_launches(emu, split):
     oh, ol = np.zeros((frames, OH, OW, C), np.float16), np.zeros((frames, OH, OW, C), np.float16)
     sums = np.zeros((frames, replicas, C), np.uint64)
     assert emu.emu_dwconv_batched(ptr(xh), lo_or_none(xl), H, W, C, ptr(oh), lo_or_none(ol), OH, OW, ptr(wk), ptr(b), k, stride, ptr(sums), replicas, frames) == 0
-    s1 = np.zeros((frames, sq), np.float32)
     ph, pl = np.zeros((frames, rows, C), np.float16), np.zeros((frames, rows, C), np.float16)
-    emu.emu_se_batched.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 6 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
-    assert emu.emu_se_batched(ptr(sums), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(s1), ptr(pw), ptr(ph), lo_or_none(pl), rows, ptr(w2), ptr(b2), frames) == 0
+    emu.emu_se_gate_scale.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 5 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
+    assert emu.emu_se_gate_scale(ptr(sums), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(pw), ptr(ph), lo_or_none(pl), rows, ptr(w2), ptr(b2), frames) == 0
 
-    emu.emu_se_fc1.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float, ct.c_void_p, ct.c_void_p, ct.c_void_p]
     for f in range(frames):
         o1, o2 = np.zeros((OH, OW, C), np.float16), np.zeros((OH, OW, C), np.float16)
         sm = np.zeros((replicas, C), np.uint64)
         fx, fl = np.ascontiguousarray(xh[f]), np.ascontiguousarray(xl[f])
         assert emu.emu_dwconv(ptr(fx), lo_or_none(fl), H, W, C, ptr(o1), lo_or_none(o2), OH, OW, ptr(wk), ptr(b), k, stride, ptr(sm), replicas) == 0
         assert np.array_equal(oh[f], o1) and np.array_equal(ol[f], o2) and np.array_equal(sums[f], sm), f
-        t1 = np.zeros(sq, np.float32)
-        assert emu.emu_se_fc1(ptr(sm), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(t1)) == 0
         q1, q2 = np.zeros((rows, C), np.float16), np.zeros((rows, C), np.float16)
-        assert emu.emu_se_scale_weights(ptr(pw), ptr(q1), lo_or_none(q2), rows, C, ptr(t1), ptr(w2), ptr(b2), sq, C) == 0
-        assert np.array_equal(s1[f], t1) and np.array_equal(ph[f], q1) and np.array_equal(pl[f], q2), f
-    emu.emu_se_gate_scale.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 5 + [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int]
-    gh, gl = np.zeros((frames, rows, C), np.float16), np.zeros((frames, rows, C), np.float16)
-    assert emu.emu_se_gate_scale(ptr(sums), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(pw), ptr(gh), lo_or_none(gl), rows, ptr(w2), ptr(b2), frames) == 0
-    assert np.array_equal(gh, ph) and np.array_equal(gl, pl)                    # one-launch form, batched: same bits
+        assert emu.emu_se_gate_scale(ptr(sm), replicas, C, C, sq, 1.0 / (OH * OW), ptr(w1), ptr(b1), ptr(pw), ptr(q1), lo_or_none(q2), rows, ptr(w2), ptr(b2), 1) == 0
+        assert np.array_equal(ph[f], q1) and np.array_equal(pl[f], q2), f
     assert len({sums[f].tobytes() for f in range(frames)}) == frames            # the frames really differ
