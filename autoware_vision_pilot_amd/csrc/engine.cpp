@@ -458,6 +458,11 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     if (!pw_gemm_supported(p)) throw std::invalid_argument("pointwise kernel (tile 4): 1x1, stride 1, bias + {none, SiLU} + optional residual add, NHWC: " + name);
     op.kernel = std::string("pw_gemm<") + (sp ? "x3>" : "x1>");
     op.run = [p, sp](hipStream_t st) { return launch_pw_gemm(p, sp, st); };
+  } else if (tile == 6 && !(tile != 5 && !(std::getenv("VP_CONVT_RS") && std::getenv("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
+    if (!gemm_dma_supported(p, sp))
+      throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
+    op.kernel = std::string("gemm_dma<co256,px128,") + (sp ? "x3>" : "x1>") + (pc.nsplit > 1 ? "+splitk" : "");
+    op.run = [p](hipStream_t st) { return launch_gemm_dma(p, st); };
   } else if (tile == 5 || (!(std::getenv("VP_CONVT_RS") && std::getenv("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
     if (!convt_rs_supported(p, sp))
       throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
@@ -646,6 +651,26 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   return out;
 }
 
+// The small-map up-sampling GEMMs go to the LDS-DMA pipelined kernel (kernels_gemm_dma.hip; tile 6).  Measured per layer on
+// MI355X (SceneSeg neck, us, old -> new): parity mode 42.1 / 41.0 / 42.2 -> 37.9 / 37.7 / 37.7 and +2.8 % frames/s with three
+// frames in flight (fewer workgroups at a higher rate leave CUs to the other frames); fp16 30.4 / 23.4 / 25.4 -> 26.8 / 26.8 /
+// 21.7: the fp16 engines take it from 2048 pixels up only.  VP_GEMM_DMA=1: wherever the shape fits, =0: never.
+bool Engine::gemm_dma_wanted(int M, int ncols, int cin_pad, int cin2_pad, int cstore) const {
+  const char* e = std::getenv("VP_GEMM_DMA");
+  if (e && e[0] == '0') return false;
+  if (!split() && M < 2048 && !(e && e[0] == '1')) return false;
+  return gemm_dma_shape_ok(M, ncols, cin_pad, cin2_pad, cstore);
+}
+
+// split-K factor of that kernel: towards ~160 workgroups while a slice keeps >= 8 K steps (VP_GEMM_DMA_NSPLIT: developer knob)
+int Engine::gemm_dma_nsplit(int M, int ncols, int kw) const {
+  if (const char* e = std::getenv("VP_GEMM_DMA_NSPLIT")) return std::max(1, std::atoi(e));
+  const int tiles = ((M + 127) / 128) * (ncols / 256), steps = kw / 32;
+  int ns = 1;
+  while (tiles * ns < 128 && steps / (ns + 1) >= 8) ++ns;
+  return ns;
+}
+
 // ConvTranspose2d(k2,s2): w [cin][cout][2][2] -> GEMM rows n = (dy*2+dx)*Cout_pad + co over input pixels.
 Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
                        const ConvOpts& o) {
@@ -662,6 +687,10 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
   if (split() && oo.tile < 0 && ncols % 128 == 0) {
     oo.tile = 0;
     if (oo.bk < 0) oo.bk = 32;
+  }
+  if (gemm_dma_wanted(in->H * in->W, ncols, cin_pad, 0, cpad) && o.tile < 0) {
+    oo.tile = 6;
+    oo.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad);
   }
   if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
   if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
@@ -708,6 +737,10 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
   if (split() && ncols % 128 == 0) {  // parity mode: see add_convT
     o.tile = 0;
     o.bk = 32;
+  }
+  if (gemm_dma_wanted(in->H * in->W, ncols, cin_pad, cs_pad, cpad)) {
+    o.tile = 6;
+    o.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad + cs_pad);
   }
   if (const char* e = std::getenv("VP_CONVT_TILE")) o.tile = std::atoi(e);
   PackedConv pc;

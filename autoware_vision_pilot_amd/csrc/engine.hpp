@@ -166,6 +166,8 @@ class Engine {
   const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)
   template <class T>
   T* dupload(const std::vector<T>& v);
+  int gemm_dma_nsplit(int M, int ncols, int kw) const;
+  bool gemm_dma_wanted(int M, int ncols, int cin_pad, int cin2_pad, int cstore) const;
   void choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc);
   void push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
                     int store_mode, int cout_real);

@@ -52,6 +52,14 @@ static int conv(int precision, int mode, int cin, int cout, int h, int w, int ks
   return rc;
 }
 
+static int conv_logits(int precision, int cin, int cout, int h, int w) {  // vp_op_conv2d mode 3: kernels_head.hip
+  std::vector<float> x = rnd((size_t)cin * h * w), wt = rnd((size_t)cin * cout * 9, 0.1f), b = rnd(cout, 0.1f), out((size_t)cout * h * w);
+  char err[256] = {0};
+  const int rc = vp_op_conv2d(0, precision, 3, x.data(), cin, h, w, wt.data(), b.data(), cout, 3, 0, 0, nullptr, -1, -1, -1, out.data(), err, sizeof err);
+  if (rc) std::fprintf(stderr, "vp_op_conv2d(mode 3) failed: %s\n", err);
+  return rc;
+}
+
 __global__ void canary_kernel(float* out) {
   __shared__ float lds[64];
   lds[threadIdx.x] = (float)threadIdx.x;
@@ -104,6 +112,13 @@ int main(int argc, char** argv) {
     if (precision == 1 || quick) bad |= conv(1, 1, 128, 128, 32, 64, 2, 0, 5, -1, 1);
     if (!quick) bad |= conv(precision, 1, 128, 128, 32, 64, 2, 0, 5, -1, 1);
     unsetenv("VP_CONVT_RS_GROUPS");
+    // LDS-DMA GEMM (kernels_gemm_dma.hip): three-stage ring, one barrier per K step, patches over the ring; 256 pixels = two tiles, 8 K steps
+    if (precision == 1 || quick) bad |= conv(1, 1, 256, 256, 8, 32, 2, 0, 6, -1, 1);
+    // a head's logits convolution (kernels_head.hip) is reached through mode 3 only: see conv_logits below
+  }
+  if (!skip_conv) {  // heads' logits convolution: DMA halo + zero page, slab reduction through LDS (128 channels)
+    bad |= conv_logits(1, 128, 3, 9, 33);
+    if (!quick) bad |= conv_logits(0, 64, 1, 17, 20);
   }
   if (!skip_conv && !quick) {
     bad |= conv(0, 0, 64, 40, 10, 40, 3, 1, 200, -1, 2);  // region kernel
@@ -117,7 +132,7 @@ int main(int argc, char** argv) {
     bad |= emu_stem(x.data(), H, W, w.data(), b.data(), hi.data(), lo.data());
     for (int k : {3, 5})
       for (int split = 0; split < 2; ++split) {
-        const int C = 144, h = 13, ww = 21, stride = k == 5 ? 2 : 1, oh = (h + stride - 1) / stride, ow = (ww + stride - 1) / stride;
+        const int C = 160, h = 13, ww = 21, stride = k == 5 ? 2 : 1, oh = (h + stride - 1) / stride, ow = (ww + stride - 1) / stride;
         std::vector<half_t> ih = rnd16((size_t)h * ww * C), il = rnd16(ih.size()), oh_((size_t)oh * ow * C), ol_(oh_.size());
         std::vector<float> wk = rnd((size_t)k * k * C, 0.3f), bb = rnd(C, 0.1f);
         std::vector<unsigned long long> sums(8 * C, 0ull);
@@ -125,7 +140,7 @@ int main(int argc, char** argv) {
                           sums.data(), 8);
         std::vector<float> w1 = rnd(6 * C, 0.2f), b1 = rnd(6, 0.1f), s1(6), w2 = rnd(C * 6, 0.5f), b2 = rnd(C, 0.1f), pw = rnd(64 * C);
         std::vector<half_t> ph((size_t)64 * C), pl(ph.size());
-        bad |= emu_se_gate_scale(sums.data(), 8, C, C, 6, 1.0f / (oh * ow), w1.data(), b1.data(), pw.data(), ph.data(), split ? pl.data() : nullptr, 64, C, w2.data(), b2.data(), 1);
+        bad |= emu_se_gate_scale(sums.data(), 8, C, C, 6, 1.0f / (oh * ow), w1.data(), b1.data(), pw.data(), ph.data(), split ? pl.data() : nullptr, 64, w2.data(), b2.data(), 1);
       }
     std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
     bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);

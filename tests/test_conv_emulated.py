@@ -184,6 +184,25 @@ def test_head_logits_conv_kernel(emu_lib, precision, monkeypatch):
         assert float((np.abs(halo - ref) / np.maximum(1.0, np.abs(ref))).max()) <= tol
 
 
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_gemm_dma_kernel(emu_lib, precision, monkeypatch):
+    """kernels_gemm_dma.hip (tile 6): both operands by LDS-DMA three K steps deep, slot swizzle and weight-row permutation applied
+    on the DMA's global side, wave-private patch epilogue; ragged pixel count (last tile re-reads the last pixel), K of 8 and of
+    more steps, the fused skip link (K extension from the 2H x 2W tensor, quadrant of the workgroup), two weight-row tiles per
+    quadrant; against torch and against the implicit-GEMM kernel on the same layer."""
+    monkeypatch.setenv("VP_GEMM_DMA", "1")          # fp16 engines take it only on request
+    _case(emu_lib, 256, 256, 9, 15, 2, 1, 0, 0, precision, [(6, -1, 1)], seed=51)                   # 135 pixels: one full tile + 7 pixels
+    _case(emu_lib, 320, 512, 8, 16, 2, 1, 0, 0, precision, [(6, -1, 1), (6, -1, 3)], seed=52)       # 10 K steps, 8 weight tiles; 3 K slices (3 + 3 + 4 steps)
+    a = _skip_case(emu_lib, 256, 24, 256, 10, 16, precision, seed=53)                               # 8 + 1 K steps, 160 pixels
+    b = _skip_case(emu_lib, 512, 40, 512, 12, 20, precision, seed=54)                               # 16 + 2 K steps, two tiles per quadrant
+    monkeypatch.setenv("VP_GEMM_DMA", "0")
+    assert float(np.abs(a - _skip_case(emu_lib, 256, 24, 256, 10, 16, precision, seed=53)).max()) <= (4e-3 if precision == 0 else 2e-5)
+    assert float(np.abs(b - _skip_case(emu_lib, 512, 40, 512, 12, 20, precision, seed=54)).max()) <= (4e-3 if precision == 0 else 2e-5)
+    monkeypatch.setenv("VP_GEMM_DMA", "1")
+    with pytest.raises(emu_lib.VpError):
+        _case(emu_lib, 256, 96, 9, 15, 2, 1, 0, 0, precision, [(6, -1, 1)], seed=55)                # 4 * 96 rows: not a multiple of 256
+
+
 def test_region_kernel(emu_lib):
     """kernels_conv3x3_region.hip (opt-in in the engine, fp16 engines only): 10x40 and 16x32 regions."""
     _case(emu_lib, 64, 40, 10, 40, 3, 0, 1, 0, 0, [(200, -1, 1), (200, -1, 2)], seed=9)

@@ -189,3 +189,38 @@ def test_head_logits_conv_kernel(precision, monkeypatch):
         halo = lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
         monkeypatch.delenv("VP_HEAD_CONV")
         assert (np.abs(halo - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_gemm_dma_kernel(precision, monkeypatch):
+    """kernels_gemm_dma.hip (tile 6; the engine's choice for the three small-map up-sampling stages in the parity mode): the neck's
+    real shapes incl. the fused skip link, against torch and the implicit-GEMM kernel; same bits run to run (asynchronous DMA ring)."""
+    from autoware_vision_pilot_amd import lib
+
+    monkeypatch.setenv("VP_GEMM_DMA", "1")
+    tol = 1.5e-3 if precision == 0 else 2e-5
+    rng = np.random.default_rng(123 + precision)
+    for cin, cs, cout, h, w in ((1280, 80, 1280, 10, 20), (768, 40, 768, 20, 40), (512, 24, 512, 40, 80), (256, 0, 256, 9, 15)):
+        x = rng.standard_normal((cin, h, w), dtype=np.float32)
+        wt = rng.standard_normal((cin, cout, 2, 2), dtype=np.float32) * np.float32(np.sqrt(2.0 / cin))
+        bt = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+        q = (lambda a: a) if precision == 1 else _h
+        y = F.conv_transpose2d(torch.from_numpy(q(x)).double()[None], torch.from_numpy(q(wt)).double(), torch.from_numpy(bt).double(), stride=2)
+        if cs:
+            sk = rng.standard_normal((cs, 2 * h, 2 * w), dtype=np.float32)
+            ws = rng.standard_normal((cout, cs), dtype=np.float32) * np.float32(np.sqrt(2.0 / cs))
+            bs = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+            y = y + F.conv2d(torch.from_numpy(q(sk)).double()[None], torch.from_numpy(q(ws)).double()[:, :, None, None], torch.from_numpy(bs).double())
+            run = lambda: lib.op_conv2d(x, np.concatenate([wt.ravel(), ws.ravel()]), np.concatenate([bt, bs]), mode=2, res=sk, res_mode=cs, precision=precision)
+        else:
+            run = lambda: lib.op_conv2d(x, wt, bt, ks=2, mode=1, precision=precision, tile=6)
+        ref = y[0].float().numpy()
+        got = run()
+        err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+        assert got.shape == ref.shape and err.max() <= tol, (cin, cs, cout, h, w, err.max())
+        for _ in range(3):
+            assert np.array_equal(got, run())
+        if cs:
+            monkeypatch.setenv("VP_GEMM_DMA", "0")
+            assert (np.abs(run() - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
+            monkeypatch.setenv("VP_GEMM_DMA", "1")
