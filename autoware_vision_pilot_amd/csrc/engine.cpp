@@ -420,9 +420,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
-    if (ht == 6 || ht == 7) {
-      if (!conv3x3_x3_supported(p)) throw std::invalid_argument("halo tiles 6 / 7 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128-channel tiles, no split-K: " + name);
-      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : "conv3x3_x3w4<co128,px128>") + (pc.nsplit > 1 ? "+splitk" : "");
+    if (ht == 6 || ht == 7 || ht == 8) {
+      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 / 7 / 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K: " + name);
+      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -542,7 +542,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         (void)wgs8;
       }
     }
-    if ((halo == 6 || halo == 7) && !split()) throw std::invalid_argument("halo tiles 6 / 7 are fp16x3 kernels: " + name);
+    if ((halo == 6 || halo == 7 || halo == 8) && !split()) throw std::invalid_argument("halo tiles 6 / 7 / 8 are fp16x3 kernels: " + name);
   }
   // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
   // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
@@ -616,6 +616,21 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     pc.nsplit = std::max(1, std::min(ns, KC));
     if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
     if (halo == 7 && blocks >= 160 && o.nsplit <= 0) pc.nsplit = 1;
+    // 64-channel tiles of the parity mode: the pipelined kernel's 64-channel shape (halo tile 8: same tiles, same split factor as
+    // halo tile 3, three workgroups per CU).  Measured on MI355X (SceneSeg, us, halo tile 3 -> tile 8): decode_layer_0..3 70.5 /
+    // 48.1 / 82.6 / 60.2 -> 77.9 / 54.6 / 90.2 / 65.6, decode_layer_5 98.6 -> 106.5, decode_layer_9 (128 -> 64 channels on
+    // 320x640) 108.0 -> 102.2; 389 -> 381 frames/s with it everywhere.  So: only the short-K big-map case (as for tile 7);
+    // VP_X3_C64=1 wherever the epilogue fits (plain, or anything behind split-K), =0 nowhere.
+    if (halo == 3 && split() && o.tile < 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 && cstride == 1) {
+      const char* e8 = std::getenv("VP_X3_C64");
+      const bool plain8 = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
+      const bool fits = plain8 || pc.nsplit > 1;
+      const bool want8 = e8 ? e8[0] == '1' : (pc.nsplit == 1 && cin_pad <= 128 && M >= 65536);
+      if (fits && want8) {
+        halo = 8;
+        pc.tile = 108;
+      }
+    }
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }
@@ -627,7 +642,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-        const int ci_sw = (halo == 6 || halo == 7) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
+        const int ci_sw = (halo == 6 || halo == 7 || halo == 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;

@@ -53,7 +53,7 @@ namespace vp {
 // writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
 // fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
 template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false>
-__global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
@@ -371,22 +371,26 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void conv3x3_x3_kernel(const Con
   }
 }
 
-bool conv3x3_x3_supported(const ConvGemmParams& p) {
-  if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % 128 == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
+// shape 8 ("x3w4c64"): 8x16 pixels x 64 channels, 4 waves of 32 channels x 64 pixels, 53 KB of LDS: THREE independent workgroups per CU.
+// The layers whose 128-channel tiles are too few (64-channel outputs, small maps with split-K): same workgroup count and split
+// factor as the halo kernel's 64-channel tile (halo tile 3), the pipelined schedule instead of its lone-wave one.
+bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
+  const int co_tile = shape == 8 ? 64 : 128;
+  if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
   if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
   return p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
 }
 
-template <int TH, int WPX, bool HDB>
+template <int CO, int TH, int WPX, bool HDB>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
-  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
+  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (CO * 64);
   static_assert(lds <= 160 * 1024, "LDS budget");
   const bool gelu = p.act == ACT_GELU, sk = p.nsplit > 1;
-  auto k = sk ? conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_NONE, 0, true>
-              : (gelu ? conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU> : conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_NONE>);
+  auto k = sk ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, 0, true>
+              : (gelu ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_GELU> : conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE>);
   static LdsAttrOnce attr_once[3];
   if (hipError_t e = set_max_dynamic_lds(attr_once[sk ? 2 : gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
-  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / 128) * p.nsplit);
+  dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / CO) * p.nsplit);
   hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -395,9 +399,10 @@ static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
 
 // shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
-  if (!conv3x3_x3_supported(p)) return hipErrorInvalidValue;
-  if (shape == 6) return launch_x3_cfg<16, 4, true>(p, st);
-  if (shape == 7) return launch_x3_cfg<8, 2, false>(p, st);
+  if (!conv3x3_x3_supported(p, shape)) return hipErrorInvalidValue;
+  if (shape == 6) return launch_x3_cfg<128, 16, 4, true>(p, st);
+  if (shape == 7) return launch_x3_cfg<128, 8, 2, false>(p, st);
+  if (shape == 8) return launch_x3_cfg<64, 8, 2, false>(p, st);
   return hipErrorInvalidValue;
 }
 

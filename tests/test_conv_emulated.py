@@ -82,8 +82,9 @@ def test_x3w8_kernel(emu_lib):
     chunk) boundaries, three weight buffers, single-buffered halo with the two-barrier chunk hand-over (tile 7), register
     epilogue with both planes; one and several 32-channel chunks, GELU and no activation, an image that is not a multiple of
     the patch, two output-channel tiles; bit-identical to halo tile 1 (same K order)."""
-    _case(emu_lib, 32, 128, 16, 32, 3, 0, 1, 0, 1, [(106, -1, 1), (107, -1, 1)], seed=21)
-    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 1, [(106, -1, 1), (107, -1, 1)], seed=22)
+    _case(emu_lib, 32, 128, 16, 32, 3, 0, 1, 0, 1, [(106, -1, 1), (107, -1, 1), (108, -1, 1)], seed=21)
+    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 1, [(106, -1, 1), (107, -1, 1), (108, -1, 1)], seed=22)
+    _case(emu_lib, 64, 64, 9, 17, 3, 0, 1, 0, 1, [(108, -1, 1), (108, -1, 2)], seed=26)         # 64-channel shape: one channel tile, ragged map; two K slices
     rng = np.random.default_rng(23)
     x = rng.standard_normal((64, 18, 33), dtype=np.float32)
     wt = rng.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.float32(0.06)
@@ -92,9 +93,10 @@ def test_x3w8_kernel(emu_lib):
     c = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=101, nsplit=1)
     assert np.array_equal(a, c)
     assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1), c)
+    assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=108, nsplit=1), c)      # 64-channel shape: same K order too
     # split-K slices of the 4-wave shape (fp32 partials + finish kernel), incl. a mul-add residual (context_layer_6's epilogue)
     _case(emu_lib, 160, 128, 10, 20, 3, 0, 1, 0, 1, [(107, -1, 2), (107, -1, 5)], seed=24)
-    _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3)], seed=25)
+    _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3), (108, -1, 3)], seed=25)
     with pytest.raises(emu_lib.VpError):
         emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # fp16 engines have no tile 6
 

@@ -102,10 +102,12 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
     assert err.max() <= 2e-5, err.max()
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=101, nsplit=1))
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=1))   # 4-wave shape, single halo buffer
+    assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=108, nsplit=1))   # 64-channel shape, three workgroups per CU
     for ns in (2, 3):                                                                                      # split-K slices + finish kernel
         if cin >= 32 * ns:
             sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=ns)
             assert (np.abs(sk - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5
+            assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=108, nsplit=ns))   # same slices, same finish kernel
     with pytest.raises(lib.VpError):
         lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=106, nsplit=1)
 
