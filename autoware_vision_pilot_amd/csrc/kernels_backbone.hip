@@ -201,9 +201,8 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const PoolParams p) {
 // projection and REBUILDS the means and all squeeze units itself (<= 48 x 1152 multiply-adds, one pass over the L2-resident fc1
 // matrix): cheaper than a dependent launch (7-10 us of the single-stream frame; this used to be two launches per block).
 // The kernel is a chain of dependent global round trips, so every phase is laid out for as few of them as possible:
-//   1 means    the replicas x C 64-bit sums are read as 16-byte pairs, eight independent loads per thread in flight, and added
-//              into LDS with 64-bit integer atomics (any order gives the same bits; a thread summing its channel's 8..64 rows
-//              one after the other was 8 serial round trips)
+//   1 means    the replicas x C 64-bit sums are read as 16-byte pairs by (pair, replica-slice) threads, all loads of a thread
+//              independent, the slices summed in LDS (integers: any grouping gives the same bits)
 //   2 squeeze  thread = (unit, K segment): all units at once, each thread a 16-byte-wide dot product over its segment, the
 //              segments of a unit summed in a fixed order (one wave per unit walking the units in turn: 12 serial round trips)
 //   3 excite   8 partial dot products per channel in a fixed order, one lane per channel finishes: sigmoid gate
@@ -218,40 +217,52 @@ __global__ __launch_bounds__(256) void se_gate_scale_kernel(const SeParams sein,
     if (p.out_lo) p.out_lo += (size_t)blockIdx.y * p.rows * p.C;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char se_smem[];
-  unsigned long long* const acc = reinterpret_cast<unsigned long long*>(se_smem);   // [C]
-  float* const mean = reinterpret_cast<float*>(se_smem + (size_t)se.C * 8);          // [C]
+  const int acc_rows = (se.C >> 1) >= 256 ? 1 : 256 / (se.C >> 1);
+  unsigned long long* const acc = reinterpret_cast<unsigned long long*>(se_smem);   // [acc_rows][C] partial sums of the replica slices
+  float* const mean = reinterpret_cast<float*>(se_smem + (size_t)acc_rows * se.C * 8);  // [C]
   __shared__ float red[256];
   __shared__ float s1[64];
   __shared__ float gate[32];
   __shared__ float part[8][32];
   const int tid = threadIdx.x, C = se.C;
-  // ---- 1: means
-  for (int c = tid; c < C; c += 256) acc[c] = 0ull;
-  __syncthreads();
+  // ---- 1: means.  Thread = (channel pair, slice of the replica rows): every load of a thread is independent (one or two round
+  // trips), the slices of a pair meet in LDS; integer sums, so any grouping gives the same bits.  (LDS atomics per loaded pair
+  // serialise -- load -> ds_add_u64 chains, 11 us in round 1 -- and a thread walking its channel's 8..64 rows alone is 8 trips.)
   {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const int CP = C >> 1, n = se.replicas * CP;  // 16-byte pairs; row r, pair cp sits at sums[r * C + 2 cp]: linear index = pair index
+    const int CP = C >> 1;                                  // 16-byte pairs per row
+    const int TPC = CP >= 256 ? 1 : 256 / CP;               // threads per pair
+    const int rows_per = (se.replicas + TPC - 1) / TPC;
     const u64x2* src = reinterpret_cast<const u64x2*>(se.sums);
-    for (int base = 0; base < n; base += 256 * 8) {
-      u64x2 v[8];
+    for (int cp = tid % (TPC == 1 ? 256 : CP); cp < CP; cp += 256) {
+      const int g = TPC == 1 ? 0 : tid / CP;
+      if (g >= TPC) break;
+      const int r_begin = g * rows_per, r_end = min(se.replicas, r_begin + rows_per);
+      unsigned long long a0 = 0ull, a1 = 0ull;
+      int r = r_begin;
+      for (; r + 8 <= r_end; r += 8) {
+        u64x2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * 256 + tid;
-        v[u] = idx < n ? src[idx] : u64x2{0ull, 0ull};
-      }
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(r + u) * CP + cp];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * 256 + tid;
-        if (idx < n) {
-          const int cp = idx % CP;
-          if (v[u][0]) atomicAdd(&acc[2 * cp], v[u][0]);
-          if (v[u][1]) atomicAdd(&acc[2 * cp + 1], v[u][1]);
-        }
+        for (int u = 0; u < 8; ++u) { a0 += v[u][0]; a1 += v[u][1]; }
       }
+      for (; r < r_end; ++r) {
+        const u64x2 v = src[(size_t)r * CP + cp];
+        a0 += v[0];
+        a1 += v[1];
+      }
+      acc[(size_t)g * C + 2 * cp] = a0;
+      acc[(size_t)g * C + 2 * cp + 1] = a1;
+      if (TPC > 1) break;  // one pair per thread in the sliced form
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      unsigned long long t = acc[c];
+      for (int g = 1; g < TPC; ++g) t += acc[(size_t)g * C + c];
+      mean[c] = (float)((double)(long long)t * (1.0 / 16777216.0)) * se.inv_hw;
     }
   }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) mean[c] = (float)((double)(long long)acc[c] * (1.0 / 16777216.0)) * se.inv_hw;
   __syncthreads();
   // ---- 2: squeeze FC
   {
@@ -405,7 +416,8 @@ hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st) {
 }
 hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipStream_t st) {
   if (!se.sums || se.C != sw.C || se.sq != sw.sq || se.frames != sw.frames || se.sq < 1 || se.sq > 64 || (se.C & 31)) return hipErrorInvalidValue;
-  const size_t lds = (size_t)se.C * 12;
+  const int acc_rows = (se.C >> 1) >= 256 ? 1 : 256 / (se.C >> 1);
+  const size_t lds = (size_t)se.C * (8 * acc_rows + 4);
   if (se.frames > 1) VP_LAUNCH(se_gate_scale_kernel<true>, dim3(sw.C / 32, se.frames), dim3(256), lds, st, se, sw);
   VP_LAUNCH(se_gate_scale_kernel<false>, dim3(sw.C / 32), dim3(256), lds, st, se, sw);
 }

@@ -151,6 +151,11 @@ class Camera:
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner from C stdio when
+    # NCCL_DEBUG is set, at process exit, i.e. AFTER our line): keep the real stdout for the JSON line, point fd 1 at stderr.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -424,7 +429,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":
