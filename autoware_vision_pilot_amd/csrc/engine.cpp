@@ -458,7 +458,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     if (!pw_gemm_supported(p)) throw std::invalid_argument("pointwise kernel (tile 4): 1x1, stride 1, bias + {none, SiLU} + optional residual add, NHWC: " + name);
     op.kernel = std::string("pw_gemm<") + (sp ? "x3>" : "x1>");
     op.run = [p, sp](hipStream_t st) { return launch_pw_gemm(p, sp, st); };
-  } else if (tile == 6 && !(tile != 5 && !(std::getenv("VP_CONVT_RS") && std::getenv("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
+  } else if (tile == 6) {  // its weights are packed in its own layout (add_convT*): no other kernel may take this launch
     if (!gemm_dma_supported(p, sp))
       throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
     op.kernel = std::string("gemm_dma<co256,px128,") + (sp ? "x3>" : "x1>") + (pc.nsplit > 1 ? "+splitk" : "");
@@ -538,7 +538,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured
         // on MI355X, the 4-wave shape without split-K took 139 vs 100 us on decode_layer_5 (200 patches) and its split-K form
         // (kernel support kept, tile 107 + nsplit) 63 vs 47 / 79 vs 70 us on decode_layer_1 / 3 (profiles/r02_splitk_x3w4.txt)
-        if (plain && wgs16 >= 160) halo = want == 6 ? 6 : 7;
+        static const char* envw = std::getenv("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
+        if (plain && wgs16 >= (envw ? std::atoi(envw) : 160)) halo = want == 6 ? 6 : 7;
         (void)wgs8;
       }
     }
@@ -593,6 +594,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     int ns = 1;
     if (o.nsplit > 0) {
       ns = o.nsplit;
+    } else if (halo == 4 && o.logits_out && cout <= 4 && (cin_pad == 64 || cin_pad == 128) && o.res_mode == RES_NONE && o.act == ACT_NONE &&
+               cstride == 1 && !(std::getenv("VP_HEAD_CONV") && std::getenv("VP_HEAD_CONV")[0] == '0')) {
+      ns = 1;  // a head's logits convolution goes to kernels_head.hip (persistent workgroups: needs no split on any map size)
     } else if (blocks < 256 && split()) {
       // parity mode (measured per layer with VP_NSPLIT_FORCE = 1..16, profiles/r02_splitk_sweep_fp16x3.txt): ONE full round of
       // workgroups at two per CU -- ns = floor(512 / blocks), at most one slice per input chunk.  A little past 512 (the fp16
@@ -670,10 +674,13 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
 // MI355X (SceneSeg neck, us, old -> new): parity mode 42.1 / 41.0 / 42.2 -> 37.9 / 37.7 / 37.7 and +2.8 % frames/s with three
 // frames in flight (fewer workgroups at a higher rate leave CUs to the other frames); fp16 30.4 / 23.4 / 25.4 -> 26.8 / 26.8 /
 // 21.7: the fp16 engines take it from 2048 pixels up only.  VP_GEMM_DMA=1: wherever the shape fits, =0: never.
-bool Engine::gemm_dma_wanted(int M, int ncols, int cin_pad, int cin2_pad, int cstore) const {
+bool Engine::gemm_dma_wanted(int H, int W, int ncols, int cin_pad, int cin2_pad, int cstore) const {
+  const int M = H * W;
   const char* e = std::getenv("VP_GEMM_DMA");
   if (e && e[0] == '0') return false;
   if (!split() && M < 2048 && !(e && e[0] == '1')) return false;
+  const char* rs = std::getenv("VP_CONVT_RS");  // the register-stationary kernel's shapes are its own (and keep the plain weight layout)
+  if (!(rs && rs[0] == '0') && convt_rs_shape_case(H, W, cin_pad, cin2_pad, ncols, cstore) != 0) return false;
   return gemm_dma_shape_ok(M, ncols, cin_pad, cin2_pad, cstore);
 }
 
@@ -703,13 +710,15 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
     oo.tile = 0;
     if (oo.bk < 0) oo.bk = 32;
   }
-  if (gemm_dma_wanted(in->H * in->W, ncols, cin_pad, 0, cpad) && o.tile < 0) {
+  if (gemm_dma_wanted(in->H, in->W, ncols, cin_pad, 0, cpad) && o.tile < 0) {
     oo.tile = 6;
     oo.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad);
   }
   if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
   if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
   choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, oo, &pc);
+  if (pc.tile == 6 && !(gemm_dma_shape_ok(in->H * in->W, ncols, cin_pad, 0, cpad) && pc.CoutW == ncols))  // before the weights are packed in its layout
+    throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
   std::vector<half_t> hi((size_t)pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
   std::vector<float> bias(pc.CoutW, 0.0f);
   for (int q = 0; q < 4; ++q)
@@ -720,8 +729,9 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
         const float v = w[((size_t)ci * cout + co) * 4 + q];  // [ci][co][dy][dx], q = dy*2+dx
         half_t h, l;
         split_half(v, &h, &l);
-        hi[(size_t)n * cin_pad + ci] = h;
-        if (split()) lo[(size_t)n * cin_pad + ci] = l;
+        const size_t d = pc.tile == 6 ? gemm_dma_pack_index(n, ci, cin_pad) : (size_t)n * cin_pad + ci;
+        hi[d] = h;
+        if (split()) lo[d] = l;
       }
     }
   pc.w_hi = dupload(hi);
@@ -753,14 +763,16 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
     o.tile = 0;
     o.bk = 32;
   }
-  if (gemm_dma_wanted(in->H * in->W, ncols, cin_pad, cs_pad, cpad)) {
+  if (gemm_dma_wanted(in->H, in->W, ncols, cin_pad, cs_pad, cpad)) {
     o.tile = 6;
     o.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad + cs_pad);
   }
   if (const char* e = std::getenv("VP_CONVT_TILE")) o.tile = std::atoi(e);
   PackedConv pc;
   choose_conv_cfg(in->H * in->W, ncols, cin_pad + cs_pad, 1, o, &pc);
-  const bool fusable = cpad % conv_tile_co(pc.tile) == 0 && !(env && env[0] == '0');
+  if (pc.tile == 6 && !(gemm_dma_shape_ok(in->H * in->W, ncols, cin_pad, cs_pad, cpad) && pc.CoutW == ncols))
+    throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): shape not covered: " + up_name);
+  const bool fusable = (cpad % conv_tile_co(pc.tile) == 0 && !(env && env[0] == '0')) || pc.tile == 6;
   if (!fusable) {
     Act* u = add_convT(up_name, in, wt, bt, cout, ConvOpts{});
     ConvOpts so;
@@ -782,8 +794,9 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
         const size_t col = k < cin ? k : cin_pad + (k - cin);
         half_t h, l;
         split_half(v, &h, &l);
-        hi[(size_t)n * kw + col] = h;
-        if (split()) lo[(size_t)n * kw + col] = l;
+        const size_t d = pc.tile == 6 ? gemm_dma_pack_index(n, (int)col, kw) : (size_t)n * kw + col;
+        hi[d] = h;
+        if (split()) lo[d] = l;
       }
     }
   pc.w_hi = dupload(hi);

@@ -167,7 +167,7 @@ class Engine {
   template <class T>
   T* dupload(const std::vector<T>& v);
   int gemm_dma_nsplit(int M, int ncols, int kw) const;
-  bool gemm_dma_wanted(int M, int ncols, int cin_pad, int cin2_pad, int cstore) const;
+  bool gemm_dma_wanted(int H, int W, int ncols, int cin_pad, int cin2_pad, int cstore) const;
   void choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc);
   void push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
                     int store_mode, int cout_real);

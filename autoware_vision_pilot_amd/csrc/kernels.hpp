@@ -119,10 +119,12 @@ bool head_conv_supported(const ConvGemmParams& p);
 hipError_t launch_head_conv(const ConvGemmParams& p, const void* zeros, hipStream_t st);
 // ConvTranspose (+ skip link) GEMM on the small maps: 8 waves, both operands by LDS-DMA three K steps deep (kernels_gemm_dma.hip)
 bool gemm_dma_shape_ok(int M, int ncols, int cin_pad, int cin2_pad, int cstore);
+size_t gemm_dma_pack_index(int n, int k, int kw);  // host packing of its weights (LDS image order per 256 x 32 tile)
 bool gemm_dma_supported(const ConvGemmParams& p, bool split);
 hipError_t launch_gemm_dma(const ConvGemmParams& p, hipStream_t st);
 // register-stationary weights, pixel tiles by LDS-DMA (kernels_convt_rs.hip): K = 128, or 256 + 32 with the skip link; both precisions
 bool convt_rs_supported(const ConvGemmParams& p, bool split);
+int convt_rs_shape_case(int H, int W, int cin_pad, int cin2_pad, int ncols, int cstore);  // 0 = not covered
 hipError_t launch_convt_rs(const ConvGemmParams& p, hipStream_t st);
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, hipStream_t st);

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(512, 2) void convt_rs_kernel(const ConvGemmParams p
 #undef VP_DMA_TILE
 }
 
+int convt_rs_shape_case(int H, int W, int cin_pad, int cin2_pad, int ncols, int cstore);
+
 namespace {
 template <int KC1, int KC2, int NT, bool SPLIT>
 hipError_t launch_rs_cfg(const ConvGemmParams& p, hipStream_t st) {
@@ -209,13 +211,19 @@ hipError_t launch_rs_cfg(const ConvGemmParams& p, hipStream_t st) {
 // 0 = not covered; else 1: K = 128 (all four quadrants per workgroup), 2: K = 256 + 32 with the skip link (one quadrant per workgroup)
 int rs_case(const ConvGemmParams& p) {
   if (p.ks != 1 || p.stride > 1 || p.store_mode != STORE_SHUFFLE2 || p.act != ACT_NONE || p.res_mode != RES_NONE || p.nsplit != 1 ||
-      p.post_act != ACT_NONE || p.out_hi == nullptr || p.CoutW != p.Ncols || p.W % 32 != 0 || p.H * p.W < 2048)
+      p.post_act != ACT_NONE || p.out_hi == nullptr || p.CoutW != p.Ncols)
     return 0;
-  if (p.Cin == 128 && p.Cin2 == 0 && p.Ncols % 512 == 0 && p.Cstore % 64 == 0) return 1;
-  if (p.Cin == 256 && p.Cin2 == 32 && p.Ncols % 256 == 0 && p.Cstore % 256 == 0) return 2;
-  return 0;
+  return convt_rs_shape_case(p.H, p.W, p.Cin, p.Cin2, p.Ncols, p.Cstore);
 }
 }  // namespace
+
+// the shape part of the test (the engine asks before it packs the weights)
+int convt_rs_shape_case(int H, int W, int cin_pad, int cin2_pad, int ncols, int cstore) {
+  if (W % 32 != 0 || H * W < 2048) return 0;
+  if (cin_pad == 128 && cin2_pad == 0 && ncols % 512 == 0 && cstore % 64 == 0) return 1;
+  if (cin_pad == 256 && cin2_pad == 32 && ncols % 256 == 0 && cstore % 256 == 0) return 2;
+  return 0;
+}
 
 bool convt_rs_supported(const ConvGemmParams& p, bool split) { return split == (p.in_lo != nullptr) && split == (p.out_lo != nullptr) && rs_case(p) != 0; }
 

@@ -61,16 +61,13 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
   // ---- DMA plan.  A lane moves the 16-byte slot (lane & 3) of row 16 j + (lane >> 2); the slot holds the logical chunk
   // slot ^ swz(row).  A rows: j = wave and wave + 8; B rows: j = wave.
   const int slot = lane & 3;
-  size_t a_src[2];  // element offset of this lane's chunk at K step 0, for the lane's two weight rows
+  // WEIGHTS: the host packs every (256-row tile, K step) as one contiguous 16 KB block per plane in its LDS IMAGE order
+  // (gemm_dma_pack_index below: rows permuted, slots swizzled), so a DMA instruction is a linear 1 KB copy of eight full cache
+  // lines (64-byte row pieces of the plain [rows][K] matrix were 16 half lines per instruction: the L2 -> LDS path is what bounds
+  // this kernel).  This lane's 16 bytes of the wave's two 1 KB pieces (j = wave, wave + 8) of the tile of K step 0:
+  size_t a_src[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int R = 16 * (wave + 8 * i) + (lane >> 2);               // row of the LDS tile
-    // LDS row R = 64 w + 32 T + rho (rho = 8 g + 4 h + i2: MFMA row) holds weight row co0 + 64 w + 32 h + 16 T + 4 g + i2, so that
-    // accumulator register 4 g + i2 of tile T in lane (pixel, h) is channel 32 h + 16 T + 4 g + i2 of the wave's 64
-    const int rho = R & 31, T = (R >> 5) & 1, g = rho >> 3, h = (rho >> 2) & 1, i2 = rho & 3;
-    const int wrow = co0 + (R & ~63) + 32 * h + 16 * T + 4 * g + i2;
-    a_src[i] = (size_t)wrow * Kw + ((slot ^ ((R >> 2) & 3)) << 3);
-  }
+  for (int i = 0; i < 2; ++i) a_src[i] = (size_t)tile_co * KS_all * (CO_T * BK) + (size_t)(wave + 8 * i) * 512 + lane * 8;
   long long b_src1, b_src2;  // element offsets of this lane's chunk of its pixel row: ConvTranspose input / skip tensor
   {
     const int r = 16 * wave + (lane >> 2);
@@ -85,8 +82,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
     char* st_ = smem + (BUF) * STAGE + wave * 1024;                                                                \
     const int k0_ = (s_first + (S)) * BK;                                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-      VP_GLOBAL_LOAD_LDS16(p.w_hi + a_src[i] + k0_, st_ + i * 8192);                                               \
-      if constexpr (SPLIT) VP_GLOBAL_LOAD_LDS16(p.w_lo + a_src[i] + k0_, st_ + A_BYTES + i * 8192);                \
+      VP_GLOBAL_LOAD_LDS16(p.w_hi + a_src[i] + (size_t)(s_first + (S)) * (CO_T * BK), st_ + i * 8192);             \
+      if constexpr (SPLIT) VP_GLOBAL_LOAD_LDS16(p.w_lo + a_src[i] + (size_t)(s_first + (S)) * (CO_T * BK), st_ + A_BYTES + i * 8192); \
     }                                                                                                              \
     if (s_first + (S) < KS1) {                                                                                     \
       VP_GLOBAL_LOAD_LDS16(p.in_hi + b_src1 + k0_, st_ + OFF_B);                                                   \
@@ -234,6 +231,18 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// Where element (row n, column k) of the [ncols][kw] weight matrix goes in the packed layout: tile (n / 256, k / 32) is a block of
+// 256 x 32 elements in LDS image order -- LDS row R = 64 w + 32 T + rho (rho = 8 g + 4 h + i2: MFMA row) holds weight row
+// 64 w + 32 h + 16 T + 4 g + i2 of the tile (accumulator register 4 g + i2 of tile T in lane (pixel, h) is then channel
+// 32 h + 16 T + 4 g + i2 of the wave's 64), and the row's four 16-byte slots are XOR-swizzled by (R >> 2) & 3.
+size_t gemm_dma_pack_index(int n, int k, int kw) {
+  const int tile_co = n >> 8, r = n & 255, w = r >> 6, c = r & 63;       // c = 32 h + 16 T + 4 g + i2
+  const int h = c >> 5, T = (c >> 4) & 1, g = (c >> 2) & 3, i2 = c & 3;
+  const int R = 64 * w + 32 * T + 8 * g + 4 * h + i2;
+  const int s = k >> 5, chunk = (k & 31) >> 3, e = k & 7;
+  return ((size_t)tile_co * (kw / 32) + s) * (256 * 32) + (size_t)R * 32 + ((chunk ^ ((R >> 2) & 3)) << 3) + e;
 }
 
 bool gemm_dma_shape_ok(int M, int ncols, int cin_pad, int cin2_pad, int cstore) {
