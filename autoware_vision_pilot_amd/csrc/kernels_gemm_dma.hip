@@ -23,7 +23,9 @@
 
 namespace vp {
 
-template <bool SPLIT>
+// ABL: ablation bits for tools/gemm_dma_ablate.hip only (1 = no DMA in the K loop, 2 = no MFMA, 4 = no LDS fragment reads in the loop,
+// 8 = no barrier / vmcnt wait in the loop, 16 = no epilogue); always 0 in the library.
+template <bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p) {
   constexpr int CO_T = 256, PX_T = 128, BK = 32, ROWB = 64;
   constexpr int PLANES = SPLIT ? 2 : 1;
@@ -143,24 +145,44 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
     const char* st = smem + (s % 3) * STAGE;
     const char* st_next = smem + ((s + 1) % 3) * STAGE;
     // tile s+2 -> the buffer tile s-1 was read from (everyone passed the previous step's barrier with those reads complete)
-    if (s + 2 < KS) VP_DMA_STAGE(s + 2, (s + 2) % 3)
+    if constexpr (!(ABL & 1)) {
+      if (s + 2 < KS) VP_DMA_STAGE(s + 2, (s + 2) % 3)
+    }
     __builtin_amdgcn_sched_barrier(0);
-    VP_MFMA_RANGE(0, 0, MT * NT / 2)
+    if constexpr (!(ABL & 2)) VP_MFMA_RANGE(0, 0, MT * NT / 2)
     __builtin_amdgcn_sched_barrier(0);
-    VP_READ_FRAGS(1, st)
+    if constexpr (!(ABL & 4)) VP_READ_FRAGS(1, st)
     __builtin_amdgcn_sched_barrier(0);
-    VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)
+    if constexpr (!(ABL & 2)) VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)
     // tile s+1 (requested one step ago) must be visible behind the barrier; the tile requested in this step stays in flight
-    if (s + 2 < KS) { VP_WAIT_VMCNT(D); } else { VP_WAIT_VMCNT(0); }
-    VP_LDS_BARRIER();
-    if (s + 1 < KS) VP_READ_FRAGS(0, st_next)
+    if constexpr (!(ABL & 8)) {
+      if (s + 2 < KS && !(ABL & 1)) { VP_WAIT_VMCNT(D); } else { VP_WAIT_VMCNT(0); }
+      VP_LDS_BARRIER();
+    }
+    if constexpr (!(ABL & 4)) {
+      if (s + 1 < KS) VP_READ_FRAGS(0, st_next)
+    }
     __builtin_amdgcn_sched_barrier(0);
-    VP_MFMA_RANGE(1, 0, MT * NT)
+    if constexpr (!(ABL & 2)) VP_MFMA_RANGE(1, 0, MT * NT)
+    if constexpr ((ABL & 2) != 0) {  // keep the fragments alive
+      acc[0][0][0] += (float)fa[0][0][0] + (float)fb[0][0][0] + (float)fa[1][0][0] + (float)fb[1][0][0];
+    }
   }
 #undef VP_MFMA_RANGE
 #undef VP_READ_FRAGS
 #undef VP_DMA_STAGE
   VP_LDS_BARRIER();  // every wave has read its last fragments: the ring becomes the epilogue patches
+  if constexpr ((ABL & 16) != 0) {  // ablation: keep the accumulators alive (a store no launch ever takes), skip the epilogue
+    if (p.H == -12345) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.partial[(i * NT + j) * 16 + r + tid * 64] = acc[i][j][r];
+    }
+    return;
+  }
 
   // ---- wave-private epilogue, one 32-pixel tile at a time
   char* const mypatch = smem + wave * PATCH;
@@ -209,6 +231,10 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
       }
   }
   const f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  // pixel-shuffle address: quadrant / channel of this lane's piece are fixed, (y, x) of its first row divided ONCE, then advanced
+  // by 8 pixels per pass (two integer divisions per 16-byte store were ~110 VALU instructions each)
+  const int cq = co - quad * p.Cstore, W2 = 2 * p.W;
+  int em = m0 + wpx * 64 + r0, ey = em / p.W, ex = em - ey * p.W;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -223,11 +249,16 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-      const int m = m0 + wpx * 64 + j * 32 + r0 + pass * 8;
       const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(pr + pass * 8 * PP);
       const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(pr + pass * 8 * PP + 16);
       float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-      if (m < M) epilogue_store8<STORE_SHUFFLE2, RES_NONE, ACT_NONE>(p, M, m, co, v, b0, b1);
+      if (em < M) epilogue_store8<STORE_SHUFFLE2, RES_NONE, ACT_NONE>(p, M, em, co, v, b0, b1, ((long long)(2 * ey + qdy) * W2 + (2 * ex + qdx)) * p.Cstore + cq);
+      em += 8;
+      ex += 8;
+      while (ex >= p.W) {
+        ex -= p.W;
+        ++ey;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
