@@ -422,7 +422,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     }
     if (ht == 6 || ht == 7 || ht == 8) {
       if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 / 7 / 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K: " + name);
-      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
+      op.kernel = std::string(ht == 6 ? (sp ? "conv3x3_x3w8<co128,px256>" : "conv3x3_x1w8<co128,px256>") : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -543,7 +543,15 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         (void)wgs8;
       }
     }
-    if ((halo == 6 || halo == 7 || halo == 8) && !split()) throw std::invalid_argument("halo tiles 6 / 7 / 8 are fp16x3 kernels: " + name);
+    // VP_FP16 engines: the 8-wave pipelined shape on single planes (kernels_conv3x3_x3.hip, X3 = false) for the same big layers;
+    // VP_X1_W8=0 keeps the halo kernel's 128-channel 16x16 tile
+    if (!split() && o.tile < 0 && (halo == 0 || halo == 1) && ncols % 128 == 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 &&
+        (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE) {
+      static const char* env1 = std::getenv("VP_X1_W8");
+      auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
+      if (env1 && env1[0] == '1' && cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128) >= 160) halo = 6;
+    }
+    if ((halo == 7 || halo == 8) && !split()) throw std::invalid_argument("halo tiles 7 / 8 are fp16x3 kernels: " + name);
   }
   // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
   // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.

@@ -52,18 +52,23 @@ namespace vp {
 // SPLITK: grid carries p.nsplit K slices per tile; a slice covers the input chunks [KC * z / nsplit, KC * (z + 1) / nsplit) and
 // writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
 // fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false>
-__global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
+// X3 = false: the SAME schedule on single fp16 planes (the VP_FP16 engines: one MFMA per tile pair, half the LDS plan -> two 8-wave
+// workgroups per CU, four waves per SIMD; shape 6 only).
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool X3 = true>
+__global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) void conv3x3_x3_kernel(const ConvGemmParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
   constexpr int HCHUNKS = HPX * 4, HP = (HCHUNKS + NTH - 1) / NTH;
   constexpr int MT = CO_TILE / WCO / 32, NT = PX / WPX / 32;
   constexpr int NHB = HDB ? 2 : 1;
+  constexpr int PL = X3 ? 2 : 1;  // planes per tensor
+  constexpr int LT = X3 ? 0 : 1;  // HDB: tap at which the next chunk's halo pieces are loaded (stored at the start of tap 3); the single-plane
+                                  // form has 128 registers per wave: one tap less of live range keeps the pieces out of scratch memory
   static_assert(MT >= 1 && NT >= 1 && HP <= 3, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo_base = smem;                               // [NHB][2 planes][HALO_BYTES]
-  char* const w_base = smem + NHB * 2 * HALO_BYTES;           // [3][2 planes][W_BYTES]
+  char* const w_base = smem + NHB * PL * HALO_BYTES;          // [3][PL planes][W_BYTES]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave / WPX, wpx = wave % WPX;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // fragment sets [K sub-step parity]: set 0 = channels 0..15 of the tap's 32, set 1 = channels 16..31
-  h8_t fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
+  h8_t fa[2][MT], fal[2][X3 ? MT : 1], fb[2][NT], fbl[2][X3 ? NT : 1];
   // halo staging ring (compile-time slots): piece pc in slot pc
   u32x4 rh_hi[3], rh_lo[3];
 #pragma unroll
@@ -136,10 +141,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   {                                                                                          \
     const int si_ = (SIDX) < s_last ? (SIDX) : s_last;                                       \
     const size_t base_ = (size_t)si_ * w_step + w_goff0;                                     \
-    char* dst_ = w_base + (BUF) * 2 * W_BYTES + wave * 1024;                                 \
+    char* dst_ = w_base + (BUF) * PL * W_BYTES + wave * 1024;                                \
     _Pragma("unroll") for (int pc = 0; pc < WPIECES; ++pc) {                                 \
       VP_GLOBAL_LOAD_LDS16(p.w_hi + base_ + pc * NW * 512, dst_ + pc * NW * 1024);           \
-      VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
+      if constexpr (X3) VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
     }                                                                                        \
   }
 #define VP_LOAD_H(SLOT, PC, C)                                                               \
@@ -147,26 +152,27 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     const int g_ = h_goff[PC];                                                               \
     const int o_ = (g_ >= 0 ? g_ : 0) + (c_first + (C)) * 32;                                \
     const u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in_hi + o_);                          \
-    const u32x4 l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                          \
+    u32x4 l_ = zero4;                                                                        \
+    if constexpr (X3) l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                    \
     rh_hi[SLOT] = g_ >= 0 ? v_ : zero4;                                                      \
     rh_lo[SLOT] = g_ >= 0 ? l_ : zero4;                                                      \
   }
 #define VP_STORE_H(SLOT, PC, BUF)                                                            \
   if (tid + NTH * (PC) < HCHUNKS) {                                                          \
-    char* dst_ = halo_base + (BUF) * 2 * HALO_BYTES + h_lds0 + (PC) * (NTH / 4) * ROWB;      \
+    char* dst_ = halo_base + (BUF) * PL * HALO_BYTES + h_lds0 + (PC) * (NTH / 4) * ROWB;     \
     *reinterpret_cast<u32x4*>(dst_) = rh_hi[SLOT];                                           \
-    *reinterpret_cast<u32x4*>(dst_ + HALO_BYTES) = rh_lo[SLOT];                              \
+    if constexpr (X3) *reinterpret_cast<u32x4*>(dst_ + HALO_BYTES) = rh_lo[SLOT];            \
   }
 #define VP_READ_FRAGS(SET, WBUF, HBUF, TAPOFS)                                               \
   {                                                                                          \
     const char* wsrc_ = (WBUF) + (a_ofs0 ^ ((SET) * 32));                                    \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
       fa[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + i * WCO * 32 * WROW);              \
-      fal[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + W_BYTES + i * WCO * 32 * WROW);   \
+      if constexpr (X3) fal[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + W_BYTES + i * WCO * 32 * WROW); \
     }                                                                                        \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
       fb[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
-      fbl[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + HALO_BYTES + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
+      if constexpr (X3) fbl[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + HALO_BYTES + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
     }                                                                                        \
   }
 #define VP_MFMA(SET) VP_MFMA_RANGE(SET, 0, MT * NT)
@@ -174,9 +180,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 #define VP_MFMA_RANGE(SET, Q0, Q1)                                                           \
   _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
     const int i = q_ / NT, j = q_ % NT;                                                      \
-    if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[SET][i][1] + (float)fb[SET][j][2] + (float)fbl[SET][j][3]; continue; } \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
+    if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[X3 ? SET : 0][X3 ? i : 0][1] + (float)fb[SET][j][2] + (float)fbl[X3 ? SET : 0][X3 ? j : 0][3]; continue; } \
+    if constexpr (X3) {                                                                      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
+    }                                                                                        \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);  \
   }
   // One tap step.  On entry fragment set 0 of THIS step is in flight / in registers (read during the previous step).
@@ -188,8 +196,8 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     constexpr int tap_ofs_ = (((T) / 3) * HWD + ((T) % 3)) * ROWB;                           \
     constexpr int tn_ = ((T) + 1) % 9;                                                       \
     constexpr int tap_next_ = ((tn_ / 3) * HWD + (tn_ % 3)) * ROWB;                          \
-    const char* wcur_ = w_base + ((T) % 3) * 2 * W_BYTES;                                    \
-    const char* wnext_ = w_base + (((T) + 1) % 3) * 2 * W_BYTES;                             \
+    const char* wcur_ = w_base + ((T) % 3) * PL * W_BYTES;                                   \
+    const char* wnext_ = w_base + (((T) + 1) % 3) * PL * W_BYTES;                            \
     const char* hnext_ = ((T) == 8 && HDB) ? hbuf_other : hbuf;                              \
     /* ---- K sub-step 0 (set 0 was fetched behind the previous barrier).  Half of its accumulator tiles go BEFORE set 1's */ \
     /* reads are issued: the wait in front of it then sees only reads that are a whole MFMA group old                    */ \
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     __builtin_amdgcn_sched_barrier(0);                                                       \
     if constexpr (!(ABL & 4)) VP_READ_FRAGS(1, wcur_, hbuf, tap_ofs_)                        \
     __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
-    if constexpr (HDB && (T) == 0 && !(ABL & 1) && !(ABL & 64)) {                            \
+    if constexpr (HDB && (T) == LT && !(ABL & 1) && !(ABL & 64)) {                           \
       _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_LOAD_H(pc, pc, next_chunk ? c + 1 : c) \
     }                                                                                        \
     if constexpr (!HDB && (T) < HP && !(ABL & 1) && !(ABL & 64)) {                           \
@@ -227,15 +235,15 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
       {                                                                                      \
         /* halo loads (2 per piece) issued in this step / in the previous step behind its DMA */ \
         constexpr int hon_ = (ABL & 64) ? 0 : 1;                                             \
-        const int hthis_ = hon_ * (HDB ? ((T) == 0 ? 2 * HP : 0) : (((T) < HP && next_chunk) ? 2 : 0)); \
-        const int hprev_ = hon_ * (HDB ? ((T) == 1 ? 2 * HP : 0) : (((T) >= 1 && (T) <= HP && next_chunk) ? 2 : 0)); \
-        const int newer_ = ((next_chunk || (T) < 7) ? 2 * WPIECES : 0) + hthis_ + hprev_;     \
-        if (newer_ >= 2 * WPIECES + 2 * HP && HDB) { VP_WAIT_VMCNT(2 * WPIECES + 2 * HP); }  \
-        else if (newer_ >= 2 * WPIECES + 4) { VP_WAIT_VMCNT(2 * WPIECES + 4); }              \
-        else if (newer_ >= 2 * WPIECES + 2) { VP_WAIT_VMCNT(2 * WPIECES + 2); }              \
-        else if (newer_ >= 2 * WPIECES) { VP_WAIT_VMCNT(2 * WPIECES); }                      \
-        else if (newer_ >= 4) { VP_WAIT_VMCNT(4); }                                          \
-        else if (newer_ >= 2) { VP_WAIT_VMCNT(2); }                                          \
+        const int hthis_ = hon_ * (HDB ? ((T) == LT ? PL * HP : 0) : (((T) < HP && next_chunk) ? PL : 0)); \
+        const int hprev_ = hon_ * (HDB ? ((T) == LT + 1 ? PL * HP : 0) : (((T) >= 1 && (T) <= HP && next_chunk) ? PL : 0)); \
+        const int newer_ = ((next_chunk || (T) < 7) ? PL * WPIECES : 0) + hthis_ + hprev_;     \
+        if (newer_ >= PL * WPIECES + PL * HP && HDB) { VP_WAIT_VMCNT(PL * WPIECES + PL * HP); } \
+        else if (newer_ >= PL * WPIECES + 2 * PL) { VP_WAIT_VMCNT(PL * WPIECES + 2 * PL); }    \
+        else if (newer_ >= PL * WPIECES + PL) { VP_WAIT_VMCNT(PL * WPIECES + PL); }            \
+        else if (newer_ >= PL * WPIECES) { VP_WAIT_VMCNT(PL * WPIECES); }                      \
+        else if (newer_ >= 2 * PL) { VP_WAIT_VMCNT(2 * PL); }                                \
+        else if (newer_ >= PL) { VP_WAIT_VMCNT(PL); }                                        \
         else { VP_WAIT_VMCNT(0); }                                                           \
       }                                                                                      \
     }                                                                                        \
@@ -276,8 +284,8 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   int hb = 0;
   for (int c = 0; c < KC; ++c) {
     const bool next_chunk = (c + 1 < KC);
-    const char* hbuf = halo_base + (HDB ? hb : 0) * 2 * HALO_BYTES;
-    const char* hbuf_other = halo_base + (HDB ? (hb ^ 1) : 0) * 2 * HALO_BYTES;
+    const char* hbuf = halo_base + (HDB ? hb : 0) * PL * HALO_BYTES;
+    const char* hbuf_other = halo_base + (HDB ? (hb ^ 1) : 0) * PL * HALO_BYTES;
     VP_TAP(0) VP_TAP(1) VP_TAP(2) VP_TAP(3) VP_TAP(4) VP_TAP(5) VP_TAP(6) VP_TAP(7) VP_TAP(8)
     hb ^= 1;
   }
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 
   // ---- register epilogue: bias + activation + (hi, lo) split, both planes staged as [pixel][CO_TILE] fp16, 16-byte stores.
   constexpr int PITCH = CO_TILE * 2 + 16, STAGE_PLANE = PX * PITCH;
-  static_assert(2 * STAGE_PLANE <= NHB * 2 * HALO_BYTES + 6 * W_BYTES, "stage fits the main buffers");
+  static_assert(PL * STAGE_PLANE <= NHB * PL * HALO_BYTES + 3 * PL * W_BYTES, "stage fits the main buffers");
   if constexpr ((ABL & 16) != 0) {  // ablation: keep the accumulators alive (a store no launch ever takes), skip arithmetic and stores
     if (p.H == -12345) {
 #pragma unroll
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
           l[r] = (half_t)(x - (float)h[r]);
         }
         *reinterpret_cast<h4_t*>(row + g * 16) = h;
-        *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
+        if constexpr (X3) *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
       }
     }
   }
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     if (m < 0) continue;
     const size_t o = (size_t)m * p.Cstore + co;
     *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
-    *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+    if constexpr (X3) *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
   }
 }
 
@@ -376,6 +384,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 // factor as the halo kernel's 64-channel tile (halo tile 3), the pipelined schedule instead of its lone-wave one.
 bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
   const int co_tile = shape == 8 ? 64 : 128;
+  if (p.in_lo == nullptr) {  // VP_FP16 engines: the 8-wave shape on single planes, conv + bias + {fp16 GELU, none}, no split-K
+    return shape == 6 && p.ks == 3 && p.stride <= 1 && p.w_lo == nullptr && p.out_lo == nullptr && p.out_hi != nullptr && p.CoutW % 128 == 0 &&
+           p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit == 1 && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE &&
+           (p.act == ACT_GELU_F16 || p.act == ACT_NONE);
+  }
   if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
   if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
   return p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
@@ -397,9 +410,22 @@ static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   return sk ? launch_splitk_finish(p, st) : hipSuccess;
 }
 
+// the VP_FP16 instantiation of shape 6: 76 KB of LDS, two workgroups per CU
+static hipError_t launch_x1_w8(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds = 2 * (18 * 18 * 80) + 3 * (128 * 64);
+  const bool gelu = p.act == ACT_GELU_F16;
+  auto k = gelu ? conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_GELU_F16, 0, false, false> : conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_NONE, 0, false, false>;
+  static LdsAttrOnce attr_once[2];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  dim3 grid(((p.H + 15) / 16) * ((p.W + 15) / 16) * (p.CoutW / 128));
+  hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
 // shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
   if (!conv3x3_x3_supported(p, shape)) return hipErrorInvalidValue;
+  if (p.in_lo == nullptr) return launch_x1_w8(p, st);
   if (shape == 6) return launch_x3_cfg<128, 16, 4, true>(p, st);
   if (shape == 7) return launch_x3_cfg<128, 8, 2, false>(p, st);
   if (shape == 8) return launch_x3_cfg<64, 8, 2, false>(p, st);

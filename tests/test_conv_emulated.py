@@ -97,8 +97,11 @@ def test_x3w8_kernel(emu_lib):
     # split-K slices of the 4-wave shape (fp32 partials + finish kernel), incl. a mul-add residual (context_layer_6's epilogue)
     _case(emu_lib, 160, 128, 10, 20, 3, 0, 1, 0, 1, [(107, -1, 2), (107, -1, 5)], seed=24)
     _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3), (108, -1, 3)], seed=25)
+    # the VP_FP16 engines' instantiation of the 8-wave shape (single planes): same K order as their halo tile 1 => same bits
+    assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1), emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=101, nsplit=1))
+    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 0, [(106, -1, 1)], seed=27)
     with pytest.raises(emu_lib.VpError):
-        emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # fp16 engines have no tile 6
+        emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=107, nsplit=1)      # fp16 engines have no tile 7
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])

@@ -108,8 +108,10 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
             sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=ns)
             assert (np.abs(sk - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5
             assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=108, nsplit=ns))   # same slices, same finish kernel
+    # VP_FP16 engines: the same 8-wave schedule on single planes -- same K order as their halo tile 1 => same bits
+    assert np.array_equal(lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=106, nsplit=1), lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=101, nsplit=1))
     with pytest.raises(lib.VpError):
-        lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=106, nsplit=1)
+        lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=107, nsplit=1)
 
 
 def test_conv_op_transpose_detecting():
