@@ -315,6 +315,14 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
   } else if (blocks < 128 && S >= 32) {  // split-K pays only for long K loops: it costs a second (finish) launch
     ns = (int)std::min<long long>(cdiv(384, blocks), std::max(1, S / 8));
     ns = std::max(1, std::min(ns, 32));
+  } else if (ks == 1 && blocks < 64) {
+    // long-K 1x1 GEMMs on small maps (the MBConv projections of stages 4-7: K = 480..1152 on 200-800 pixels, 12-42 workgroups
+    // walking 8-18 dependent staging steps): slices of >= 3 steps up to ~128 workgroups.  Measured (parity mode, per launch incl.
+    // the finish kernel): 25 -> 15 us on stages 6 / 7, 20 -> 15 on stage 5, SceneSeg single stream 2.076 -> 2.015 ms.
+    // VP_PROJ_SPLIT = minimum steps per slice (0 = never split).
+    const char* e = std::getenv("VP_PROJ_SPLIT");
+    const int min_steps = e ? std::atoi(e) : 3;
+    if (min_steps > 0 && S >= 2 * min_steps) ns = std::max(1, std::min<int>(S / min_steps, (int)cdiv(128, blocks)));
   }
   pc->nsplit = std::min(ns, std::max(1, S));
   if (tile == 4) pc->nsplit = 1;
