@@ -1027,7 +1027,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
 // scene_context.py:25-57 (== depth_context.py, auto_steer_context.py with 1456 channels)
 Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const Act* deep, int cctx) {
   const int HW = deep->H * deep->W;
-  const int nslab = 1;  // 200 pixels: one slab, the pool kernel spreads over channels
+  const int nslab = 8;  // 200 pixels in 8 slabs of 25: 40 workgroups with ONE round of loads each (one slab: 5 workgroups walking 25 pixels
+                        // per thread in 7 dependent rounds, 21 us); the first FC sums the slab partials in a fixed order
   float* partial = static_cast<float*>(dalloc((size_t)nslab * deep->C * sizeof(float)));
   {
     PoolParams pp{deep->view(), partial, nslab};

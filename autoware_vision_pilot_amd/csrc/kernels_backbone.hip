@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
     float xv;
     if (p.partial) {
       xv = 0.f;
-      for (int q = 0; q < p.nslab; ++q) xv += p.partial[(size_t)q * p.Kstride + k];
+#pragma unroll 8
+      for (int q = 0; q < p.nslab; ++q) xv += p.partial[(size_t)q * p.Kstride + k];  // independent loads: one round trip, fixed order
       xv *= p.inv_hw;
     } else {
       xv = p.x[k];
