@@ -67,6 +67,8 @@ struct ConvGemmParams {
   // (argmax / threshold / lane priority, kernels_misc.hip decode_mask_kernel's rules) into mask_out[pixel]; nullptr = off
   uint8_t* mask_out;
   int decode_mode;
+  // >= 16 bytes of zeros in device memory (the engine's zero page): LDS-DMA source for pixels outside the map (kernels_conv3x3_x3.hip)
+  const half_t* zeros;
 };
 
 // nn.GELU() (exact erf form, scene_neck.py:8).  ~300 M activations per frame: libm's erff (~45 VALU ops, branchy)

@@ -357,6 +357,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.Cstore = out ? out->C : 0;
   p.out_f32 = o.logits_out;
   p.Creal = cout_real;
+  p.zeros = static_cast<const half_t*>(zero_page());
   // the head's logits convolution decodes the mask in its epilogue (one launch and a 2.4 MB re-read less per network)
   const bool fuse_decode = store_mode == STORE_NCHW_F32 && o.logits_out == d_logits_ && d_mask_ && cout_real <= 8 && ncols <= 32 && kind_ >= 0 &&
                            kind_ != 4 && !(std::getenv("VP_FUSE_DECODE") && std::getenv("VP_FUSE_DECODE")[0] == '0');
