@@ -3,6 +3,7 @@
 #include "conv_epilogue.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -135,6 +136,10 @@ Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engi
 }
 
 void Engine::construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base) {
+  {  // process-unique plan epochs: a combined graph keyed on (engine address, epoch) can never match a later engine at the same address
+    static std::atomic<unsigned long long> next_epoch{1};
+    plan_epoch_ = next_epoch.fetch_add(1ull << 32);
+  }
   if (base) {
     if (kind < 0 || base->kind_ < 0) throw std::invalid_argument("shared engines need model kinds on both sides");
     if (base->base_) throw std::invalid_argument("the base of a shared engine must own its whole network");
@@ -168,6 +173,14 @@ void Engine::release() {
   if (graph_) hipGraphDestroy(graph_);
   graph_exec_ = nullptr;
   graph_ = nullptr;
+  if (multi_exec_) hipGraphExecDestroy(multi_exec_);
+  if (multi_graph_) hipGraphDestroy(multi_graph_);
+  multi_exec_ = nullptr;
+  multi_graph_ = nullptr;
+  for (hipStream_t sd : side_streams_) hipStreamDestroy(sd);
+  side_streams_.clear();
+  for (hipEvent_t ev : side_events_) hipEventDestroy(ev);
+  side_events_.clear();
   for (void* p : allocs_) hipFree(p);
   allocs_.clear();
   d_zero_ = nullptr;
@@ -1219,6 +1232,7 @@ void Engine::build_model(const WeightBlob& blob) {
   }
   }  // !base_
   std::vector<Act*> feats = base_ ? base_->feats_ : build_backbone(blob, pf.bb);
+  if (!base_) n_fork_ops_ = ops_.size();
   if (base_ && base_->frames_ > 1)
     for (Act*& t : feats) t = frame_view(t, frame_index_);
   feats_ = feats;
@@ -1558,13 +1572,13 @@ void Engine::finish_plan() {
 // ------------------------------------------------------------------------------------------ frame handling
 void Engine::set_input_format(int pixel_format, int plane_order) {
   if (pixel_format < 0 || pixel_format > 1 || plane_order < 0 || plane_order > 1) throw std::invalid_argument("bad input format");
-  if (pixel_format != pixel_format_ || plane_order != plane_order_) graph_valid_ = false;
+  if (pixel_format != pixel_format_ || plane_order != plane_order_) { graph_valid_ = false; ++plan_epoch_; }
   pixel_format_ = pixel_format;
   plane_order_ = plane_order;
 }
 void Engine::set_decode_mode(int mode) {
   if (mode < 0 || mode > 2) throw std::invalid_argument("bad decode mode");
-  if (mode != decode_mode_) graph_valid_ = false;
+  if (mode != decode_mode_) { graph_valid_ = false; ++plan_epoch_; }
   decode_mode_ = mode;
 }
 
@@ -1619,9 +1633,9 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int in
     VP_HIP_CHECK(hipStreamSynchronize(stream_));
     d_frame_ = static_cast<uint8_t*>(dalloc(need * frames_, true));
     frame_cap_ = need * frames_;
-    graph_valid_ = false;
+    { graph_valid_ = false; ++plan_epoch_; }
   }
-  if (h != frame_h_ || w != frame_w_ || stride != frame_stride_) graph_valid_ = false;
+  if (h != frame_h_ || w != frame_w_ || stride != frame_stride_) { graph_valid_ = false; ++plan_epoch_; }
   ensure_tables(h, w);
   frame_h_ = h;
   frame_w_ = w;
@@ -1652,7 +1666,7 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int in
   } else {
     VP_HIP_CHECK(hipMemcpy2DAsync(dst, stride, frame, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, stream_));
   }
-  if (input_is_tensor_) graph_valid_ = false;
+  if (input_is_tensor_) { graph_valid_ = false; ++plan_epoch_; }
   input_is_tensor_ = false;
 }
 
@@ -1662,14 +1676,88 @@ void Engine::upload_tensor(const float* nchw) {
   if (!nchw) throw std::invalid_argument("null tensor");
   VP_HIP_CHECK(hipSetDevice(gpu_));
   VP_HIP_CHECK(hipMemcpyAsync(d_input_, nchw, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyHostToDevice, stream_));
-  if (!input_is_tensor_) graph_valid_ = false;
+  if (!input_is_tensor_) { graph_valid_ = false; ++plan_epoch_; }
   input_is_tensor_ = true;
 }
 
-void Engine::run_eager() {
-  for (size_t i = input_is_tensor_ ? first_net_op_ : 0; i < ops_.size(); ++i) {
-    hipError_t e = ops_[i].run(stream_);
+void Engine::run_ops(hipStream_t st, size_t begin, size_t end) {
+  for (size_t i = begin; i < end; ++i) {
+    hipError_t e = ops_[i].run(st);
     if (e != hipSuccess) throw std::runtime_error("launch failed in layer '" + ops_[i].name + "': " + hipGetErrorString(e));
+  }
+}
+void Engine::run_eager() { run_ops(stream_, input_is_tensor_ ? first_net_op_ : 0, ops_.size()); }
+
+// One frame through this engine AND its shared-prefix heads as ONE graph launch on this engine's stream (so every stream-order
+// guarantee of the separate vp_enqueue calls holds).  Inside the graph the heads that consume only the backbone (shared level 1:
+// Scene3D, EgoLanes on a SceneSeg base) are forked onto side streams right behind the backbone and joined at the end: a single
+// frame's two or three decoders overlap (the small-map neck layers and the 200-tile big layers leave CUs idle on their own).
+// Same kernels, same arguments, same results as base.enqueue() followed by head.enqueue().
+void Engine::enqueue_multi(const std::vector<Engine*>& heads) {
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  if (base_) throw std::invalid_argument("enqueue_multi: call it on the engine that owns the encoder");
+  for (Engine* h : heads)
+    if (!h || h->base_ != this || h->stream_ != stream_) throw std::invalid_argument("enqueue_multi: every head must be a shared-prefix engine of this engine");
+  bool plain = !multi_fork_ || !use_graph_ || !warmed_ || kind_ == 4 || frames_ > 1 || n_fork_ops_ == 0 || heads.empty();
+  for (Engine* h : heads) plain = plain || !h->warmed_ || !h->use_graph_;
+  if (plain) {  // first frames (eager warm-up), graph replay switched off, or nothing to fork
+    enqueue();
+    for (Engine* h : heads) h->enqueue();
+    return;
+  }
+  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
+  std::vector<std::pair<const Engine*, unsigned long long>> key{{this, plan_epoch_}};
+  for (Engine* h : heads) key.emplace_back(h, h->plan_epoch_);
+  if (!multi_exec_ || key != multi_key_) {
+    if (multi_exec_) hipGraphExecDestroy(multi_exec_);
+    if (multi_graph_) hipGraphDestroy(multi_graph_);
+    multi_exec_ = nullptr;
+    multi_graph_ = nullptr;
+    size_t n_side = 0;
+    for (Engine* h : heads) n_side += h->shared_level_ == 1 ? 1 : 0;
+    while (side_streams_.size() < n_side) {
+      hipStream_t s = nullptr;
+      VP_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+      side_streams_.push_back(s);
+    }
+    while (side_events_.size() < n_side + 1) {
+      hipEvent_t e = nullptr;
+      VP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      side_events_.push_back(e);
+    }
+    VP_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    try {
+      const size_t first = input_is_tensor_ ? first_net_op_ : 0;
+      run_ops(stream_, first, n_fork_ops_);
+      VP_HIP_CHECK(hipEventRecord(side_events_[0], stream_));
+      size_t si = 0;
+      for (Engine* h : heads)
+        if (h->shared_level_ == 1) {
+          VP_HIP_CHECK(hipStreamWaitEvent(side_streams_[si], side_events_[0], 0));
+          h->run_ops(side_streams_[si], 0, h->ops_.size());
+          VP_HIP_CHECK(hipEventRecord(side_events_[1 + si], side_streams_[si]));
+          ++si;
+        }
+      run_ops(stream_, n_fork_ops_, ops_.size());
+      for (Engine* h : heads)
+        if (h->shared_level_ != 1) h->run_ops(stream_, 0, h->ops_.size());  // needs this engine's context + neck: behind them, in order
+      for (size_t i = 0; i < si; ++i) VP_HIP_CHECK(hipStreamWaitEvent(stream_, side_events_[1 + i], 0));
+    } catch (...) {
+      hipGraph_t g = nullptr;
+      hipStreamEndCapture(stream_, &g);
+      if (g) hipGraphDestroy(g);
+      throw;
+    }
+    VP_HIP_CHECK(hipStreamEndCapture(stream_, &multi_graph_));
+    VP_HIP_CHECK(hipGraphInstantiate(&multi_exec_, multi_graph_, nullptr, nullptr, 0));
+    multi_key_ = key;
+  }
+  VP_HIP_CHECK(hipGraphLaunch(multi_exec_, stream_));
+  have_outputs_ = true;
+  host_logits_valid_ = host_mask_valid_ = false;
+  for (Engine* h : heads) {
+    h->have_outputs_ = true;
+    h->host_logits_valid_ = h->host_mask_valid_ = false;
   }
 }
 

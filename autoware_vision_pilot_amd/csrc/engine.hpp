@@ -144,6 +144,9 @@ class Engine {
   Act* add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
                  const ConvOpts& o);
   void run_eager();
+  void run_ops(hipStream_t st, size_t begin, size_t end);
+  void enqueue_multi(const std::vector<Engine*>& heads);
+  void set_multi_fork(bool on) { multi_fork_ = on; }
   void upload_act(Act* a, const float* chw);
   hipStream_t stream() const { return stream_; }
   int gpu() const { return gpu_; }
@@ -247,6 +250,16 @@ class Engine {
   bool use_graph_ = true;
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;
+  // enqueue_multi: ONE graph for this engine and its shared-prefix heads, the heads that need only the backbone forked onto side
+  // streams behind it (they overlap this engine's own context / neck / head); keyed by the head list and every member's plan epoch
+  hipGraph_t multi_graph_ = nullptr;
+  hipGraphExec_t multi_exec_ = nullptr;
+  std::vector<std::pair<const Engine*, unsigned long long>> multi_key_;
+  std::vector<hipStream_t> side_streams_;
+  std::vector<hipEvent_t> side_events_;   // [0] fork, [1 + i] join of side stream i
+  bool multi_fork_ = true;                // vp_set_multi_fork
+  size_t n_fork_ops_ = 0;                 // ops_[0, n_fork_ops_): preprocess + backbone (what a level-1 head consumes)
+  unsigned long long plan_epoch_ = 0;     // bumped whenever graph_valid_ is cleared
   bool graph_valid_ = false;
   bool warmed_ = false;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;

@@ -287,12 +287,26 @@ int vp_infer_multi(vp_engine* base, vp_engine* const* shared, int n_shared, cons
       if (shared[i]->impl->shared_level() == 0 || shared[i]->impl->stream() != g.stream())
         throw std::invalid_argument("vp_infer_multi: every head must be a shared-prefix engine of this base");
     g.upload_frame(frame, h, w, stride_bytes);
-    g.enqueue();
-    for (int i = 0; i < n_shared; ++i) shared[i]->impl->enqueue();
+    std::vector<vp::Engine*> heads;
+    for (int i = 0; i < n_shared; ++i) heads.push_back(shared[i]->impl.get());
+    g.enqueue_multi(heads);
     g.enqueue_fetch();
     for (int i = 0; i < n_shared; ++i) shared[i]->impl->enqueue_fetch();
     g.sync();
   });
+}
+int vp_enqueue_multi(vp_engine* base, vp_engine* const* shared, int n_shared) {
+  if (n_shared < 0 || (n_shared > 0 && !shared)) return VP_ERR_ARG;
+  for (int i = 0; i < n_shared; ++i)
+    if (!shared[i] || !shared[i]->impl) return VP_ERR_ARG;
+  return guarded(base, [&](vp::Engine& g) {
+    std::vector<vp::Engine*> heads;
+    for (int i = 0; i < n_shared; ++i) heads.push_back(shared[i]->impl.get());
+    g.enqueue_multi(heads);
+  });
+}
+int vp_set_multi_fork(vp_engine* base, int enable) {
+  return guarded(base, [&](vp::Engine& g) { g.set_multi_fork(enable != 0); });
 }
 int vp_infer_pair(vp_engine* e, const uint8_t* prev, const uint8_t* curr, int h, int w, int stride_bytes) {
   return guarded(e, [&](vp::Engine& g) {

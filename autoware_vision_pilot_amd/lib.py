@@ -57,6 +57,8 @@ _SIGS = {
     "vp_set_outputs": (C.c_int, [_P, C.c_int]),
     "vp_set_pinned_staging": (C.c_int, [_P, C.c_int]),
     "vp_infer_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, C.c_int]),
+    "vp_enqueue_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
+    "vp_set_multi_fork": (C.c_int, [_P, C.c_int]),
     "vp_visualize_depth_bgr8": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vp_input_tensor": (C.c_int, [_P, _P]),
     "vp_upload_frame": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
@@ -283,6 +285,16 @@ class Engine:
 
     def set_pinned_staging(self, on):
         self._ck(self._lib.vp_set_pinned_staging(self._h, int(bool(on))))
+
+    def set_multi_fork(self, on):
+        """Latency mode (default): enqueue_multi / infer_multi fork the backbone-only heads; off for several cameras in flight."""
+        self._ck(self._lib.vp_set_multi_fork(self._h, 1 if on else 0))
+
+    def enqueue_multi(self, heads):
+        """Asynchronous: this base engine and its shared-prefix ``heads`` as one graph launch (level-1 heads forked behind the
+        backbone, overlapping this engine's own decoder); same results and stream order as enqueue() on each."""
+        arr = (C.c_void_p * max(1, len(heads)))(*[h._h for h in heads])
+        self._ck(self._lib.vp_enqueue_multi(self._h, arr, len(heads)))
 
     def infer_multi(self, heads, frame_u8):
         """One frame through this base engine and its shared-prefix ``heads``: one H2D, one host synchronisation."""

@@ -123,20 +123,28 @@ def cpu_baseline(kinds, sds, frame, seconds, nthreads=0):
 
 class Camera:
     """One in-flight frame slot: the encoder-owning engine plus its shared-prefix heads, all on one HIP stream."""
+    fork = True   # vp_enqueue_multi (default) vs separate vp_enqueue calls (--no-fork)
 
     def __init__(self, lib, kinds, blobs, precision, gpu, frame):
         self.base = lib.Engine(kinds[0], blobs[0], precision=precision, gpu_id=gpu)
         self.heads = [lib.Engine(k, b, precision=precision, gpu_id=gpu, base=self.base) for k, b in zip(kinds[1:], blobs[1:])]
         self.frame = frame
+        # no forked graph (hence no side stream) unless a latency leg asks for it: HIP streams are dealt round-robin onto a few
+        # hardware queues (4 by default), and a side stream created between two cameras' streams made two cameras share a queue
+        self.base.set_multi_fork(False)
         self.base.upload_frame(frame)  # resident in HBM before any timed region
         for _ in range(2):             # first pass is eager (sets kernel attributes), second captures the graphs
             self.enqueue()
         self.sync()
 
     def enqueue(self):
-        self.base.enqueue()
-        for h in self.heads:
-            h.enqueue()
+        if self.heads:
+            self.base.enqueue_multi(self.heads)   # one call; forked inside or one engine after the other (set_fork)
+        else:
+            self.base.enqueue()
+
+    def set_fork(self, on):
+        self.base.set_multi_fork(bool(on) and Camera.fork)
 
     def sync(self):
         self.base.sync()
@@ -170,6 +178,8 @@ def main():
                          "encoder of frame n+1 overlaps the MFMA-bound decoder of frame n")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="floor of every timed region")
     ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL through the C ABI)")
+    ap.add_argument("--no-fork", action="store_true", help="enqueue the base engine and its heads one after the other (vp_enqueue) "
+                    "instead of one forked graph per frame (vp_enqueue_multi)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp16 and host-to-host legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -178,6 +188,7 @@ def main():
     args = ap.parse_args()
     if args.kind:
         args.workload = args.kind
+    Camera.fork = not args.no_fork
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,9 +264,15 @@ def main():
         return np.array(lat)
 
     def three_figures(cams, steps, warmup, gather=False):
+        # several cameras in flight: engines one after the other (the chip is full; forked heads only add contention);
+        # one camera / one frame at a time: the backbone-only heads forked behind the shared encoder (vp_set_multi_fork)
+        for c in cams:
+            c.set_fork(False)
         k, el = throughput(cams, steps, warmup, gather)
+        cams[0].set_fork(True)
         k1, el1 = throughput(cams[:1], max(steps // 3, 1), 3)
         lat = latency(cams[0], args.latency_iters)
+        cams[0].set_fork(False)
         return dict(steps=k, elapsed=el, fps=world * k / el, single=k1 / el1,
                     p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)))
 
@@ -293,15 +310,20 @@ def main():
             return sum(r[0] for r in res) / wall
 
         for c in cams:
+            c.set_fork(False)
             c.host_frame()
         host_run(0.2)
         h2h = {"fps": host_run(max(args.min_seconds, 1.0))}
+        cams[0].set_fork(True)
+        for _ in range(3):
+            cams[0].host_frame()
         lat = []
         for _ in range(max(20, args.latency_iters // 2)):
             t1 = time.perf_counter()
             cams[0].host_frame()
             lat.append((time.perf_counter() - t1) * 1e3)
         h2h["p50"] = float(np.percentile(lat, 50))
+        cams[0].set_fork(False)
         for c in cams:  # masks only: logits stay in HBM (vp_set_outputs), the hosts that publish the mask never read them
             c.base.set_outputs(logits=False, mask=True)
             for h in c.heads:
@@ -391,6 +413,11 @@ def main():
             "fps_per_gpu": round(main_fig["fps"] / world, 2),
             "single_stream_fps": round(main_fig["single"], 2),
             "p50_ms": round(main_fig["p50"], 4), "p99_ms": round(main_fig["p99"], 4),
+            "modes_note": ("`value` / host_to_host_fps: several cameras in flight, every camera's engines enqueued one after the "
+                           "other (vp_set_multi_fork 0); single_stream_fps / p50_ms / p99_ms / host_to_host_p50_ms: ONE camera, one "
+                           "frame at a time, the backbone-only heads forked behind the shared encoder inside one graph "
+                           "(vp_enqueue_multi / vp_infer_multi, the default) -- same kernels, bit-identical results"
+                           + ("" if Camera.fork else "; --no-fork: forking disabled everywhere")),
             "roofline": roofline,
         }
         if h2h is not None:
@@ -399,7 +426,7 @@ def main():
             out["host_to_host_masks_only_fps"] = round(h2h["fps_masks_only"], 2)
             out["host_to_host_note"] = (f"vp_infer_multi per frame from {nstreams} host threads (one per in-flight engine): pageable "
                                         f"{fw}x{fh}x3 frame -> pinned staging -> H2D, all networks, D2H of every network's fp32 logits "
-                                        "+ u8 mask, one sync; p50 = one thread alone; masks_only = logits left in HBM "
+                                        "+ u8 mask, one sync; p50 = one thread alone (heads forked); masks_only = logits left in HBM "
                                         "(vp_set_outputs) except Scene3D's depth map")
     for c in cams:
         c.close()

@@ -144,6 +144,16 @@ int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes)
  * all networks enqueued back to back on the base engine's stream, the selected outputs of every engine copied D2H behind
  * them, ONE host synchronisation -- instead of vp_infer + n x vp_infer_shared (n + 1 synchronisations). */
 int vp_infer_multi(vp_engine* base, vp_engine* const* shared, int n_shared, const uint8_t* frame, int h, int w, int stride_bytes);
+/* Asynchronous half of it for a frame that is already resident (vp_upload_frame): the base engine and its shared-prefix heads as
+ * ONE graph launch on the base engine's stream.  Inside the graph the heads that consume only the backbone (Scene3D, EgoLanes on a
+ * SceneSeg base) are forked behind it and joined at the end, so one frame's decoders overlap; results are bit-identical to
+ * vp_enqueue(base) followed by vp_enqueue(head) for every head, and so is the stream order seen from outside. */
+int vp_enqueue_multi(vp_engine* base, vp_engine* const* shared, int n_shared);
+/* The fork is a LATENCY lever (measured on MI355X, SceneSeg + Scene3D: one camera 3.49 -> 3.19 ms per frame; three heads 4.47 ->
+ * 3.99 ms) and a throughput loss when several cameras are already in flight on one GPU (three cameras: 390 -> 333 frames/s: the
+ * chip is full, more concurrent kernels only contend).  Default 1 (the reference node is synchronous, one frame at a time);
+ * a host that pipelines several cameras per GPU sets 0: vp_enqueue_multi / vp_infer_multi then enqueue one engine after the other. */
+int vp_set_multi_fork(vp_engine* base, int enable);
 int vp_infer_tensor(vp_engine* e, const float* nchw_1x3x320x640);
 /* AutoDrive.forward(image_prev, image_curr) (autodrive_network.py:32-36): backbone on `prev`, then backbone + head on `curr`.
  * Plain vp_infer on a VP_AUTODRIVE engine is the streaming form: the previous call's frame is `prev` (the first frame of

@@ -98,3 +98,47 @@ def test_shared_errors_are_loud(shared_setup, state_dicts, frame720):
         heads["scene3d"].infer(frame720)
     with pytest.raises(ValueError, match="not a shared"):
         base.infer_shared()
+
+
+@pytest.mark.parametrize("prec", ["fp16x3", "fp16"])
+def test_enqueue_multi_is_the_same_frame(shared_setup, frame720, prec):
+    """vp_enqueue_multi: base engine + heads as ONE graph launch, the backbone-only heads (Scene3D, EgoLanes) forked onto side
+    streams behind the shared encoder, the context+neck-sharing head (DomainSeg) in order behind the base's neck.  Same kernels on
+    the same data => bit-identical logits and class maps to the one-after-the-other vp_enqueue calls, frame after frame (graph
+    replays), for every subset / order of heads, and after a decode-mode change (which must re-capture the combined graph)."""
+    _, out = shared_setup
+    base, heads = out[prec]
+    order = ["scene3d", "domainseg", "egolanes"]
+
+    def sequential(names, frame):
+        base.upload_frame(frame)
+        base.enqueue()
+        for k in names:
+            heads[k].enqueue()
+        base.sync()
+        return [base.logits().copy(), base.mask().copy()] + [a for k in names for a in (heads[k].logits().copy(), heads[k].mask().copy())]
+
+    def forked(names, frame):
+        base.upload_frame(frame)
+        base.enqueue_multi([heads[k] for k in names])
+        base.sync()
+        return [base.logits().copy(), base.mask().copy()] + [a for k in names for a in (heads[k].logits().copy(), heads[k].mask().copy())]
+
+    frame2 = np.ascontiguousarray(frame720[::-1])          # a second, different frame
+    for names in (order, ["scene3d"], ["egolanes", "scene3d"], []):
+        for fr in (frame720, frame2, frame720):
+            want, got = sequential(names, fr), forked(names, fr)
+            assert all(np.array_equal(a, b) for a, b in zip(want, got)), (prec, names)
+    base.set_multi_fork(False)                              # several cameras in flight: one engine after the other, same call
+    want, got = sequential(order, frame720), forked(order, frame720)
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    base.set_multi_fork(True)
+    base._ck(base._lib.vp_set_decode_mode(base._h, 2))      # class-index masks: both graphs are stale now
+    try:
+        want, got = sequential(order, frame2), forked(order, frame2)
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+        assert got[1].max() <= 2                            # the class indices, not the {0, 255} mask
+    finally:
+        base._ck(base._lib.vp_set_decode_mode(base._h, 0))
+    with pytest.raises(Exception):
+        heads["scene3d"].enqueue_multi([])                  # only the encoder-owning engine can lead
