@@ -124,6 +124,7 @@ def cpu_baseline(kinds, sds, frame, seconds, nthreads=0):
 class Camera:
     """One in-flight frame slot: the encoder-owning engine plus its shared-prefix heads, all on one HIP stream."""
     fork = True   # vp_enqueue_multi (default) vs separate vp_enqueue calls (--no-fork)
+    fork_all = False  # --fork-all: forked graphs in the throughput legs too (experiment)
 
     def __init__(self, lib, kinds, blobs, precision, gpu, frame):
         self.base = lib.Engine(kinds[0], blobs[0], precision=precision, gpu_id=gpu)
@@ -144,7 +145,7 @@ class Camera:
             self.base.enqueue()
 
     def set_fork(self, on):
-        self.base.set_multi_fork(bool(on) and Camera.fork)
+        self.base.set_multi_fork((bool(on) or Camera.fork_all) and Camera.fork)
 
     def sync(self):
         self.base.sync()
@@ -180,6 +181,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather per-camera masks every step (RCCL through the C ABI)")
     ap.add_argument("--no-fork", action="store_true", help="enqueue the base engine and its heads one after the other (vp_enqueue) "
                     "instead of one forked graph per frame (vp_enqueue_multi)")
+    ap.add_argument("--fork-all", action="store_true", help="experiment: forked graphs in the several-cameras legs too")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fp16 and host-to-host legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -189,6 +191,7 @@ def main():
     if args.kind:
         args.workload = args.kind
     Camera.fork = not args.no_fork
+    Camera.fork_all = args.fork_all
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
