@@ -252,6 +252,20 @@ const void* Engine::zero_page() {
   return d_zero_;
 }
 
+// stream-K workspace (kernels_conv3x3_x3.hip shape 9): two persistent workgroups per CU
+int Engine::streamk_slots() const {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_) != hipSuccess || cus < 8) cus = 256;
+  return 2 * cus / 8 * 8;
+}
+void Engine::ensure_streamk_ws(int slots) {
+  if (slots <= sk_cap_) return;
+  if (sk_cap_ != 0) throw std::runtime_error("stream-K workspace: layers of one engine must agree on the slot count");  // ops already captured its pointers
+  sk_slabs_ = static_cast<float*>(dalloc((size_t)slots * conv3x3_sk_slab_bytes(), false));
+  sk_flags_ = static_cast<unsigned*>(dalloc((size_t)(slots + 1) * sizeof(unsigned), true));
+  sk_cap_ = slots;
+}
+
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
@@ -386,6 +400,12 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   }
   const int M = p.H * p.W;
   p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
+  if (pc.tile == 109) {  // stream-K: one slab + flag per slot, shared by this engine's layers (they are serialised on its stream)
+    ensure_streamk_ws(pc.sk_slots);
+    p.partial = sk_slabs_;
+    p.sk_flags = sk_flags_;
+    p.sk_slots = pc.sk_slots;
+  }
   const int tile = pc.tile, bk = pc.bk;
   const bool sp = split();
   Op op;
@@ -442,9 +462,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
-    if (ht == 6 || ht == 7 || ht == 8) {
-      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 / 7 / 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K: " + name);
-      op.kernel = std::string(ht == 6 ? (sp ? "conv3x3_x3w8<co128,px256>" : "conv3x3_x1w8<co128,px256>") : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
+    if (ht >= 6 && ht <= 9) {
+      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 9 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
+      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : (ht == 8 ? "conv3x3_x3w4<co64,px128>" : "conv3x3_x3sk<co128,px128>"))) + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -565,15 +585,18 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         (void)wgs8;
       }
     }
-    // VP_FP16 engines: the 8-wave pipelined shape on single planes (kernels_conv3x3_x3.hip, X3 = false) for the same big layers;
-    // VP_X1_W8=0 keeps the halo kernel's 128-channel 16x16 tile
-    if (!split() && o.tile < 0 && (halo == 0 || halo == 1) && ncols % 128 == 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 &&
+    // parity mode, stream-K (kernels_conv3x3_x3.hip shape 9, round 3): the 8x16 x 128-channel tiles' K loops dealt in equal chunk-step
+    // ranges to 2 x #CU persistent workgroups.  VP_STREAMK: 0 = never, 1 = the layers of shapes 6 / 7 (default), 2 = also every other
+    // plain 128-channel-tiled layer with at least two chunk steps per slot (decode_layer_5; the split-K layers of the small maps).
+    if (split() && o.tile < 0 && halo >= 0 && ncols % 128 == 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 &&
         (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE) {
-      static const char* env1 = std::getenv("VP_X1_W8");
-      auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
-      if (env1 && env1[0] == '1' && cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128) >= 160) halo = 6;
+      static const char* envsk = std::getenv("VP_STREAMK");
+      const int level = envsk ? std::atoi(envsk) : 1;
+      const long long steps = (long long)((in->H + 7) / 8) * ((in->W + 15) / 16) * (ncols / 128) * (cin_pad / 32);
+      if (level >= 1 && (halo == 6 || halo == 7)) halo = 9;
+      else if (level >= 2 && (halo == 1 || halo == 3) && steps >= 2LL * streamk_slots()) halo = 9;
     }
-    if ((halo == 7 || halo == 8) && !split()) throw std::invalid_argument("halo tiles 7 / 8 are fp16x3 kernels: " + name);
+    if ((halo == 6 || halo == 7 || halo == 8 || halo == 9) && !split()) throw std::invalid_argument("halo tiles 6 - 9 are fp16x3 kernels: " + name);
   }
   // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
   // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
@@ -649,6 +672,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
     if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
+    if (halo == 9) {               // stream-K: the slots carry the K split (the operator entry passes a slot count as `nsplit`: small test grids)
+      pc.nsplit = 1;
+      pc.sk_slots = o.nsplit >= 8 ? o.nsplit / 8 * 8 : streamk_slots();
+    }
     if (halo == 7 && blocks >= 160 && o.nsplit <= 0) pc.nsplit = 1;
     // 64-channel tiles of the parity mode: the pipelined kernel's 64-channel shape (halo tile 8: same tiles, same split factor as
     // halo tile 3, three workgroups per CU).  Measured on MI355X (SceneSeg, us, halo tile 3 -> tile 8): decode_layer_0..3 70.5 /
@@ -676,7 +703,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-        const int ci_sw = (halo == 6 || halo == 7 || halo == 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
+        const int ci_sw = (halo >= 6 && halo <= 9) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;

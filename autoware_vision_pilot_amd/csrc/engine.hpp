@@ -162,10 +162,13 @@ class Engine {
     half_t* w_lo = nullptr;
     float* bias = nullptr;
     int CoutW = 0, tile = 0, bk = 32, nsplit = 1;
+    int sk_slots = 0;  // stream-K (tile 109): persistent workgroups
   };
   void construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base);
   void release();  // frees every device / host resource; idempotent (destructor and failed construction)
   void* dalloc(size_t bytes, bool zero = true);
+  int streamk_slots() const;
+  void ensure_streamk_ws(int slots);
   const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)
   template <class T>
   T* dupload(const std::vector<T>& v);
@@ -228,6 +231,11 @@ class Engine {
   size_t h_frame_cap_ = 0;
   int h_frame_slot_ = 0;
   bool pinned_staging_ = true;
+
+  // stream-K slabs / flags (one set per engine)
+  float* sk_slabs_ = nullptr;
+  unsigned* sk_flags_ = nullptr;
+  int sk_cap_ = 0;
 
   // split-K scratch
   std::vector<float**> partial_slots_;

@@ -101,8 +101,9 @@ int conv_tile_px(int tile);
 // 3x3 halo kernel (kernels_conv3x3.hip); weights packed [cin/32][9][CoutW][32].
 // halo tile ids: 0 = 128co x 16x16 px, 1 = 128co x 8x16, 2 = 64co x 16x16, 3 = 64co x 8x16, 4 = 32co x 8x16
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st);
-// halo tiles 6 / 7: the pipelined fp16x3 kernels (kernels_conv3x3_x3.hip); conv + bias + {GELU, none}, NHWC, no split-K
+// halo tiles 6 - 9: the pipelined fp16x3 kernels (kernels_conv3x3_x3.hip); conv + bias + {GELU, none}, NHWC; 9 = stream-K
 bool conv3x3_x3_supported(const ConvGemmParams& p, int shape);
+size_t conv3x3_sk_slab_bytes();  // shape 9 (stream-K): fp32 slab per persistent workgroup
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st);
 int halo_tile_co(int tile);
 int halo_tile_px(int tile);

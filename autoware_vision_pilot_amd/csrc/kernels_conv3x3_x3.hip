@@ -19,10 +19,12 @@
 //     With the register-staged version the 16 KiB of ds_write_b128 per tap (13 cycles each) plus their vmcnt waits cost
 //     47 of 189 us on decode_layer_4 (tools/x3_ablate.hip, profiles/r02_x3_ablate.txt);
 //   * halo pieces travel global -> registers (loaded three taps before their LDS store) -> LDS: border pixels are zeroed
-//     in registers, and the 80-byte halo pitch is not a linear copy;
+//     in registers, and the 80-byte halo pitch is not a linear copy.  (The halo by LDS-DMA with a zero page for the border was
+//     measured SLOWER, profiles/r02_x3_halo_dma_ab.txt, and so was this schedule on the VP_FP16 engines' single planes: DESIGN.md
+//     "tried and dropped"; neither is in the library);
 //   * register epilogue: bias + exact-erf GELU + (hi, lo) split on the accumulators, BOTH fp16 planes staged once in LDS
 //     and written as 256 contiguous bytes per pixel and plane.
-// Two shapes (halo tile ids, kernels.hpp):
+// Shapes (halo tile ids, kernels.hpp):
 //   6 "x3w8": 512 threads, 16x16 pixels x 128 channels, halo double-buffered (the next chunk's halo is complete five taps
 //             before it is needed, so the prefetch also crosses chunk boundaries).  152 832 B of LDS: one workgroup per CU,
 //             the two waves of a SIMD belong to the same workgroup and reach prologue / epilogue together.
@@ -30,6 +32,8 @@
 //             is written between two barriers at the chunk boundary).  77 952 B: TWO INDEPENDENT workgroups per CU, one
 //             wave of each per SIMD -- they drift out of phase, so one workgroup's prologue / chunk hand-over / epilogue
 //             (exact GELU + split: ~1000 VALU instructions per wave, 64 KiB of stores) runs under the other's MFMAs.
+//   8 "x3w4c64": shape 7 on 64-channel tiles (53 KB, three workgroups per CU).
+//   9 "x3sk": shape 7, PERSISTENT, with the K loops of the tiles dealt STREAM-K (below).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -52,30 +56,36 @@ namespace vp {
 // SPLITK: grid carries p.nsplit K slices per tile; a slice covers the input chunks [KC * z / nsplit, KC * (z + 1) / nsplit) and
 // writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
 // fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
-// X3 = false: the SAME schedule on single fp16 planes (the VP_FP16 engines: one MFMA per tile pair, half the LDS plan -> two 8-wave
-// workgroups per CU, four waves per SIMD; shape 6 only).
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool X3 = true>
-__global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) void conv3x3_x3_kernel(const ConvGemmParams p) {
+// STREAMK (round 3, shape 9): the grid is 2 x #CU workgroup SLOTS, not tiles.  The tiles are dealt to the eight XCDs as before (an
+// XCD's L2 sees a contiguous range of pixel tiles of one weight slice); inside an XCD group the tiles' K loops are laid end to
+// end, T tiles x KC input chunks, and cut into S = slots / 8 EQUAL contiguous ranges of chunk steps, so a slot works through
+// [tail of a tile][whole tiles][head of a tile] and every slot carries the same number of tap steps: the big decoder layers
+// are 400 / 800 / 1600 tiles of 16 / 8 / 4 chunks = 6400 chunk steps on 512 slots = 12.5 each, where the tile-per-workgroup
+// grids ran 1.56 / 3.125 tiles per slot in 2 / 4 rounds (22 % of the machine idle in the last one).
+// A slot that stops short of a tile's last chunk (only its LAST segment can) writes its fp32 accumulators to its 64 KiB slab of
+// p.partial in register order (1 KiB-per-wave-instruction linear stores) and raises its flag; the slot that holds the tile's LAST
+// chunk owns the tile: it adds the slabs of the lower-numbered slots that hold the tile's earlier chunks, in the fixed order
+// j-1, j-2, ..., and runs the epilogue.  A slot walks its segments from the last tile to the first: the slab is published first
+// (the owner needs it only at the end of its own range, a whole range later), the tile that waits on a slab comes last.  A slot
+// only ever waits on LOWER-numbered slots of its own group (lower blockIdx), so the wait cannot deadlock under in-order dispatch
+// even when other streams' kernels keep part of the grid from being resident; the spin is bounded anyway (the accumulators are
+// poisoned with NaN on time-out, which the engine's finite-logits probe reports).  Hand-off = MI355X_MICROARCH.md's recipe:
+// plain stores, every thread drains vmcnt, barrier, lane 0: agent-scope release fence + drained vmcnt + relaxed agent flag store;
+// owner: lane 0 polls relaxed, agent-scope acquire fence, barrier, plain loads; the owner clears the flag for the next launch.
+// Results differ from the tile-per-workgroup kernels only in the fp32 summation order of a cut tile (deterministic: the cuts
+// depend on the layer shape and the slot count alone).
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool STREAMK = false>
+__global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
+  static_assert(!(SPLITK && STREAMK) && !(STREAMK && HDB), "stream-K: the single-halo 4-wave shape, with its own fix-up path");
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
   constexpr int HCHUNKS = HPX * 4, HP = (HCHUNKS + NTH - 1) / NTH;
   constexpr int MT = CO_TILE / WCO / 32, NT = PX / WPX / 32;
   constexpr int NHB = HDB ? 2 : 1;
-  constexpr int PL = X3 ? 2 : 1;  // planes per tensor
-  // HDMA (ABL bit 512, tools/x3_ablate.hip only -- MEASURED SLOWER, not in the library): the halo goes global -> LDS by LDS-DMA too.
-  // The image [halo pixel][80 B] is linear in the 16-byte slot index (4 data slots + 1 pad per pixel), so a wave instruction
-  // copies 64 consecutive slots; pixels outside the map and the pad slots are fetched from the engine's ZERO PAGE; no halo
-  // registers, no ds_write, no compiler-tracked load in the K loop, one piece per wave and tap.  K loop of the 8-wave shape:
-  // 77 % matrix-pipe busy against 80 % with the register path on the same box (profiles/r02_x3_halo_dma_ab.txt): a DMA piece
-  // costs more issue time beside the MFMAs than a global_load + ds_write pair (MI355X_MICROARCH.md prices it at 60-185 cycles).
-  constexpr bool HDMA = HDB && X3 && (ABL & 512) != 0;
-  constexpr int HSLOTS = HPX * 5, NHI = (HSLOTS + 63) / 64;       // DMA instructions per plane
-  constexpr int HSTRIDE = HDMA ? NHI * 1024 : HALO_BYTES;          // plane stride in LDS (the last instruction's tail is padding)
-  constexpr int NHINSTR = PL * NHI, HDPW = (NHINSTR + NTH / 64 - 1) / (NTH / 64);  // per chunk; per wave (waves beyond the count skip their last)
-  static_assert(!HDMA || HDPW <= 7, "one halo piece per wave and tap, taps 0..6");
-  constexpr int LT = X3 ? 0 : 1;  // HDB: tap at which the next chunk's halo pieces are loaded (stored at the start of tap 3); the single-plane
-                                  // form has 128 registers per wave: one tap less of live range keeps the pieces out of scratch memory
+  constexpr int PL = 2;                // planes per tensor: (hi, lo)
+  constexpr int HSTRIDE = HALO_BYTES;  // plane stride in LDS
+  constexpr int LT = 0;                // HDB: tap at which the next chunk's halo pieces are loaded (stored at the start of tap 3)
   static_assert(MT >= 1 && NT >= 1 && HP <= 3, "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo_base = smem;                               // [NHB][2 planes][HALO_BYTES]
@@ -84,21 +94,72 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave / WPX, wpx = wave % WPX;
   const int tiles_x = (p.W + TW - 1) / TW;
-  int vid;  // XCD-aware workgroup -> tile map (see kernels_conv3x3.hip)
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-  }
   const int n_px_tiles = tiles_x * ((p.H + TH - 1) / TH);
   const int n_co_tiles = p.CoutW / CO_TILE;
+  const int KC_all = p.Cin >> 5;
+  // ---- work of this workgroup.  Tile-per-workgroup grids: ONE segment = tile `vid` of the XCD-aware map (see kernels_conv3x3.hip),
+  // all chunks (or K slice zsplit).  Stream-K: the chunk-step range [sk_a, sk_b) of XCD group sk_g, whose tiles start at sk_t0.
+  int sk_g = 0, sk_j = 0, sk_S = 1, sk_t0 = 0, sk_a = 0, sk_b = 1;
+  long long sk_W = 0;
+  int vid0 = 0;
+  if constexpr (STREAMK) {
+    const int n_tiles = n_px_tiles * n_co_tiles, q = n_tiles >> 3, r = n_tiles & 7;
+    sk_g = blockIdx.x & 7;
+    sk_j = blockIdx.x >> 3;
+    sk_S = gridDim.x >> 3;
+    sk_t0 = sk_g < r ? sk_g * (q + 1) : r * (q + 1) + (sk_g - r) * q;
+    sk_W = (long long)(q + (sk_g < r ? 1 : 0)) * KC_all;
+    sk_a = (int)(sk_W * sk_j / sk_S);
+    sk_b = (int)(sk_W * (sk_j + 1) / sk_S);
+  } else {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    vid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int lt_last = STREAMK ? (sk_b - 1) / KC_all : 0;
+  const int nseg = STREAMK ? (sk_b > sk_a ? lt_last - sk_a / KC_all + 1 : 0) : 1;
+
+  // ---- per-thread constants that do not depend on the tile
+  const int h_lds0 = (tid >> 2) * ROWB + (tid & 3) * 16;
+  constexpr int NW = NTH / 64, WPIECES = W_BYTES / 1024 / NW;
+  static_assert(W_BYTES % (1024 * NW) == 0, "weight tile splits into 1 KiB pieces per wave");
+  const size_t w_step = (size_t)p.CoutW * 32;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // fragment addressing (same LDS image and lane maps as the halo kernel)
+  int b_ofs0;  // pixel tile j of the wave sits two halo rows further: + j * 2 * HWD * ROWB
+  {
+    int rowbit, px;
+    lane_to_px16(lane & 31, rowbit, px);
+    b_ofs0 = ((2 * (wpx * NT) + rowbit) * HWD + px) * ROWB + (lane >> 5) * 16;
+  }
+  const int a_swz = ((lane & 31) >> 2) & 3;
+  const int a_ofs0 = (wco * 32 + (lane & 31)) * WROW + (((lane >> 5) ^ a_swz) << 4);  // K sub-step 1: chunk index ^ 2 -> ^ 32 bytes
+
+  for (int seg = 0; seg < nseg; ++seg) {
+  // ---- this segment: tile, chunk range [c_first, c_first + KC), role
+  int vid = vid0, c_first = 0, KC = KC_all, zsplit = 0;
+  bool sk_producer = false, sk_consumer = false;
+  int sk_lt = 0;
+  if constexpr (STREAMK) {
+    sk_lt = lt_last - seg;  // last tile first (it is the one that may publish a slab), first tile last (it may wait for one)
+    const int t_lo = sk_lt * KC_all;
+    c_first = (sk_a > t_lo ? sk_a : t_lo) - t_lo;
+    const int c_end = (sk_b < t_lo + KC_all ? sk_b : t_lo + KC_all) - t_lo;
+    KC = c_end - c_first;
+    sk_producer = c_end < KC_all;
+    sk_consumer = !sk_producer && c_first > 0;
+    vid = sk_t0 + sk_lt;
+  }
   const int tile_px = vid % n_px_tiles, tile_rest = vid / n_px_tiles;
-  const int tile_co = SPLITK ? tile_rest % n_co_tiles : tile_rest, zsplit = SPLITK ? tile_rest / n_co_tiles : 0;
+  const int tile_co = SPLITK ? tile_rest % n_co_tiles : tile_rest;
+  if constexpr (SPLITK) {
+    zsplit = tile_rest / n_co_tiles;
+    c_first = (int)(((long long)KC_all * zsplit) / p.nsplit);
+    KC = (int)(((long long)KC_all * (zsplit + 1)) / p.nsplit) - c_first;  // chunks of THIS slice; c below is slice-relative
+  }
   const int tyi = tile_px / tiles_x, txi = tile_px - tyi * tiles_x;
   const int y0 = tyi * TH, x0 = txi * TW;
   const int co0 = tile_co * CO_TILE;
-  const int KC_all = p.Cin >> 5;
-  const int c_first = SPLITK ? (int)(((long long)KC_all * zsplit) / p.nsplit) : 0;
-  const int KC = (SPLITK ? (int)(((long long)KC_all * (zsplit + 1)) / p.nsplit) : KC_all) - c_first;  // chunks of THIS slice; c below is slice-relative
 
   // ---- staging assignment: thread t moves 16-byte piece t + NTH * pc of a tile (pieces of one thread sit NTH / 4 rows apart)
   int h_goff[HP];
@@ -111,40 +172,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
     const bool ok = hidx < HCHUNKS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     h_goff[pc] = ok ? (gy * p.W + gx) * p.Cin + ch * 8 : -1;
   }
-  const int h_lds0 = (tid >> 2) * ROWB + (tid & 3) * 16;
-  // HDMA plan: instruction ii = wave + (NTH / 64) i moves slots [64 j, 64 j + 64) of plane ii / NHI; element offset of this lane's
-  // slot in chunk 0, or -1 (outside the map / pad slot / past the image: zero page)
-  int hd_goff[HDMA ? HDPW : 1];
-  if constexpr (HDMA) {
-#pragma unroll
-    for (int i = 0; i < HDPW; ++i) {
-      const int ii = wave + (NTH / 64) * i;
-      const int slot = 64 * (ii % NHI) + lane;
-      const int hp = slot / 5, part = slot - hp * 5;
-      const int hy = hp / HWD, hx = hp - hy * HWD;
-      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      const bool ok = ii < NHINSTR && slot < HSLOTS && part < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      hd_goff[i] = ok ? (gy * p.W + gx) * p.Cin + part * 8 : -1;
-    }
-  }
   // weight tiles by LDS-DMA: a (chunk, tap) tile plane is CO_TILE x 64 B = W_BYTES contiguous bytes in global memory, already
   // in LDS image order; wave v copies the 1 KiB pieces v, v + NW, ... of both planes
-  constexpr int NW = NTH / 64, WPIECES = W_BYTES / 1024 / NW;
-  static_assert(W_BYTES % (1024 * NW) == 0, "weight tile splits into 1 KiB pieces per wave");
-  const size_t w_step = (size_t)p.CoutW * 32;
-  const size_t w_goff0 = (size_t)c_first * 9 * w_step + co0 * 32 + wave * 512 + lane * 8;  // elements: this lane's 16 bytes of the wave's first piece (of the slice's first tile)
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-  // ---- fragment addressing (same LDS image and lane maps as the halo kernel)
-  int b_ofs0;  // pixel tile j of the wave sits two halo rows further: + j * 2 * HWD * ROWB
-  {
-    int rowbit, px;
-    lane_to_px16(lane & 31, rowbit, px);
-    b_ofs0 = ((2 * (wpx * NT) + rowbit) * HWD + px) * ROWB + (lane >> 5) * 16;
-  }
-  const int a_swz = ((lane & 31) >> 2) & 3;
-  const int a_ofs0 = (wco * 32 + (lane & 31)) * WROW + (((lane >> 5) ^ a_swz) << 4);  // K sub-step 1: chunk index ^ 2 -> ^ 32 bytes
+  const size_t w_goff0 = (size_t)c_first * 9 * w_step + co0 * 32 + wave * 512 + lane * 8;  // elements: this lane's 16 bytes of the wave's first piece (of the segment's first tile)
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -155,7 +185,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // fragment sets [K sub-step parity]: set 0 = channels 0..15 of the tap's 32, set 1 = channels 16..31
-  h8_t fa[2][MT], fal[2][X3 ? MT : 1], fb[2][NT], fbl[2][X3 ? NT : 1];
+  h8_t fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
   // halo staging ring (compile-time slots): piece pc in slot pc
   u32x4 rh_hi[3], rh_lo[3];
 #pragma unroll
@@ -170,18 +200,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
     char* dst_ = w_base + (BUF) * PL * W_BYTES + wave * 1024;                                \
     _Pragma("unroll") for (int pc = 0; pc < WPIECES; ++pc) {                                 \
       VP_GLOBAL_LOAD_LDS16(p.w_hi + base_ + pc * NW * 512, dst_ + pc * NW * 1024);           \
-      if constexpr (X3) VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
-    }                                                                                        \
-  }
-  // halo piece I of this wave for chunk C -> halo image BUF (HDMA)
-#define VP_DMA_H(I, C, BUF)                                                                  \
-  {                                                                                          \
-    const int ii_ = wave + (NTH / 64) * (I);                                                 \
-    if (ii_ < NHINSTR) {                                                                     \
-      const int pl_ = ii_ >= NHI ? 1 : 0;                                                    \
-      const half_t* base_ = pl_ ? p.in_lo : p.in_hi;                                         \
-      const half_t* src_ = hd_goff[I] >= 0 ? base_ + hd_goff[I] + (c_first + (C)) * 32 : p.zeros; \
-      VP_GLOBAL_LOAD_LDS16(src_, halo_base + (BUF) * PL * HSTRIDE + ii_ * 1024);             \
+      VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
     }                                                                                        \
   }
 #define VP_LOAD_H(SLOT, PC, C)                                                               \
@@ -189,8 +208,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
     const int g_ = h_goff[PC];                                                               \
     const int o_ = (g_ >= 0 ? g_ : 0) + (c_first + (C)) * 32;                                \
     const u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in_hi + o_);                          \
-    u32x4 l_ = zero4;                                                                        \
-    if constexpr (X3) l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                    \
+    const u32x4 l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                          \
     rh_hi[SLOT] = g_ >= 0 ? v_ : zero4;                                                      \
     rh_lo[SLOT] = g_ >= 0 ? l_ : zero4;                                                      \
   }
@@ -198,18 +216,18 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
   if (tid + NTH * (PC) < HCHUNKS) {                                                          \
     char* dst_ = halo_base + (BUF) * PL * HSTRIDE + h_lds0 + (PC) * (NTH / 4) * ROWB;        \
     *reinterpret_cast<u32x4*>(dst_) = rh_hi[SLOT];                                           \
-    if constexpr (X3) *reinterpret_cast<u32x4*>(dst_ + HSTRIDE) = rh_lo[SLOT];               \
+    *reinterpret_cast<u32x4*>(dst_ + HSTRIDE) = rh_lo[SLOT];                                 \
   }
 #define VP_READ_FRAGS(SET, WBUF, HBUF, TAPOFS)                                               \
   {                                                                                          \
     const char* wsrc_ = (WBUF) + (a_ofs0 ^ ((SET) * 32));                                    \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
       fa[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + i * WCO * 32 * WROW);              \
-      if constexpr (X3) fal[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + W_BYTES + i * WCO * 32 * WROW); \
+      fal[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + W_BYTES + i * WCO * 32 * WROW);   \
     }                                                                                        \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
       fb[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
-      if constexpr (X3) fbl[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + HSTRIDE + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
+      fbl[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + HSTRIDE + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
     }                                                                                        \
   }
 #define VP_MFMA(SET) VP_MFMA_RANGE(SET, 0, MT * NT)
@@ -217,11 +235,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
 #define VP_MFMA_RANGE(SET, Q0, Q1)                                                           \
   _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
     const int i = q_ / NT, j = q_ % NT;                                                      \
-    if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[X3 ? SET : 0][X3 ? i : 0][1] + (float)fb[SET][j][2] + (float)fbl[X3 ? SET : 0][X3 ? j : 0][3]; continue; } \
-    if constexpr (X3) {                                                                      \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
-    }                                                                                        \
+    if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[SET][i][1] + (float)fb[SET][j][2] + (float)fbl[SET][j][3]; continue; } \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);  \
   }
   // One tap step.  On entry fragment set 0 of THIS step is in flight / in registers (read during the previous step).
@@ -246,21 +262,18 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
     /* is the weight tile requested one step ago, which this step's barrier needs anyway.  With the stores spread over taps    */ \
     /* 2..4 behind the DMA issue, each of those waits drained the just-requested tile (an L2 round trip) with the matrix pipe  */ \
     /* idle: 74 % busy in the K loop against 85 % with either stream alone (profiles/r02_x3_clock_probe.txt).                  */ \
-    if constexpr (HDB && !HDMA && (T) == 3 && !(ABL & 1) && !(ABL & 64)) {                   \
+    if constexpr (HDB && (T) == 3 && !(ABL & 1) && !(ABL & 64)) {                            \
       if (next_chunk) { _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_STORE_H(pc, pc, hb ^ 1) } \
     }                                                                                        \
     if constexpr (!(ABL & 1) && !(ABL & 128)) {                                              \
       if (next_chunk || (T) < 7) VP_DMA_W(((T) + 2) % 3, c * 9 + (T) + 2)                     \
-    }                                                                                        \
-    if constexpr (HDMA && (T) < HDPW && !(ABL & 1) && !(ABL & 64)) {                         \
-      if (next_chunk) VP_DMA_H((T) < HDPW ? (T) : 0, c + 1, hb ^ 1)                          \
     }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     VP_MFMA_RANGE(0, 0, MT * NT / 2)                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     if constexpr (!(ABL & 4)) VP_READ_FRAGS(1, wcur_, hbuf, tap_ofs_)                        \
     __builtin_amdgcn_sched_barrier(0); /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
-    if constexpr (HDB && !HDMA && (T) == LT && !(ABL & 1) && !(ABL & 64)) {                  \
+    if constexpr (HDB && (T) == LT && !(ABL & 1) && !(ABL & 64)) {                           \
       _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_LOAD_H(pc, pc, next_chunk ? c + 1 : c) \
     }                                                                                        \
     if constexpr (!HDB && (T) < HP && !(ABL & 1) && !(ABL & 64)) {                           \
@@ -275,20 +288,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
       {                                                                                      \
         /* halo loads (2 per piece) issued in this step / in the previous step behind its DMA */ \
         constexpr int hon_ = (ABL & 64) ? 0 : 1;                                             \
-        /* HDMA: one piece per wave and tap 0..HDPW-1 while a next chunk exists (a wave past the instruction count skips its last) */ \
-        const int hd_this_ = ((T) < HDPW && next_chunk && wave + (NTH / 64) * (T) < NHINSTR) ? 1 : 0; \
-        const int hd_prev_ = ((T) >= 1 && (T) <= HDPW && next_chunk && wave + (NTH / 64) * ((T) - 1) < NHINSTR) ? 1 : 0; \
-        const int hthis_ = hon_ * (HDMA ? hd_this_ : (HDB ? ((T) == LT ? PL * HP : 0) : (((T) < HP && next_chunk) ? PL : 0))); \
-        const int hprev_ = hon_ * (HDMA ? hd_prev_ : (HDB ? ((T) == LT + 1 ? PL * HP : 0) : (((T) >= 1 && (T) <= HP && next_chunk) ? PL : 0))); \
+        const int hthis_ = hon_ * (HDB ? ((T) == LT ? PL * HP : 0) : (((T) < HP && next_chunk) ? PL : 0)); \
+        const int hprev_ = hon_ * (HDB ? ((T) == LT + 1 ? PL * HP : 0) : (((T) >= 1 && (T) <= HP && next_chunk) ? PL : 0)); \
         const int newer_ = ((next_chunk || (T) < 7) ? PL * WPIECES : 0) + hthis_ + hprev_;     \
-        if (HDMA) {                                                                          \
-          if (newer_ >= PL * WPIECES + 2) { VP_WAIT_VMCNT(PL * WPIECES + 2); }               \
-          else if (newer_ == PL * WPIECES + 1) { VP_WAIT_VMCNT(PL * WPIECES + 1); }          \
-          else if (newer_ == PL * WPIECES) { VP_WAIT_VMCNT(PL * WPIECES); }                  \
-          else if (newer_ == 2) { VP_WAIT_VMCNT(2); }                                        \
-          else if (newer_ == 1) { VP_WAIT_VMCNT(1); }                                        \
-          else { VP_WAIT_VMCNT(0); }                                                         \
-        } else                                                                               \
         if (newer_ >= PL * WPIECES + PL * HP && HDB) { VP_WAIT_VMCNT(PL * WPIECES + PL * HP); } \
         else if (newer_ >= PL * WPIECES + 2 * PL) { VP_WAIT_VMCNT(PL * WPIECES + 2 * PL); }    \
         else if (newer_ >= PL * WPIECES + PL) { VP_WAIT_VMCNT(PL * WPIECES + PL); }            \
@@ -315,15 +317,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
   }
 
   // ---- prologue: halo(chunk 0) and weight tiles 0, 1 -> LDS
-  if constexpr (HDMA) {
 #pragma unroll
-    for (int i = 0; i < HDPW; ++i) VP_DMA_H(i, 0, 0)
-  } else {
-#pragma unroll
-    for (int pc = 0; pc < HP; ++pc) {
-      VP_LOAD_H(0, pc, 0)
-      VP_STORE_H(0, pc, 0)
-    }
+  for (int pc = 0; pc < HP; ++pc) {
+    VP_LOAD_H(0, pc, 0)
+    VP_STORE_H(0, pc, 0)
   }
   VP_DMA_W(0, 0)
   VP_DMA_W(1, 1)
@@ -358,7 +355,6 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
 #undef VP_READ_FRAGS
 #undef VP_STORE_H
 #undef VP_LOAD_H
-#undef VP_DMA_H
 #undef VP_DMA_W
 
   // ---- register epilogue: bias + activation + (hi, lo) split, both planes staged as [pixel][CO_TILE] fp16, 16-byte stores.
@@ -395,6 +391,68 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
     }
     return;
   }
+  if constexpr (STREAMK) {
+    constexpr int SLAB_V4 = MT * NT * 4 * NTH;  // f32x4 elements per slot: 64 KiB for the 128 x 128 tile
+    if (sk_producer) {
+      // the slab is in REGISTER order -- [accumulator group][thread] -- so the owner's thread t reads back exactly what the producer's
+      // thread t held, and every wave instruction moves 1 KiB of contiguous memory
+      f32x4_t* slab = reinterpret_cast<f32x4_t*>(p.partial) + (size_t)blockIdx.x * SLAB_V4 + tid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4_t v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            slab[((i * NT + j) * 4 + g) * NTH] = v;
+          }
+      VP_DRAIN_VMEM();   // this thread's stores have reached the L2
+      __syncthreads();   // ... and so have everybody's; also: every wave is out of the K loop (LDS free for the next segment)
+      if (tid == 0) {
+        VP_FENCE_RELEASE_AGENT();
+        VP_DRAIN_VMEM();
+        VP_FLAG_STORE(p.sk_flags + blockIdx.x, 1u);
+      }
+      continue;
+    }
+    if (sk_consumer) {
+      const int t_lo = sk_lt * KC_all;
+      for (int jp = sk_j - 1; jp >= 0; --jp) {
+        const int ap = (int)(sk_W * jp / sk_S), bp = (int)(sk_W * (jp + 1) / sk_S);
+        if (bp <= t_lo) break;    // slot jp (and every lower one) ends before this tile starts
+        if (ap >= bp) continue;   // empty range: publishes nothing
+        const int pslot = (jp << 3) | sk_g;
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (VP_FLAG_LOAD(p.sk_flags + pslot) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) break;  // ~ seconds: the producer never ran (see header); poisoned below
+          }
+          if (spins > (1u << 24)) VP_FLAG_STORE(p.sk_flags + gridDim.x, 1u);  // time-out word behind the flags
+          VP_FENCE_ACQUIRE_AGENT();
+          VP_FLAG_STORE(p.sk_flags + pslot, 0u);  // ready for the next launch (stream order separates the launches)
+        }
+        __syncthreads();
+        const f32x4_t* slab = reinterpret_cast<const f32x4_t*>(p.partial) + (size_t)pslot * SLAB_V4 + tid;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4_t v = slab[((i * NT + j) * 4 + g) * NTH];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][4 * g + r] += v[r];
+            }
+      }
+      if (VP_FLAG_LOAD(p.sk_flags + gridDim.x) != 0u) {  // a producer timed out (this launch or an earlier one): poison, loudly
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j][0] = __builtin_nanf("");
+      }
+    }
+  }
   __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
   const PixPatch<TW> pix{y0, x0, p.H, p.W};
 #pragma unroll
@@ -416,7 +474,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
           l[r] = (half_t)(x - (float)h[r]);
         }
         *reinterpret_cast<h4_t*>(row + g * 16) = h;
-        if constexpr (X3) *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
+        *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
       }
     }
   }
@@ -425,15 +483,18 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
   static_assert(NTH % CPR == 0 && PX % RPI == 0, "row loop shape");
   const int c8 = tid % CPR, r0 = tid / CPR;
   const int co = co0 + c8 * 8;
-  if (co >= p.Ncols) return;
+  if (co < p.Ncols) {
 #pragma unroll 4
-  for (int r = r0; r < PX; r += RPI) {
-    const int m = pix(r);
-    if (m < 0) continue;
-    const size_t o = (size_t)m * p.Cstore + co;
-    *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
-    if constexpr (X3) *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+    for (int r = r0; r < PX; r += RPI) {
+      const int m = pix(r);
+      if (m < 0) continue;
+      const size_t o = (size_t)m * p.Cstore + co;
+      *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
+      *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+    }
   }
+  if constexpr (STREAMK) __syncthreads();  // the stage is read out before the next segment's prologue overwrites it
+  }  // segment loop
 }
 
 // shape 8 ("x3w4c64"): 8x16 pixels x 64 channels, 4 waves of 32 channels x 64 pixels, 53 KB of LDS: THREE independent workgroups per CU.
@@ -441,15 +502,14 @@ __global__ __launch_bounds__(64 * WCO * WPX, X3 ? (CO_TILE == 64 ? 3 : 2) : 4) v
 // factor as the halo kernel's 64-channel tile (halo tile 3), the pipelined schedule instead of its lone-wave one.
 bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
   const int co_tile = shape == 8 ? 64 : 128;
-  if (p.in_lo == nullptr) {  // VP_FP16 engines: the 8-wave shape on single planes, conv + bias + {fp16 GELU, none}, no split-K
-    return shape == 6 && p.ks == 3 && p.stride <= 1 && p.w_lo == nullptr && p.out_lo == nullptr && p.out_hi != nullptr && p.CoutW % 128 == 0 &&
-           p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit == 1 && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE &&
-           (p.act == ACT_GELU_F16 || p.act == ACT_NONE);
-  }
   if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
+  const bool plain = p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
+  if (shape == 9) return plain && p.nsplit == 1 && p.partial != nullptr && p.sk_flags != nullptr && p.sk_slots >= 8 && p.sk_slots % 8 == 0;
   if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
-  return p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
+  return plain;
 }
+
+size_t conv3x3_sk_slab_bytes() { return (size_t)128 * 128 * sizeof(float); }
 
 template <int CO, int TH, int WPX, bool HDB>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
@@ -467,25 +527,25 @@ static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   return sk ? launch_splitk_finish(p, st) : hipSuccess;
 }
 
-// the VP_FP16 instantiation of shape 6: 76 KB of LDS, two workgroups per CU
-static hipError_t launch_x1_w8(const ConvGemmParams& p, hipStream_t st) {
-  constexpr int lds = 2 * (18 * 18 * 80) + 3 * (128 * 64);
-  const bool gelu = p.act == ACT_GELU_F16;
-  auto k = gelu ? conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_GELU_F16, 0, false, false> : conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_NONE, 0, false, false>;
+// shape 9: p.sk_slots persistent workgroups (a multiple of 8: two per CU), stream-K over the 8x16 x 128-channel tiles
+static hipError_t launch_x3_streamk(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds = 2 * (10 * 18 * 80) + 6 * (128 * 64);
+  const bool gelu = p.act == ACT_GELU;
+  auto k = gelu ? conv3x3_x3_kernel<128, 8, 2, 2, false, ACT_GELU, 0, false, true> : conv3x3_x3_kernel<128, 8, 2, 2, false, ACT_NONE, 0, false, true>;
   static LdsAttrOnce attr_once[2];
   if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
-  dim3 grid(((p.H + 15) / 16) * ((p.W + 15) / 16) * (p.CoutW / 128));
-  hipLaunchKernelGGL(k, grid, dim3(512), lds, st, p);
+  hipLaunchKernelGGL(k, dim3(p.sk_slots), dim3(256), lds, st, p);
   return hipGetLastError();
 }
 
-// shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU
+// shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU;
+// shape 8: shape 7 on 64-channel tiles; shape 9: shape 7, persistent + stream-K
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
   if (!conv3x3_x3_supported(p, shape)) return hipErrorInvalidValue;
-  if (p.in_lo == nullptr) return launch_x1_w8(p, st);
   if (shape == 6) return launch_x3_cfg<128, 16, 4, true>(p, st);
   if (shape == 7) return launch_x3_cfg<128, 8, 2, false>(p, st);
   if (shape == 8) return launch_x3_cfg<64, 8, 2, false>(p, st);
+  if (shape == 9) return launch_x3_streamk(p, st);
   return hipErrorInvalidValue;
 }
 

@@ -97,11 +97,32 @@ def test_x3w8_kernel(emu_lib):
     # split-K slices of the 4-wave shape (fp32 partials + finish kernel), incl. a mul-add residual (context_layer_6's epilogue)
     _case(emu_lib, 160, 128, 10, 20, 3, 0, 1, 0, 1, [(107, -1, 2), (107, -1, 5)], seed=24)
     _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3), (108, -1, 3)], seed=25)
-    # the VP_FP16 engines' instantiation of the 8-wave shape (single planes): same K order as their halo tile 1 => same bits
-    assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1), emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=101, nsplit=1))
-    _case(emu_lib, 96, 256, 19, 21, 3, 0, 0, 0, 0, [(106, -1, 1)], seed=27)
     with pytest.raises(emu_lib.VpError):
         emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=107, nsplit=1)      # fp16 engines have no tile 7
+    with pytest.raises(emu_lib.VpError):
+        emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # ... nor tile 6 (its single-plane form was measured slower and removed)
+
+
+def test_x3_stream_k(emu_lib):
+    """kernels_conv3x3_x3.hip shape 9 (tile 109; the operator entry passes the SLOT count as `nsplit`): persistent workgroups, the
+    tiles' K loops cut into equal chunk-step ranges per XCD group.  Slot counts chosen so that the 12 tiles x 3 chunks of the first
+    case give: one slot per group (whole tiles only), two (a tile cut in two: producer + owner), three (a slot that finishes one tile
+    and starts the next; a tile cut in three: the owner sums two slabs), eight (more slots than chunk steps: empty slots).  Against
+    torch, against the tile-per-workgroup kernel (only the fp32 summation order of a cut tile differs), and run to run."""
+    for slots in (8, 16, 24, 64):
+        _case(emu_lib, 96, 256, 19, 21, 3, 0, 1, 0, 1, [(109, -1, slots)], seed=41)
+    _case(emu_lib, 160, 128, 24, 48, 3, 0, 0, 0, 1, [(109, -1, 8), (109, -1, 40), (109, -1, 56)], seed=42)   # 9 tiles x 5 chunks: groups of 2 and 1 tiles
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((64, 18, 33), dtype=np.float32)
+    wt = rng.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.float32(0.06)
+    b = rng.standard_normal((128,), dtype=np.float32) * np.float32(0.1)
+    ref = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1)
+    assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=109, nsplit=8), ref)    # uncut tiles: the same K order, the same bits
+    a = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=109, nsplit=24)
+    assert np.abs(a - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(a, emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=109, nsplit=24))     # deterministic cuts and summation order
+    with pytest.raises(emu_lib.VpError):
+        emu_lib.op_conv2d(x, wt, b, ks=3, act=2, precision=1, tile=109, nsplit=8)      # SiLU: not one of the shape's epilogues
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
