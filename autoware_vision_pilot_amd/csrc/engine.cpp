@@ -193,6 +193,10 @@ void Engine::release() {
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   ev0_ = ev1_ = nullptr;
+  for (hipEvent_t& ev : h_frame_ev_) {
+    if (ev) hipEventDestroy(ev);
+    ev = nullptr;
+  }
   if (stream_ && !base_) hipStreamDestroy(stream_);
   stream_ = nullptr;
 }
@@ -1681,13 +1685,19 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int in
       VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_frame_), need * 2, hipHostMallocDefault));  // two slots: frame n+1 is staged while n flies
       h_frame_cap_ = need;
     }
-    uint8_t* slot = h_frame_ + (size_t)(h_frame_slot_ ^= 1) * h_frame_cap_;
+    h_frame_slot_ ^= 1;
+    uint8_t* slot = h_frame_ + (size_t)h_frame_slot_ * h_frame_cap_;
+    // A pinned source makes the H2D below truly asynchronous: the copy that last read this slot (two uploads ago) may still be
+    // queued behind earlier frames' graphs.  Its event orders this host write behind it.
+    if (!h_frame_ev_[h_frame_slot_]) VP_HIP_CHECK(hipEventCreateWithFlags(&h_frame_ev_[h_frame_slot_], hipEventDisableTiming));
+    else VP_HIP_CHECK(hipEventSynchronize(h_frame_ev_[h_frame_slot_]));
     if (stride == 3 * w) {
       std::memcpy(slot, frame, packed);
     } else {
       for (int y = 0; y < h; ++y) std::memcpy(slot + (size_t)y * stride, frame + (size_t)y * stride, (size_t)3 * w);
     }
     VP_HIP_CHECK(hipMemcpyAsync(dst, slot, packed, hipMemcpyHostToDevice, stream_));
+    VP_HIP_CHECK(hipEventRecord(h_frame_ev_[h_frame_slot_], stream_));
   } else if (stride == 3 * w) {
     VP_HIP_CHECK(hipMemcpyAsync(dst, frame, packed, hipMemcpyHostToDevice, stream_));
   } else {

@@ -150,6 +150,8 @@ class Engine {
   void upload_act(Act* a, const float* chw);
   hipStream_t stream() const { return stream_; }
   int gpu() const { return gpu_; }
+  int decode_mode() const { return decode_mode_; }
+  bool host_logits_current() const { return host_logits_valid_; }  // the pinned host logits belong to the LAST pass
   bool split() const { return (precision_ & 15) == 1; }
   bool fp8_weights() const { return (precision_ & 16) != 0; }
   int shared_level() const { return shared_level_; }  // 0 own network, 1 backbone shared, 2 backbone + context + neck shared
@@ -230,6 +232,7 @@ class Engine {
   uint8_t* h_frame_ = nullptr;
   size_t h_frame_cap_ = 0;
   int h_frame_slot_ = 0;
+  hipEvent_t h_frame_ev_[2] = {nullptr, nullptr};  // recorded behind the H2D that reads a slot; awaited before the slot is rewritten
   bool pinned_staging_ = true;
 
   // stream-K slabs / flags (one set per engine)

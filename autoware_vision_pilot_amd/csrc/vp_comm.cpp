@@ -78,6 +78,7 @@ struct vp_comm {
   void* d_gather = nullptr;   // [world][bytes_per_rank]
   void* h_gather = nullptr;   // pinned host copy, filled by vp_comm_fetch
   size_t last_bytes = 0;      // record size of the last vp_gather
+  hipStream_t last_stream = nullptr;  // ... and the stream it was enqueued on: the only stream vp_comm_fetch's copy is ordered on
   std::string err;
 };
 
@@ -186,6 +187,7 @@ int vp_gather(vp_engine* e, vp_comm* c, int what) {
     return VP_ERR_HIP;
   }
   c->last_bytes = bytes;
+  c->last_stream = e->impl->stream();
   return VP_OK;
 }
 
@@ -202,6 +204,10 @@ int vp_comm_fetch(vp_comm* c, vp_engine* e, const void** host, size_t* record_by
   if (c->last_bytes == 0) {
     c->err = "vp_comm_fetch: nothing gathered yet";
     return VP_ERR_STATE;
+  }
+  if (e->impl->stream() != c->last_stream) {  // another engine's stream carries no order against the all-gather: stale or partial records
+    c->err = "vp_comm_fetch: pass the engine whose stream ran the last vp_gather";
+    return VP_ERR_ARG;
   }
   if (hipSetDevice(c->gpu) != hipSuccess) return VP_ERR_HIP;
   if (hipMemcpyAsync(c->h_gather, c->d_gather, c->last_bytes * c->world, hipMemcpyDeviceToHost, e->impl->stream()) != hipSuccess ||

@@ -43,6 +43,9 @@ _SIGS = {
     "vp_last_error": (C.c_char_p, [_P]),
     "vp_set_input_format": (C.c_int, [_P, C.c_int, C.c_int]),
     "vp_set_decode_mode": (C.c_int, [_P, C.c_int]),
+    "vp_get_decode_mode": (C.c_int, [_P]),
+    "vp_gpu_id": (C.c_int, [_P]),
+    "vp_host_logits_current": (C.c_int, [_P]),
     "vp_input_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     "vp_infer_tensor": (C.c_int, [_P, _P]),
@@ -79,6 +82,8 @@ _SIGS = {
     "vp_tensor_read": (C.c_int, [_P, C.c_int, _P]),
     "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
+    "vp_op_conv2d_repeat": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
     "vp_version": (C.c_char_p, []),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
@@ -114,10 +119,17 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VpError(f"{LIB_PATH} not built -- run __graft_entry__.build(); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in list(_SIGS.items()) + list(_COMM_SIGS.items()):
+    for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the multi-camera exchange is bound where the build carries it (a single-camera host may build without the RCCL headers:
+    # csrc/Makefile VP_NO_COMM=1); Comm raises on first use otherwise.  tests/test_host_cpu.py checks the shipped library has them all.
+    for name, (res, args) in _COMM_SIGS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -402,6 +414,13 @@ def decode_logits_host(logits_chw, decode_mode=VP_DECODE_SEG_MASK, gpu_id=0):
     return out
 
 
+def _comm_lib():
+    lib = load()
+    if not hasattr(lib, "vp_comm_create"):
+        raise VpError("this libvp_hip.so was built without the multi-camera exchange (csrc/Makefile VP_NO_COMM=1)")
+    return lib
+
+
 class Comm:
     """RCCL communicator behind the C ABI (vp_comm_*): per-frame all-gather of the per-camera result records."""
 
@@ -409,13 +428,13 @@ class Comm:
     def unique_id():
         buf = C.create_string_buffer(VP_COMM_ID_BYTES)
         err = C.create_string_buffer(512)
-        rc = load().vp_comm_unique_id(buf, err, len(err))
+        rc = _comm_lib().vp_comm_unique_id(buf, err, len(err))
         if rc != 0:
             raise VpError(f"vp_comm_unique_id failed ({rc}): {err.value.decode(errors='replace')}")
         return buf.raw
 
     def __init__(self, unique_id, rank, world, gpu_id, record_bytes_max):
-        self._lib = load()
+        self._lib = _comm_lib()
         self._h = C.c_void_p()
         err = C.create_string_buffer(512)
         idbuf = C.create_string_buffer(bytes(unique_id), VP_COMM_ID_BYTES)
@@ -478,4 +497,22 @@ def op_conv2d(x, weight, bias, ks=3, mode=0, act=0, res=None, res_mode=0, precis
                           _ptr(r) if r is not None else None, tile, bk, nsplit, _ptr(out), err, len(err))
     if rc != 0:
         raise VpError(f"vp_op_conv2d failed ({rc}): {err.value.decode(errors='replace')}")
+    return out
+
+
+def op_conv2d_repeat(xs, weight, bias, ks=3, act=0, precision=VP_FP16, tile=-1, bk=-1, nsplit=-1, rounds=2, gpu_id=0):
+    """vp_op_conv2d_repeat: the conv operator on every input of `xs`, `rounds` times over, through ONE plan and workspace.
+    Returns out[round][input] (arrays [Cout][h][w])."""
+    lib = load()
+    x = np.ascontiguousarray(np.stack(xs), dtype=np.float32)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    out = np.empty((rounds, n, cout, h, w), dtype=np.float32)
+    err = C.create_string_buffer(512)
+    rc = lib.vp_op_conv2d_repeat(gpu_id, precision, _ptr(x), n, rounds, cin, h, w, _ptr(weight), _ptr(bias), cout, ks, act, tile, bk, nsplit,
+                                 _ptr(out), err, len(err))
+    if rc != 0:
+        raise VpError(f"vp_op_conv2d_repeat failed ({rc}): {err.value.decode(errors='replace')}")
     return out

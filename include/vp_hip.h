@@ -111,8 +111,11 @@ int vp_infer_shared(vp_engine* e);
  *     vp_create_batched(&enc, VP_SCENESEG, "SceneSeg.onnx", VP_FP16, gpu, 3, ...);
  *     for f in 0..2: vp_create_shared_frame(&head[f], enc, f, VP_SCENESEG, "SceneSeg.onnx", VP_FP16, gpu, ...);
  *     per pass: vp_upload_frame_n(enc, f, frame_f, h, w, stride) x3;  vp_enqueue(enc);  vp_infer_shared(head[f]) x3.
- * All frames of a pass share one geometry.  Errors as for vp_create_shared; frames in 1..16.  Bit-identical per
- * camera to the single-frame engine (CPU emulation and MI355X); throughput not yet measured, see DESIGN.md. */
+ * All frames of a pass share one geometry.  Errors as for vp_create_shared; frames in 1..16.  Per camera the results equal
+ * the single-frame engine's up to fp32 summation order (the split-K factor of a 1x1 GEMM follows its pixel count, which the
+ * batch multiplies; measured bit-identical on the tested networks, the tests hold them to 1e-3).  Timed in DESIGN.md.
+ * vp_upload_frame* stages pageable frames through two pinned slots: a slot is rewritten only after the H2D copy that last read it
+ * has completed (per-slot event), so any number of uploads may be queued without a synchronisation in between. */
 int vp_create_batched(vp_engine** out, int model_kind, const char* weights_path, int precision, int gpu_id, int frames, char* err,
                       size_t err_len);
 int vp_create_batched_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id,
@@ -127,6 +130,9 @@ int vp_upload_frame_n(vp_engine* e, int index, const uint8_t* frame, int h, int 
 /* ---- configuration ------------------------------------------------------------------------------------- */
 int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order);
 int vp_set_decode_mode(vp_engine* e, int decode_mode);
+int vp_get_decode_mode(const vp_engine* e);      /* the vp_decode_mode in force (>= 0), or VP_ERR_ARG */
+int vp_gpu_id(const vp_engine* e);               /* the device the engine lives on */
+int vp_host_logits_current(const vp_engine* e);  /* 1 = the host pointer vp_logits() hands out holds the LAST pass's logits */
 int vp_input_hw(const vp_engine* e, int* h, int* w);
 
 /* Which outputs vp_infer / vp_infer_shared / vp_infer_multi copy to the host before they return (default both, what
@@ -240,6 +246,12 @@ int vp_tensor_read(vp_engine* e, int i, float* dst_chw);                       /
 int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,
                  char* err, size_t err_len);
+
+/* the mode-0 operator on n_in inputs ([n_in][Cin][h][w]), `rounds` times over, through ONE plan and workspace; out is
+ * [rounds][n_in][Cout][h][w].  Tests of what a kernel leaves behind for its next launch (stream-K slabs and flags). */
+int vp_op_conv2d_repeat(int gpu_id, int precision, const float* in, int n_in, int rounds, int cin, int h, int w, const float* weight,
+                        const float* bias, int cout, int ks, int act, int tile, int bk, int nsplit, float* out, char* err,
+                        size_t err_len);
 
 const char* vp_version(void);
 

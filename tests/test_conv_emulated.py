@@ -123,6 +123,13 @@ def test_x3_stream_k(emu_lib):
     assert np.array_equal(a, emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=109, nsplit=24))     # deterministic cuts and summation order
     with pytest.raises(emu_lib.VpError):
         emu_lib.op_conv2d(x, wt, b, ks=3, act=2, precision=1, tile=109, nsplit=8)      # SiLU: not one of the shape's epilogues
+    # one plan, several frames, several rounds: the flags are back to zero and no slab survives into the next launch's sums
+    xs = [x, x * np.float32(0.25), rng.standard_normal(x.shape, dtype=np.float32)]
+    refs = [emu_lib.op_conv2d(v, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1) for v in xs]
+    outs = emu_lib.op_conv2d_repeat(xs, wt, b, ks=3, act=1, precision=1, tile=109, nsplit=24, rounds=2)
+    for r in range(2):
+        for o, ref in zip(outs[r], refs):
+            assert np.abs(o - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
