@@ -264,7 +264,7 @@ int Engine::streamk_slots() const {
 }
 void Engine::ensure_streamk_ws(int slots) {
   if (slots <= sk_cap_) return;
-  if (sk_cap_ != 0) throw std::runtime_error("stream-K workspace: layers of one engine must agree on the slot count");  // ops already captured its pointers
+  if (sk_cap_ != 0) throw std::runtime_error("stream-K workspace: allocated for fewer slots");  // ops already captured its pointers
   sk_slabs_ = static_cast<float*>(dalloc((size_t)slots * conv3x3_sk_slab_bytes(), false));
   sk_flags_ = static_cast<unsigned*>(dalloc((size_t)(slots + 1) * sizeof(unsigned), true));
   sk_cap_ = slots;
@@ -404,8 +404,8 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   }
   const int M = p.H * p.W;
   p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
-  if (pc.tile == 109) {  // stream-K: one slab + flag per slot, shared by this engine's layers (they are serialised on its stream)
-    ensure_streamk_ws(pc.sk_slots);
+  if (pc.tile == 109 || pc.tile == 110) {  // stream-K: one slab + flag per slot, shared by this engine's layers (they are serialised on its stream)
+    ensure_streamk_ws(std::max(pc.sk_slots, streamk_slots()));
     p.partial = sk_slabs_;
     p.sk_flags = sk_flags_;
     p.sk_slots = pc.sk_slots;
@@ -466,9 +466,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
-    if (ht >= 6 && ht <= 9) {
+    if (ht >= 6 && ht <= 10) {
       if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 9 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
-      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : (ht == 8 ? "conv3x3_x3w4<co64,px128>" : "conv3x3_x3sk<co128,px128>"))) + (pc.nsplit > 1 ? "+splitk" : "");
+      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : (ht == 8 ? "conv3x3_x3w4<co64,px128>" : (ht == 9 ? "conv3x3_x3sk<co128,px128>" : "conv3x3_x3sk8<co128,px256>")))) + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -595,12 +595,13 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     if (split() && o.tile < 0 && halo >= 0 && ncols % 128 == 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 &&
         (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE) {
       static const char* envsk = std::getenv("VP_STREAMK");
-      const int level = envsk ? std::atoi(envsk) : 1;
+      const int level = envsk ? std::atoi(envsk) : 0;
       const long long steps = (long long)((in->H + 7) / 8) * ((in->W + 15) / 16) * (ncols / 128) * (cin_pad / 32);
-      if (level >= 1 && (halo == 6 || halo == 7)) halo = 9;
-      else if (level >= 2 && (halo == 1 || halo == 3) && steps >= 2LL * streamk_slots()) halo = 9;
+      if (level == 1 && (halo == 6 || halo == 7)) halo = 9;
+      else if (level == 2 && (halo == 1 || halo == 3 || halo == 6 || halo == 7) && steps >= 2LL * streamk_slots()) halo = 9;
+      else if (level == 3 && halo == 6) halo = 10;   // the 8-wave shape's layers on one 8-wave slot per CU
     }
-    if ((halo == 6 || halo == 7 || halo == 8 || halo == 9) && !split()) throw std::invalid_argument("halo tiles 6 - 9 are fp16x3 kernels: " + name);
+    if (halo >= 6 && halo <= 10 && !split()) throw std::invalid_argument("halo tiles 6 - 9 are fp16x3 kernels: " + name);
   }
   // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
   // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
@@ -676,9 +677,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
     if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
-    if (halo == 9) {               // stream-K: the slots carry the K split (the operator entry passes a slot count as `nsplit`: small test grids)
+    if (halo == 9 || halo == 10) {  // stream-K: the slots carry the K split (the operator entry passes a slot count as `nsplit`: small test grids)
       pc.nsplit = 1;
-      pc.sk_slots = o.nsplit >= 8 ? o.nsplit / 8 * 8 : streamk_slots();
+      pc.sk_slots = o.nsplit >= 8 ? o.nsplit / 8 * 8 : streamk_slots() / (halo == 10 ? 2 : 1) / 8 * 8;
     }
     if (halo == 7 && blocks >= 160 && o.nsplit <= 0) pc.nsplit = 1;
     // 64-channel tiles of the parity mode: the pipelined kernel's 64-channel shape (halo tile 8: same tiles, same split factor as
@@ -707,7 +708,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-        const int ci_sw = (halo >= 6 && halo <= 9) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
+        const int ci_sw = (halo >= 6 && halo <= 10) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;
@@ -1256,6 +1257,7 @@ void Engine::build_model(const WeightBlob& blob) {
         pp.stdv[c] = std_rgb[colour];
       }
       pp.out = d_input_ + (size_t)fi * 3 * net_h() * net_w();
+      if (resize_mode_ != 0) return launch_pil_resample(pil_params(pp), st);
       return launch_preprocess(pp, st);
     };
     ops_.push_back(std::move(op));
@@ -1316,6 +1318,7 @@ void Engine::build_autodrive(const WeightBlob& blob) {
   };
   d_input_ = static_cast<float*>(dalloc((size_t)3 * net_h() * net_w() * sizeof(float)));
   plane_order_ = 1;  // RGB planes, ImageNet constants (visualizations/AutoDrive/video_visualization.py:29-33)
+  resize_mode_ = 1;  // ... behind PIL's antialiased Image.resize(..., Image.BILINEAR) (same lines)
   push("preprocess", "preprocess", [this](hipStream_t st) {
     PreprocessParams pp{};
     pp.frame = d_frame_;
@@ -1332,6 +1335,7 @@ void Engine::build_autodrive(const WeightBlob& blob) {
       pp.stdv[c] = std_rgb[colour];
     }
     pp.out = d_input_;
+    if (resize_mode_ != 0) return launch_pil_resample(pil_params(pp), st);
     return launch_preprocess(pp, st);
   });
   first_net_op_ = 1;
@@ -1636,8 +1640,102 @@ static void linear_taps_u8(int src, int dst, std::vector<int>* tab) {
   }
 }
 
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) in the same double arithmetic, operation for
+// operation (restated and pinned against PIL in oracle/pre_post.py pil_resample_coeffs): filter support scaled by the
+// down-scaling factor, taps normalised to sum 1, quantised to 22 fractional bits.  filter: 1 = BILINEAR, 2 = BICUBIC (a = -0.5).
+#pragma clang fp contract(off)
+int pil_coeffs(int in_size, int out_size, int filter, std::vector<int>* bounds, std::vector<int>* kk) {
+  auto weight = [filter](double x) -> double {
+    if (x < 0.0) x = -x;
+    if (filter == 1) return x < 1.0 ? 1.0 - x : 0.0;
+    const double a = -0.5;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+  };
+  double filterscale = (double)in_size / out_size;
+  const double scale = filterscale;
+  if (filterscale < 1.0) filterscale = 1.0;
+  const double support = (filter == 1 ? 1.0 : 2.0) * filterscale;
+  const int ksize = (int)std::ceil(support) * 2 + 1;
+  bounds->assign((size_t)out_size * 2, 0);
+  kk->assign((size_t)out_size * ksize, 0);
+  std::vector<double> k(ksize);
+  const double ss = 1.0 / filterscale;
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    double ww = 0.0;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; ++x) {
+      const double w = weight((x + xmin - center + 0.5) * ss);
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x) {
+      if (ww != 0.0) k[x] /= ww;
+      (*kk)[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << 22)) : (int)(0.5 + k[x] * (1 << 22));
+    }
+    (*bounds)[2 * xx] = xmin;
+    (*bounds)[2 * xx + 1] = xmax;
+  }
+  return ksize;
+}
+
+PilResampleParams Engine::pil_params(const PreprocessParams& pp) const {
+  PilResampleParams q{};
+  q.frame = pp.frame;
+  q.stride = pp.stride;
+  q.in_h = frame_h_;
+  q.in_w = frame_w_;
+  q.out_h = pp.out_h;
+  q.out_w = pp.out_w;
+  q.hb = d_pil_hb_;
+  q.hk = d_pil_hk_;
+  q.hks = pil_hks_;
+  q.vb = d_pil_vb_;
+  q.vk = d_pil_vk_;
+  q.vks = pil_vks_;
+  q.tmp = d_pil_tmp_;
+  for (int c = 0; c < 3; ++c) {
+    q.src_c[c] = pp.src_c[c];
+    q.mean[c] = pp.mean[c];
+    q.stdv[c] = pp.stdv[c];
+  }
+  q.out = pp.out;
+  return q;
+}
+
+void Engine::set_resize_mode(int mode) {
+  if (mode < 0 || mode > 2) throw std::invalid_argument("resize mode: 0 = cv::resize INTER_LINEAR model, 1 = PIL BILINEAR, 2 = PIL BICUBIC");
+  if (base_) throw std::invalid_argument("shared engine: the base engine owns the frame path");
+  if (mode != resize_mode_) {
+    resize_mode_ = mode;
+    tab_h_ = tab_w_ = 0;
+    graph_valid_ = false;
+    ++plan_epoch_;
+  }
+}
+
 void Engine::ensure_tables(int h, int w) {
   if (h == tab_h_ && w == tab_w_) return;
+  if (resize_mode_ != 0) {  // Pillow's resample: per-output tap tables for both passes + the u8 image between them
+    std::vector<int> hb, hk, vb, vk;
+    pil_hks_ = pil_coeffs(w, net_w(), resize_mode_, &hb, &hk);
+    pil_vks_ = pil_coeffs(h, net_h(), resize_mode_, &vb, &vk);
+    VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    d_pil_hb_ = dupload(hb);
+    d_pil_hk_ = dupload(hk);
+    d_pil_vb_ = dupload(vb);
+    d_pil_vk_ = dupload(vk);
+    d_pil_tmp_ = static_cast<uint8_t*>(dalloc((size_t)h * net_w() * 3, false));
+    tab_h_ = h;
+    tab_w_ = w;
+    return;
+  }
   std::vector<int> xt, yt;
   linear_taps_u8(w, net_w(), &xt);
   linear_taps_u8(h, net_h(), &yt);

@@ -41,6 +41,9 @@ class WeightBlob {
 std::map<std::string, HostTensor> load_onnx_state_dict(const std::string& path);
 std::vector<char> onnx_to_blob(const std::string& path);
 
+// Pillow's resample coefficient tables (engine.cpp): bounds [out][2], coefficients [out][ksize] with 22 fractional bits; returns ksize
+int pil_coeffs(int in_size, int out_size, int filter, std::vector<int>* bounds, std::vector<int>* kk);
+
 struct Act {
   std::string name;
   int Creal = 0, C = 0, H = 0, W = 0;
@@ -85,6 +88,10 @@ class Engine {
   // configuration
   void set_input_format(int pixel_format, int plane_order);
   void set_decode_mode(int mode);
+  // frame resize ahead of the network: 0 = the integer bilinear modelled on cv::resize INTER_LINEAR (the C++ nodes; default of the scene
+  // networks), 1 / 2 = Pillow's antialiased BILINEAR / BICUBIC (the Python scripts' Image.resize; 1 is AutoDrive's default)
+  void set_resize_mode(int mode);
+  int resize_mode() const { return resize_mode_; }
   int net_h() const { return kind_ == 4 ? 512 : 320; }   // AutoDrive: autodrive_network.py:8-9
   int net_w() const { return kind_ == 4 ? 1024 : 640; }
   // AutoDrive (kind 4) pairs every frame with the previous one: infer_pair() runs the backbone on `prev` first
@@ -215,6 +222,14 @@ class Engine {
   int* d_ytab_ = nullptr;
   int tab_h_ = 0, tab_w_ = 0;
   float* d_input_ = nullptr;  // [3][320][640]
+  int resize_mode_ = 0;
+  int* d_pil_hb_ = nullptr;
+  int* d_pil_hk_ = nullptr;
+  int* d_pil_vb_ = nullptr;
+  int* d_pil_vk_ = nullptr;
+  int pil_hks_ = 0, pil_vks_ = 0;
+  uint8_t* d_pil_tmp_ = nullptr;
+  PilResampleParams pil_params(const PreprocessParams& pp) const;
   bool input_is_tensor_ = false;
 
   // outputs

@@ -15,6 +15,26 @@ struct PreprocessParams {
   float* out;            // [3][out_h][out_w]
 };
 
+// Pillow's antialiased resample (PIL.Image.resize with BILINEAR / BICUBIC; src/libImaging/Resample.c 8bpc path) + /255 + (x-mean)/std +
+// HWC->CHW: the AutoDrive frame path (Models/visualizations/AutoDrive/video_visualization.py:29-33) and the scene networks' Python
+// visualisation scripts.  Definition pinned against PIL itself: oracle/pre_post.py resize_pil_u8.  Two passes, as Pillow's: horizontal
+// into a u8 image [in_h][out_w][3], vertical from it; coefficient tables (22 fractional bits) are built on the host in double.
+struct PilResampleParams {
+  const uint8_t* frame;  // device, in_h x in_w x 3
+  int stride;            // bytes per row
+  int in_h, in_w, out_h, out_w;
+  const int* hb;         // [out_w][2] = first source column, tap count
+  const int* hk;         // [out_w][hks]
+  int hks;
+  const int* vb;         // [out_h][2]
+  const int* vk;         // [out_h][vks]
+  int vks;
+  uint8_t* tmp;          // [in_h][out_w][3]
+  int src_c[3];
+  float mean[3], stdv[3];
+  float* out;            // [3][out_h][out_w]
+};
+
 struct StemParams {
   const float* in;  // [3][H][W]
   int H, W;         // input size (output is H/2 x W/2)
@@ -128,6 +148,7 @@ bool convt_rs_supported(const ConvGemmParams& p, bool split);
 int convt_rs_shape_case(int H, int W, int cin_pad, int cin2_pad, int ncols, int cstore);  // 0 = not covered
 hipError_t launch_convt_rs(const ConvGemmParams& p, hipStream_t st);
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
+hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st);  // both passes
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);

@@ -33,7 +33,7 @@
 //             wave of each per SIMD -- they drift out of phase, so one workgroup's prologue / chunk hand-over / epilogue
 //             (exact GELU + split: ~1000 VALU instructions per wave, 64 KiB of stores) runs under the other's MFMAs.
 //   8 "x3w4c64": shape 7 on 64-channel tiles (53 KB, three workgroups per CU).
-//   9 "x3sk": shape 7, PERSISTENT, with the K loops of the tiles dealt STREAM-K (below).
+//   9 "x3sk": shape 7, PERSISTENT, with the K loops of the tiles dealt STREAM-K (below);  10 "x3sk8": shape 6 likewise (one slot per CU).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -76,7 +76,7 @@ namespace vp {
 // depend on the layer shape and the slot count alone).
 template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool STREAMK = false>
 __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
-  static_assert(!(SPLITK && STREAMK) && !(STREAMK && HDB), "stream-K: the single-halo 4-wave shape, with its own fix-up path");
+  static_assert(!(SPLITK && STREAMK), "stream-K has its own fix-up path");
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
@@ -504,12 +504,12 @@ bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
   const int co_tile = shape == 8 ? 64 : 128;
   if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
   const bool plain = p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
-  if (shape == 9) return plain && p.nsplit == 1 && p.partial != nullptr && p.sk_flags != nullptr && p.sk_slots >= 8 && p.sk_slots % 8 == 0;
+  if (shape == 9 || shape == 10) return plain && p.nsplit == 1 && p.partial != nullptr && p.sk_flags != nullptr && p.sk_slots >= 8 && p.sk_slots % 8 == 0;
   if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
   return plain;
 }
 
-size_t conv3x3_sk_slab_bytes() { return (size_t)128 * 128 * sizeof(float); }
+size_t conv3x3_sk_slab_bytes() { return (size_t)128 * 256 * sizeof(float); }  // the larger of the two stream-K tiles (shape 10)
 
 template <int CO, int TH, int WPX, bool HDB>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
@@ -538,6 +538,17 @@ static hipError_t launch_x3_streamk(const ConvGemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// shape 10: p.sk_slots persistent 8-wave workgroups (one per CU), stream-K over the 16x16 x 128-channel tiles
+static hipError_t launch_x3_streamk_w8(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds = 2 * 2 * (18 * 18 * 80) + 6 * (128 * 64);
+  const bool gelu = p.act == ACT_GELU;
+  auto k = gelu ? conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_GELU, 0, false, true> : conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_NONE, 0, false, true>;
+  static LdsAttrOnce attr_once[2];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(p.sk_slots), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
 // shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU;
 // shape 8: shape 7 on 64-channel tiles; shape 9: shape 7, persistent + stream-K
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
@@ -546,6 +557,7 @@ hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st)
   if (shape == 7) return launch_x3_cfg<128, 8, 2, false>(p, st);
   if (shape == 8) return launch_x3_cfg<64, 8, 2, false>(p, st);
   if (shape == 9) return launch_x3_streamk(p, st);
+  if (shape == 10) return launch_x3_streamk_w8(p, st);
   return hipErrorInvalidValue;
 }
 

@@ -27,6 +27,50 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
   }
 }
 
+// Pillow's 8-bit resample passes (kernels.hpp PilResampleParams): int32 accumulation from 1 << 21 of u8 x 22-bit coefficients,
+// `>> 22`, clip to u8 (Resample.c clip8) -- integer work, bit-exact by construction.
+__device__ __forceinline__ int pil_clip8(int acc) { return min(max(acc >> 22, 0), 255); }
+__global__ __launch_bounds__(256) void pil_resample_h_kernel(const PilResampleParams p) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= p.out_w) return;
+  const int lo = p.hb[2 * x], n = p.hb[2 * x + 1];
+  const int* k = p.hk + (size_t)x * p.hks;
+  const uint8_t* row = p.frame + (size_t)y * p.stride + (size_t)lo * 3;
+  int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+  for (int t = 0; t < n; ++t) {
+    const int kt = k[t];
+    a0 += (int)row[3 * t + 0] * kt;
+    a1 += (int)row[3 * t + 1] * kt;
+    a2 += (int)row[3 * t + 2] * kt;
+  }
+  uint8_t* d = p.tmp + ((size_t)y * p.out_w + x) * 3;
+  d[0] = (uint8_t)pil_clip8(a0);
+  d[1] = (uint8_t)pil_clip8(a1);
+  d[2] = (uint8_t)pil_clip8(a2);
+}
+__global__ __launch_bounds__(256) void pil_resample_v_kernel(const PilResampleParams p) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= p.out_w) return;
+  const int lo = p.vb[2 * y], n = p.vb[2 * y + 1];
+  const int* k = p.vk + (size_t)y * p.vks;
+  const uint8_t* col = p.tmp + ((size_t)lo * p.out_w + x) * 3;
+  int a[3] = {1 << 21, 1 << 21, 1 << 21};
+  for (int t = 0; t < n; ++t) {
+    const int kt = k[t];
+    const uint8_t* s = col + (size_t)t * p.out_w * 3;
+    a[0] += (int)s[0] * kt;
+    a[1] += (int)s[1] * kt;
+    a[2] += (int)s[2] * kt;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = p.src_c[c];
+    const int q = pil_clip8(sc == 0 ? a[0] : (sc == 1 ? a[1] : a[2]));
+    const float t = __fdiv_rn((float)q, 255.0f);   // torchvision to_tensor: u8 -> fp32 / 255
+    p.out[((size_t)c * p.out_h + y) * p.out_w + x] = __fdiv_rn(__fsub_rn(t, p.mean[c]), p.stdv[c]);
+  }
+}
+
 // context_layer_3: Conv 3x3 1->128 on the 10x20 sigmoid map + GELU (scene_context.py:19,46-47).
 __global__ __launch_bounds__(256) void ctx_conv1_kernel(const CtxConv1Params p) {
   const int CG = p.out.C >> 3;
@@ -234,6 +278,11 @@ __global__ __launch_bounds__(256) void act_to_nchw_kernel(ActView a, int Creal, 
 // ---------------------------------------------------------------------------------------------- launchers
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st) {
   VP_LAUNCH(preprocess_kernel, dim3(nblk(p.out_w), p.out_h), dim3(256), 0, st, p);
+}
+hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(pil_resample_h_kernel, dim3(nblk(p.out_w), p.in_h), dim3(256), 0, st, p);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  VP_LAUNCH(pil_resample_v_kernel, dim3(nblk(p.out_w), p.out_h), dim3(256), 0, st, p);
 }
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st) {
   VP_LAUNCH(ctx_conv1_kernel, dim3(nblk((long long)p.H * p.W * (p.out.C >> 3))), dim3(256), 0, st, p);

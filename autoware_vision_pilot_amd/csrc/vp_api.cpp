@@ -250,6 +250,20 @@ int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order) {
 int vp_set_decode_mode(vp_engine* e, int mode) {
   return guarded(e, [&](vp::Engine& g) { g.set_decode_mode(mode); });
 }
+int vp_set_resize_mode(vp_engine* e, int mode) {
+  return guarded(e, [&](vp::Engine& g) { g.set_resize_mode(mode); });
+}
+// host only: the tap tables the VP_RESIZE_PIL_* modes use for one axis (tests pin them against Pillow's through the oracle)
+int vp_resample_coeffs(int in_size, int out_size, int resize_mode, int* bounds, int* coeffs, int coeffs_cap) {
+  if (in_size < 1 || out_size < 1 || (resize_mode != 1 && resize_mode != 2) || !bounds || !coeffs) return VP_ERR_ARG;
+  std::vector<int> b, k;
+  const int ksize = vp::pil_coeffs(in_size, out_size, resize_mode, &b, &k);
+  if ((long long)ksize * out_size > coeffs_cap) return VP_ERR_ARG;
+  std::copy(b.begin(), b.end(), bounds);
+  std::copy(k.begin(), k.end(), coeffs);
+  return ksize;
+}
+int vp_get_resize_mode(const vp_engine* e) { return (e && e->impl) ? e->impl->resize_mode() : VP_ERR_ARG; }
 int vp_get_decode_mode(const vp_engine* e) { return (e && e->impl) ? e->impl->decode_mode() : VP_ERR_ARG; }
 int vp_gpu_id(const vp_engine* e) { return (e && e->impl) ? e->impl->gpu() : VP_ERR_ARG; }
 int vp_host_logits_current(const vp_engine* e) { return (e && e->impl) ? (e->impl->host_logits_current() ? 1 : 0) : VP_ERR_ARG; }

@@ -45,6 +45,21 @@ class _NetworkInfer:
         self.model.infer_tensor(image_loader(image))
         return self.model.logits()  # CxHxW fp32
 
+    def _post(self):
+        raise NotImplementedError
+
+    def inference_resized(self, frame):
+        """The visualisation scripts' call pair ``image_pil = image_pil.resize((640, 320))`` + ``inference(image_pil)``
+        (Models/visualizations/Scene3D/video_visualization.py:87-88, DomainSeg/video_visualization.py:112-113) as ONE device pass on a
+        frame of any size (HxWx3 uint8 RGB, e.g. a PIL image): Pillow's default-filter resize (BICUBIC, antialiased) is done by the
+        engine, bit-exact against Pillow (VP_RESIZE_PIL_BICUBIC).  Same return value as ``inference``."""
+        a = np.asarray(frame)
+        if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+            raise ValueError("frame must be HxWx3 uint8 RGB")
+        self.model.set_resize_mode(_lib.VP_RESIZE_PIL_BICUBIC)
+        self.model.infer(a)
+        return self._post()
+
 
 class SceneSegNetworkInfer(_NetworkInfer):
     _kind = "sceneseg"
@@ -53,28 +68,41 @@ class SceneSegNetworkInfer(_NetworkInfer):
         super().__init__(checkpoint_path, precision, gpu_id)
         self.model.set_decode_mode(_lib.VP_DECODE_CLASS_INDEX)
 
+    def _post(self):
+        return self.model.mask().astype(np.int64)  # argmax index map, first max wins (scene_seg_infer.py:52-55)
+
     def inference(self, image):
         self._forward(image)
-        return self.model.mask().astype(np.int64)  # argmax index map, first max wins (scene_seg_infer.py:52-55)
+        return self._post()
 
 
 class Scene3DNetworkInfer(_NetworkInfer):
     _kind = "scene3d"
 
+    def _post(self):
+        return np.ascontiguousarray(self.model.logits().transpose(1, 2, 0))
+
     def inference(self, image):
-        return np.ascontiguousarray(self._forward(image).transpose(1, 2, 0))
+        self._forward(image)
+        return self._post()
 
 
 class DomainSegNetworkInfer(_NetworkInfer):
     _kind = "domainseg"
 
+    def _post(self):
+        return (self.model.mask() > 0).astype(np.float32)[..., None]  # 0/1 floats (domain_seg_infer.py:54-58)
+
     def inference(self, image):
         self._forward(image)
-        return (self.model.mask() > 0).astype(np.float32)[..., None]  # 0/1 floats (domain_seg_infer.py:54-58)
+        return self._post()
 
 
 class EgoLanesNetworkInfer(_NetworkInfer):
     _kind = "egolanes"
+
+    def _post(self):
+        return self.model.logits()
 
     def inference(self, image):
         return self._forward(image, check_size=False)  # ego_lanes_infer.py:50-62 has no size check
@@ -82,8 +110,9 @@ class EgoLanesNetworkInfer(_NetworkInfer):
 
 class AutoDriveInfer:
     """Models/model_components/autodrive/autodrive_network.py:15-36 behind the engine: ``forward(prev, curr)`` on two
-    HxWx3 uint8 frames (any size; the engine does the visualisation script's preprocess -- bilinear resize to
-    1024x512, RGB planes, ImageNet normalisation, video_visualization.py:29-33) -> (d_norm, curvature, flag_logit);
+    HxWx3 uint8 frames (any size; the engine does the visualisation script's preprocess -- PIL's antialiased
+    Image.resize((1024, 512), Image.BILINEAR), bit-exact against Pillow, RGB planes, to_tensor + ImageNet normalisation,
+    video_visualization.py:29-33) -> (d_norm, curvature, flag_logit);
     ``step(frame)`` is the streaming form (pairs each frame with the previous one).  ``frames_are_bgr`` matches
     OpenCV captures.  ``weights_fp8`` selects the per-channel e4m3 weight format of BASELINE configs[4]."""
 

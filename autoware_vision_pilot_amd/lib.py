@@ -44,6 +44,9 @@ _SIGS = {
     "vp_set_input_format": (C.c_int, [_P, C.c_int, C.c_int]),
     "vp_set_decode_mode": (C.c_int, [_P, C.c_int]),
     "vp_get_decode_mode": (C.c_int, [_P]),
+    "vp_set_resize_mode": (C.c_int, [_P, C.c_int]),
+    "vp_get_resize_mode": (C.c_int, [_P]),
+    "vp_resample_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "vp_gpu_id": (C.c_int, [_P]),
     "vp_host_logits_current": (C.c_int, [_P]),
     "vp_input_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -101,6 +104,7 @@ _COMM_SIGS = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGS) + tuple(_COMM_SIGS)
 VP_OUT_LOGITS, VP_OUT_MASK = 1, 2
+VP_RESIZE_CV_LINEAR, VP_RESIZE_PIL_BILINEAR, VP_RESIZE_PIL_BICUBIC = 0, 1, 2
 VP_GATHER_MASK, VP_GATHER_LOGITS = 0, 1
 VP_COMM_ID_BYTES = 128
 
@@ -215,6 +219,13 @@ class Engine:
 
     def set_decode_mode(self, mode):
         self._ck(self._lib.vp_set_decode_mode(self._h, mode))
+
+    def set_resize_mode(self, mode):
+        """VP_RESIZE_CV_LINEAR (the C++ nodes' cv::resize model), VP_RESIZE_PIL_BILINEAR / _BICUBIC (the Python scripts' Image.resize)."""
+        self._ck(self._lib.vp_set_resize_mode(self._h, mode))
+
+    def resize_mode(self):
+        return self._lib.vp_get_resize_mode(self._h)
 
     def input_hw(self):
         h, w = C.c_int(), C.c_int()
@@ -516,3 +527,14 @@ def op_conv2d_repeat(xs, weight, bias, ks=3, act=0, precision=VP_FP16, tile=-1, 
     if rc != 0:
         raise VpError(f"vp_op_conv2d_repeat failed ({rc}): {err.value.decode(errors='replace')}")
     return out
+
+
+def resample_coeffs(in_size, out_size, mode):
+    """vp_resample_coeffs: (bounds [out][2], coefficients [out][ksize]) of a VP_RESIZE_PIL_* mode for one axis (host only)."""
+    cap = out_size * (2 * int(np.ceil(2.0 * max(1.0, in_size / out_size))) + 1)
+    b = np.zeros((out_size, 2), dtype=np.int32)
+    k = np.zeros(cap, dtype=np.int32)
+    ks = load().vp_resample_coeffs(in_size, out_size, mode, _ptr(b), _ptr(k), cap)
+    if ks <= 0:
+        raise VpError(f"vp_resample_coeffs failed ({ks})")
+    return b, k[: out_size * ks].reshape(out_size, ks)

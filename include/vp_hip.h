@@ -130,6 +130,17 @@ int vp_upload_frame_n(vp_engine* e, int index, const uint8_t* frame, int h, int 
 /* ---- configuration ------------------------------------------------------------------------------------- */
 int vp_set_input_format(vp_engine* e, int pixel_format, int plane_order);
 int vp_set_decode_mode(vp_engine* e, int decode_mode);
+/* How a frame of another size reaches the network's input size.  VP_RESIZE_CV_LINEAR (default of the scene networks): the integer
+ * bilinear modelled on cv::resize INTER_LINEAR, what the C++ nodes do (onnx_runtime_backend.cpp:44).  VP_RESIZE_PIL_BILINEAR
+ * (default of VP_AUTODRIVE) / VP_RESIZE_PIL_BICUBIC: Pillow's antialiased Image.resize, bit-exact against Pillow 12.2 -- the
+ * Python scripts' frame path (Models/visualizations/AutoDrive/video_visualization.py:29-33 BILINEAR; the scene networks'
+ * visualisation scripts call Image.resize((640, 320)) with Pillow's default filter, BICUBIC).  VP_ERR_ARG on a shared engine. */
+enum vp_resize_mode { VP_RESIZE_CV_LINEAR = 0, VP_RESIZE_PIL_BILINEAR = 1, VP_RESIZE_PIL_BICUBIC = 2 };
+int vp_set_resize_mode(vp_engine* e, int resize_mode);
+int vp_get_resize_mode(const vp_engine* e);
+/* host only: one axis' tap tables of the VP_RESIZE_PIL_* modes -- bounds[out][2] = {first source index, taps}, coeffs[out][ksize] with
+ * 22 fractional bits; returns ksize (> 0) or VP_ERR_ARG (coeffs_cap < out_size * ksize ints).  For tests / external checks. */
+int vp_resample_coeffs(int in_size, int out_size, int resize_mode, int* bounds, int* coeffs, int coeffs_cap);
 int vp_get_decode_mode(const vp_engine* e);      /* the vp_decode_mode in force (>= 0), or VP_ERR_ARG */
 int vp_gpu_id(const vp_engine* e);               /* the device the engine lives on */
 int vp_host_logits_current(const vp_engine* e);  /* 1 = the host pointer vp_logits() hands out holds the LAST pass's logits */

@@ -26,12 +26,31 @@ FRAME_SEEDS = (20, 21)
 GOLDEN = os.path.join(ROOT, "tests", "golden", "autodrive.npz")
 
 
+def reference_preprocess(frame_bgr):
+    """Models/visualizations/AutoDrive/video_visualization.py:29-33 with the SAME library calls where they exist here: BGR -> RGB,
+    PIL Image.resize((1024, 512), Image.BILINEAR) (Pillow itself), torchvision's to_tensor (u8 -> fp32 / 255, HWC -> CHW) and
+    normalize ((t - mean) / std, fp32) spelled out in torch (torchvision and cv2 are not installed; both steps are one-liners
+    in torchvision/transforms/_functional_tensor.py)."""
+    from PIL import Image
+
+    rgb = np.ascontiguousarray(frame_bgr[..., ::-1])
+    pil = Image.fromarray(rgb).resize((autodrive.NET_W, autodrive.NET_H), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).to(torch.float32).div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32).view(3, 1, 1)
+    return t.sub(mean).div(std)[None].numpy()
+
+
 def frames():
-    """Two synthetic 1080p BGR frames -> network inputs 1x3x512x1024 (our integer bilinear, RGB planes, ImageNet norm)."""
+    """Two synthetic 1080p BGR frames -> network inputs 1x3x512x1024 by the reference's own frame path (PIL's antialiased BILINEAR);
+    the oracle's restatement of that path (pre_post.preprocess(resize="pil_bilinear")) must reproduce it bit for bit."""
     out = []
     for s in FRAME_SEEDS:
         f = pre_post.synthetic_frame(1080, 1920, s)
-        out.append(pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=autodrive.NET_H, out_w=autodrive.NET_W))
+        x = reference_preprocess(f)
+        mine = pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=autodrive.NET_H, out_w=autodrive.NET_W, resize="pil_bilinear")
+        assert np.array_equal(x, mine), "oracle frame path != PIL + to_tensor + normalize"
+        out.append(x)
     return out
 
 

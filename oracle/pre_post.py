@@ -68,6 +68,79 @@ def resize_bilinear_u8(img, out_h=NET_H, out_w=NET_W):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
+# ---------------------------------------------------------------------- Pillow's antialiased resample
+# Image.resize(size, Image.BILINEAR) -- Models/visualizations/AutoDrive/video_visualization.py:29-33 (the AutoDrive frame path; also
+# image_visualization.py:30) -- and Image.resize(size) with Pillow's default filter (BICUBIC) in the scene networks' visualisation
+# scripts (Models/visualizations/Scene3D/video_visualization.py:87, DomainSeg/video_visualization.py:112).  Pillow is a third-party
+# dependency of the reference (requirements: pillow, unpinned); it IS installed here (12.2.0), so this restatement of its
+# src/libImaging/Resample.c (precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc) is PINNED
+# bit for bit against PIL itself (tests/test_oracle_golden.py::test_pil_resample_is_pillows).  The filter support scales with the
+# down-scaling factor (that is the antialiasing), coefficients are normalised in double and quantised to 22 fractional bits, each
+# pass accumulates in int32 from 1 << 21 and clips through `>> 22` to u8: the horizontal pass writes a u8 image, the vertical pass
+# reads it (two roundings).
+PIL_PRECISION_BITS = 32 - 8 - 2
+PIL_BILINEAR, PIL_BICUBIC = 2, 3          # PIL.Image.Resampling values
+
+
+def _pil_filter(x, which):
+    x = np.abs(x)
+    if which == PIL_BILINEAR:
+        return np.where(x < 1.0, 1.0 - x, 0.0)
+    a = -0.5
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+
+
+def pil_resample_coeffs(in_size, out_size, which=PIL_BILINEAR):
+    """-> (bounds [out][2] = first source index, tap count; coefficients [out][ksize] int32 with 22 fractional bits)."""
+    support0 = 1.0 if which == PIL_BILINEAR else 2.0
+    scale = filterscale = np.float64(in_size) / np.float64(out_size)
+    if filterscale < 1.0:
+        filterscale = np.float64(1.0)
+    support = support0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = np.float64(1.0) / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = _pil_filter((np.arange(xmax, dtype=np.float64) + xmin - center + 0.5) * ss, which)
+        ww = np.float64(0.0)
+        for v in w:          # Pillow sums in tap order
+            ww += v
+        if ww != 0.0:
+            w = w / ww
+        q = np.where(w < 0, (-0.5 + w * (1 << PIL_PRECISION_BITS)).astype(np.int64), (0.5 + w * (1 << PIL_PRECISION_BITS)).astype(np.int64))
+        kk[xx, :xmax] = q
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _pil_pass(img, bounds, kk, axis):
+    """one 8-bit pass along `axis` of an HxWxC u8 image"""
+    src = np.moveaxis(img.astype(np.int32), axis, 0)
+    out = np.empty((len(bounds),) + src.shape[1:], dtype=np.uint8)
+    for i, (lo, n) in enumerate(bounds):
+        acc = np.full(src.shape[1:], 1 << (PIL_PRECISION_BITS - 1), dtype=np.int32)
+        for t in range(n):
+            acc = acc + src[lo + t] * kk[i, t]
+        out[i] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def resize_pil_u8(img, out_h, out_w, which=PIL_BILINEAR):
+    """HxWxC uint8 -> out_h x out_w x C uint8, Pillow's Image.resize((out_w, out_h), which): horizontal pass, then vertical;
+    a pass whose size does not change is skipped (ImagingResample: need_horizontal / need_vertical)."""
+    img = np.ascontiguousarray(img)
+    h, w, _ = img.shape
+    if w != out_w:
+        img = _pil_pass(img, *pil_resample_coeffs(w, out_w, which), axis=1)
+    if h != out_h:
+        img = _pil_pass(img, *pil_resample_coeffs(h, out_h, which), axis=0)
+    return img
+
+
 def normalize_planes(img_u8, input_is_bgr, planes_rgb):
     """uint8 HxWx3 -> fp32 3xHxW.  ``planes_rgb`` False gives B,G,R plane order (middleware 'common'
     backends), True gives R,G,B (EgoLanes engine, Python).  Constants always follow the plane's colour."""
@@ -78,9 +151,15 @@ def normalize_planes(img_u8, input_is_bgr, planes_rgb):
     return np.ascontiguousarray(out.transpose(2, 0, 1)).astype(np.float32)
 
 
-def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False, out_h=NET_H, out_w=NET_W):
-    """Any-size u8 frame -> 1x3xout_hxout_w fp32 network input (320x640 for the scene networks, 512x1024 for AutoDrive)."""
-    return normalize_planes(resize_bilinear_u8(frame_u8, out_h, out_w), input_is_bgr, planes_rgb)[None]
+def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False, out_h=NET_H, out_w=NET_W, resize="cv"):
+    """Any-size u8 frame -> 1x3xout_hxout_w fp32 network input (320x640 for the scene networks, 512x1024 for AutoDrive).
+    resize: "cv" = the integer bilinear above (the C++ nodes' cv::resize), "pil_bilinear" / "pil_bicubic" = Pillow's antialiased
+    resample (the Python scripts' Image.resize: AutoDrive's BILINEAR, the scene visualisations' default BICUBIC)."""
+    if resize == "cv":
+        small = resize_bilinear_u8(frame_u8, out_h, out_w)
+    else:
+        small = resize_pil_u8(frame_u8, out_h, out_w, {"pil_bilinear": PIL_BILINEAR, "pil_bicubic": PIL_BICUBIC}[resize])
+    return normalize_planes(small, input_is_bgr, planes_rgb)[None]
 
 
 # ------------------------------------------------------------------------------------------ decode

@@ -51,6 +51,14 @@ int emu_preprocess(const uint8_t* frame, int stride, const int* xtab, const int*
   for (int c = 0; c < 3; ++c) { p.src_c[c] = src_c[c]; p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
   return launch_preprocess(p, nullptr);
 }
+int emu_pil_resample(const uint8_t* frame, int stride, int in_h, int in_w, int out_h, int out_w, const int* hb, const int* hk, int hks, const int* vb,
+                     const int* vk, int vks, uint8_t* tmp, const int* src_c, const float* mean3, const float* std3, float* out) {
+  PilResampleParams p{};
+  p.frame = frame; p.stride = stride; p.in_h = in_h; p.in_w = in_w; p.out_h = out_h; p.out_w = out_w; p.hb = hb; p.hk = hk; p.hks = hks;
+  p.vb = vb; p.vk = vk; p.vks = vks; p.tmp = tmp; p.out = out;
+  for (int c = 0; c < 3; ++c) { p.src_c[c] = src_c[c]; p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
+  return launch_pil_resample(p, nullptr);
+}
 int emu_decode_mask(const float* logits, int C, int HW, int mode, uint8_t* out) { return launch_decode_mask(logits, C, HW, mode, out, nullptr); }
 int emu_resize_nearest(const uint8_t* src, int sw, const int* ytab, const int* xtab, int oh, int ow, uint8_t* dst) {
   return launch_resize_nearest(src, sw, ytab, xtab, oh, ow, dst, nullptr);

@@ -112,6 +112,8 @@ def test_x3_stream_k(emu_lib):
     for slots in (8, 16, 24, 64):
         _case(emu_lib, 96, 256, 19, 21, 3, 0, 1, 0, 1, [(109, -1, slots)], seed=41)
     _case(emu_lib, 160, 128, 24, 48, 3, 0, 0, 0, 1, [(109, -1, 8), (109, -1, 40), (109, -1, 56)], seed=42)   # 9 tiles x 5 chunks: groups of 2 and 1 tiles
+    # shape 10: the same deal over the 8-wave shape's 16x16 tiles (double-buffered halo, 128 KiB slabs)
+    _case(emu_lib, 96, 256, 33, 40, 3, 0, 1, 0, 1, [(110, -1, 8), (110, -1, 16), (110, -1, 24), (110, -1, 64)], seed=44)    # 3 x 3 x 2 = 18 tiles x 3 chunks
     rng = np.random.default_rng(43)
     x = rng.standard_normal((64, 18, 33), dtype=np.float32)
     wt = rng.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.float32(0.06)

@@ -43,7 +43,7 @@ def test_autodrive_engine_end_to_end_on_cpu(emu_lib):
         eng.infer_pair(frames[0], frames[1])                     # eager pass + graph capture
         got = eng.logits().reshape(3)
         assert np.abs(got - g["fp32_out"]).max() <= 1e-3, (got, g["fp32_out"])      # the GPU parity bar (measured 2.5e-6)
-        want_in = pre_post.preprocess(frames[1], input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024)
+        want_in = pre_post.preprocess(frames[1], input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize="pil_bilinear")   # the reference's frame path: PIL's antialiased BILINEAR
         assert np.array_equal(eng.input_tensor(), want_in)
         p5 = None
         for i, (n, c, h, w) in enumerate(eng.tensors()):

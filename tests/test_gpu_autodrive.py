@@ -33,15 +33,26 @@ def _tensor(eng, name):
 
 
 def test_preprocess_1024x512_bit_exact(setup):
-    from autoware_vision_pilot_amd import lib
+    """The AutoDrive frame path is the reference's (video_visualization.py:29-33): PIL's antialiased BILINEAR to 1024x512, to_tensor,
+    normalize -- bit-exact against the oracle's restatement, which the CPU suite pins against Pillow itself; 1920x1080 (a 1.875x /
+    2.11x down-scale: 5 / 7 taps per pass), two odd sizes (up-scaling along one axis; a pass that is skipped), and the other two
+    resize modes behind vp_set_resize_mode."""
+    from autoware_vision_pilot_amd import lib, synthetic
 
     _, frames, _, blob = setup
     eng = lib.Engine("autodrive", blob, precision="fp16")
     try:
         assert eng.input_hw() == (512, 1024)
-        eng.infer(frames[1])
-        want = pre_post.preprocess(frames[1], input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024)
-        assert np.array_equal(eng.input_tensor(), want)
+        assert eng.resize_mode() == lib.VP_RESIZE_PIL_BILINEAR
+        for f in (frames[1], synthetic.synthetic_frame(487, 651, 3), synthetic.synthetic_frame(512, 1300, 4), synthetic.synthetic_frame(2160, 3840, 5)):
+            eng.infer(f)
+            want = pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize="pil_bilinear")
+            assert np.array_equal(eng.input_tensor(), want), f.shape
+        for mode, name in ((lib.VP_RESIZE_PIL_BICUBIC, "pil_bicubic"), (lib.VP_RESIZE_CV_LINEAR, "cv"), (lib.VP_RESIZE_PIL_BILINEAR, "pil_bilinear")):
+            eng.set_resize_mode(mode)
+            eng.infer(frames[0])
+            want = pre_post.preprocess(frames[0], input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize=name)
+            assert np.array_equal(eng.input_tensor(), want), name
     finally:
         eng.close()
 
@@ -53,7 +64,7 @@ def test_autodrive_parity_fp16x3(setup, fp8):
     g, frames, sd, blob = setup
     tag = "fp8" if fp8 else "fp32"
     sdt = {k: torch.from_numpy(v) for k, v in (autodrive.quantize_fp8_e4m3(sd) if fp8 else sd).items()}
-    xs = [torch.from_numpy(pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024)) for f in frames]
+    xs = [torch.from_numpy(pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize="pil_bilinear")) for f in frames]
     with torch.no_grad():
         p5, inter = autodrive.backbone(sdt, xs[1], return_intermediates=True)
         ref = np.array([float(v) for v in autodrive.forward(sdt, xs[0], xs[1])], dtype=np.float32)

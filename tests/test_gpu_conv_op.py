@@ -113,11 +113,12 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
             lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=tile, nsplit=1)
     # stream-K (shape 9): slot counts from "whole tiles only" to the engine's own 2 x #CU (most slots cut a tile or stay empty at these
     # sizes); only the fp32 summation order of a cut tile differs from the tile-per-workgroup kernel; deterministic
-    for slots in (8, 48, 136, -1):
-        sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=109, nsplit=slots)
-        assert (np.abs(sk - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5, slots
-        assert np.abs(sk - got).max() <= 4e-6 * max(1.0, np.abs(got).max()), slots
-        assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=109, nsplit=slots)), slots
+    for tile in (109, 110):     # the 4-wave shape on two slots per CU, the 8-wave shape on one
+        for slots in (8, 48, 136, -1):
+            sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=tile, nsplit=slots)
+            assert (np.abs(sk - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5, (tile, slots)
+            assert np.abs(sk - got).max() <= 4e-6 * max(1.0, np.abs(got).max()), (tile, slots)
+            assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=tile, nsplit=slots)), (tile, slots)
 
 
 def test_stream_k_hand_off_at_layer_size():
@@ -134,11 +135,12 @@ def test_stream_k_hand_off_at_layer_size():
     b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
     xs = [rng.standard_normal((cin, 80, 160), dtype=np.float32) * np.float32(s) for s in (1.0, 0.3, 2.0)]
     refs = [lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1) for x in xs]
-    got = lib.op_conv2d_repeat(xs, wt, b, ks=3, act=1, precision=1, tile=109, rounds=4)
-    for r, outs in enumerate(got):
-        for i, (o, ref) in enumerate(zip(outs, refs)):
-            assert np.abs(o - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max()), (r, i)
-            assert np.array_equal(o, got[0][i]), (r, i)
+    for tile in (109, 110):
+        got = lib.op_conv2d_repeat(xs, wt, b, ks=3, act=1, precision=1, tile=tile, rounds=4)
+        for r, outs in enumerate(got):
+            for i, (o, ref) in enumerate(zip(outs, refs)):
+                assert np.abs(o - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max()), (tile, r, i)
+                assert np.array_equal(o, got[0][i]), (tile, r, i)
 
 
 def test_conv_op_transpose_detecting():

@@ -66,6 +66,38 @@ def test_preprocess_kernel_bit_exact(emu, shape, bgr, planes_rgb):
     assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize("shape,out,which,bgr", [((45, 80), (32, 64), "pil_bilinear", True), ((70, 131), (32, 64), "pil_bicubic", False),
+                                                 ((20, 64), (32, 64), "pil_bilinear", False), ((33, 41), (48, 72), "pil_bicubic", True)])
+def test_pil_resample_kernels_bit_exact(emu, shape, out, which, bgr):
+    """Pillow's antialiased resample (kernels_misc.hip pil_resample_h / _v kernels; the AutoDrive frame path) against the oracle's
+    restatement, which test_oracle_golden pins against PIL itself: down-scaling with 5- to 9-tap supports, up-scaling, a pass
+    whose size does not change (identity taps), both filters; the tables come from the LIBRARY's host code (vp_resample_coeffs),
+    checked against the oracle's here too."""
+    oh, ow = out
+    frame = pre_post.synthetic_frame(shape[0], shape[1], 5, smooth=False)
+    mode = {"pil_bilinear": 1, "pil_bicubic": 2}[which]
+    tabs = []
+    for n_in, n_out in ((shape[1], ow), (shape[0], oh)):
+        bo, ko = pre_post.pil_resample_coeffs(n_in, n_out, pre_post.PIL_BILINEAR if mode == 1 else pre_post.PIL_BICUBIC)
+        b = np.zeros((n_out, 2), np.int32)
+        k = np.zeros(n_out * ko.shape[1], np.int32)
+        emu.vp_resample_coeffs.restype = ct.c_int
+        assert emu.vp_resample_coeffs(n_in, n_out, mode, ptr(b), ptr(k), k.size) == ko.shape[1]
+        assert np.array_equal(b, bo) and np.array_equal(k.reshape(ko.shape), ko)
+        tabs.append((b, k, ko.shape[1]))
+    want = pre_post.preprocess(frame, input_is_bgr=bgr, planes_rgb=True, out_h=oh, out_w=ow, resize=which)[0]
+    src_c, mean, std = np.zeros(3, np.int32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+    for c in range(3):
+        src_c[c] = (2 - c) if bgr else c
+        mean[c], std[c] = pre_post.MEAN_RGB[c], pre_post.STD_RGB[c]
+    tmp = np.zeros((shape[0], ow, 3), np.uint8)
+    got = np.empty((3, oh, ow), dtype=np.float32)
+    (hb, hk, hks), (vb, vk, vks) = tabs
+    assert emu.emu_pil_resample(ptr(frame), frame.strides[0], shape[0], shape[1], oh, ow, ptr(hb), ptr(hk), hks, ptr(vb), ptr(vk), vks, ptr(tmp),
+                                ptr(src_c), ptr(mean), ptr(std), ptr(got)) == 0
+    assert np.array_equal(got, want)
+
+
 def test_decode_kernels_bit_exact(emu):
     rng = np.random.default_rng(0)
     logits = rng.standard_normal((3, 20, 30)).astype(np.float32)

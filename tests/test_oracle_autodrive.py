@@ -15,7 +15,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "autodrive.npz")
 def inputs():
     g = np.load(GOLDEN)
     xs = [torch.from_numpy(pre_post.preprocess(pre_post.synthetic_frame(1080, 1920, int(s)), input_is_bgr=True, planes_rgb=True,
-                                               out_h=autodrive.NET_H, out_w=autodrive.NET_W)) for s in g["frame_seeds"]]
+                                               out_h=autodrive.NET_H, out_w=autodrive.NET_W, resize="pil_bilinear")) for s in g["frame_seeds"]]
     return g, xs
 
 

@@ -171,3 +171,25 @@ def test_exact_2x_downscale_is_the_box_average():
     s = img.astype(np.int32)
     box = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
     assert np.array_equal(got, box.astype(np.uint8))
+
+
+def test_pil_resample_is_pillows():
+    """oracle/pre_post.py resize_pil_u8 (the AutoDrive frame path, Models/visualizations/AutoDrive/video_visualization.py:29-33, and
+    the scene visualisations' default-filter Image.resize) against PIL ITSELF, bit for bit: the headline 1920x1080 -> 1024x512,
+    odd sizes, up-scaling along one or both axes, a pass that is skipped, both filters -- and the fp32 planes against PIL +
+    to_tensor + normalize spelled out in torch."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(12)
+    cases = [((1080, 1920), (512, 1024)), ((487, 651), (512, 1024)), ((720, 1280), (320, 640)), ((33, 47), (64, 90)), ((512, 1024), (512, 1024)),
+             ((320, 700), (320, 640)), ((1081, 641), (320, 640)), ((2, 3), (320, 640))]
+    for (h, w), (oh, ow) in cases:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for which, pilf in ((pre_post.PIL_BILINEAR, Image.BILINEAR), (pre_post.PIL_BICUBIC, Image.BICUBIC)):
+            ref = np.asarray(Image.fromarray(img).resize((ow, oh), pilf))
+            assert np.array_equal(pre_post.resize_pil_u8(img, oh, ow, which), ref), ((h, w), (oh, ow), which)
+    frame = pre_post.synthetic_frame(1080, 1920, 20)           # BGR
+    pil = Image.fromarray(np.ascontiguousarray(frame[..., ::-1])).resize((1024, 512), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).to(torch.float32).div(255)
+    t = t.sub(torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)).div(torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1))
+    mine = pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize="pil_bilinear")
+    assert np.array_equal(mine[0], t.numpy())

@@ -8,7 +8,7 @@ from oracle import autodrive, pre_post
 frames = [pre_post.synthetic_frame(1080, 1920, s) for s in (20, 21)]
 sd = autodrive.make_state_dict(5)
 sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
-xs = [torch.from_numpy(pre_post.preprocess(f, True, True, 512, 1024)) for f in frames]
+xs = [torch.from_numpy(pre_post.preprocess(f, True, True, 512, 1024, resize="pil_bilinear")) for f in frames]
 with torch.no_grad():
     fp, fc = autodrive.backbone(sdt, xs[0]), autodrive.backbone(sdt, xs[1])
     x = torch.cat([fp, fc], 1)
