@@ -264,6 +264,10 @@ int vp_resample_coeffs(int in_size, int out_size, int resize_mode, int* bounds, 
   return ksize;
 }
 int vp_get_resize_mode(const vp_engine* e) { return (e && e->impl) ? e->impl->resize_mode() : VP_ERR_ARG; }
+int vp_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 int vp_get_decode_mode(const vp_engine* e) { return (e && e->impl) ? e->impl->decode_mode() : VP_ERR_ARG; }
 int vp_gpu_id(const vp_engine* e) { return (e && e->impl) ? e->impl->gpu() : VP_ERR_ARG; }
 int vp_host_logits_current(const vp_engine* e) { return (e && e->impl) ? (e->impl->host_logits_current() ? 1 : 0) : VP_ERR_ARG; }

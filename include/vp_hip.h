@@ -143,6 +143,7 @@ int vp_get_resize_mode(const vp_engine* e);
 int vp_resample_coeffs(int in_size, int out_size, int resize_mode, int* bounds, int* coeffs, int coeffs_cap);
 int vp_get_decode_mode(const vp_engine* e);      /* the vp_decode_mode in force (>= 0), or VP_ERR_ARG */
 int vp_gpu_id(const vp_engine* e);               /* the device the engine lives on */
+int vp_device_count(void);                       /* GPUs visible to this process (0 = none): a thread-per-GPU host sizes its world with it */
 int vp_host_logits_current(const vp_engine* e);  /* 1 = the host pointer vp_logits() hands out holds the LAST pass's logits */
 int vp_input_hw(const vp_engine* e, int* h, int* w);
 

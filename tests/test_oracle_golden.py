@@ -193,3 +193,20 @@ def test_pil_resample_is_pillows():
     t = t.sub(torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)).div(torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1))
     mine = pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize="pil_bilinear")
     assert np.array_equal(mine[0], t.numpy())
+
+
+def test_metric_configuration_against_golden():
+    """BASELINE.json's metric configuration -- SceneSeg + Scene3D on one frame, Scene3D on SceneSeg's encoder (scene_3d_network.py:9-13)
+    -- against the fixture the REFERENCE's DepthContext / Scene3DNeck / Scene3DHead modules produced on SceneSeg's taps
+    (oracle/pin_against_reference.py section 5).  SceneSeg's half is full_sceneseg.npz (test_full_network_against_golden)."""
+    from autoware_vision_pilot_amd import synthetic
+
+    g = np.load(os.path.join(GOLDEN, "metric_scene3d_on_sceneseg.npz"))
+    seed_seg, seed_3d = (int(v) for v in g["weight_seeds"])
+    sd3 = synthetic.share_backbone(weights.make_state_dict("scene3d", seed_3d), "scene3d", weights.make_state_dict("sceneseg", seed_seg), "sceneseg")
+    frame = pre_post.synthetic_frame(720, 1280, int(g["frame_seed"]))
+    x = torch.from_numpy(pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=False))
+    out = nets.forward("scene3d", nets.to_torch(sd3), x)[0].numpy()
+    assert tuple(out.shape) == tuple(g["shape"])
+    assert _close(out.ravel()[g["samples_idx"]], g["samples"], tol=2e-4)
+    assert _close(out[0, ::8, ::8], g["depth_ds8"], tol=2e-4)
