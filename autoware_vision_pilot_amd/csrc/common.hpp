@@ -69,10 +69,6 @@ struct ConvGemmParams {
   int decode_mode;
   // >= 16 bytes of zeros in device memory (the engine's zero page): LDS-DMA source for pixels outside the map (kernels_conv3x3_x3.hip)
   const half_t* zeros;
-  // stream-K (kernels_conv3x3_x3.hip shape 9): sk_slots persistent workgroups (a multiple of 8); `partial` holds one 64 KiB fp32 slab per
-  // slot; sk_flags = [sk_slots] hand-off flags + one time-out word, all zero between launches
-  unsigned* sk_flags;
-  int sk_slots;
 };
 
 // nn.GELU() (exact erf form, scene_neck.py:8).  ~300 M activations per frame: libm's erff (~45 VALU ops, branchy)

@@ -256,20 +256,6 @@ const void* Engine::zero_page() {
   return d_zero_;
 }
 
-// stream-K workspace (kernels_conv3x3_x3.hip shape 9): two persistent workgroups per CU
-int Engine::streamk_slots() const {
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gpu_) != hipSuccess || cus < 8) cus = 256;
-  return 2 * cus / 8 * 8;
-}
-void Engine::ensure_streamk_ws(int slots) {
-  if (slots <= sk_cap_) return;
-  if (sk_cap_ != 0) throw std::runtime_error("stream-K workspace: allocated for fewer slots");  // ops already captured its pointers
-  sk_slabs_ = static_cast<float*>(dalloc((size_t)slots * conv3x3_sk_slab_bytes(), false));
-  sk_flags_ = static_cast<unsigned*>(dalloc((size_t)(slots + 1) * sizeof(unsigned), true));
-  sk_cap_ = slots;
-}
-
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
@@ -314,17 +300,8 @@ void Engine::upload_act(Act* a, const float* chw) {
 void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc) {
   auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
   int tile;
-  // small 1x1 GEMMs (the encoder's expand / project / top convolutions): the LDS-free pointwise kernel (kernels_pw.hip)
-  static const char* env_pw = std::getenv("VP_PW");
-  const bool pw_ok = ks == 1 && o.stride <= 1 && !o.in2 && !o.logits_out && !o.pixel_shuffle && o.post_act == ACT_NONE &&
-                     (o.res_mode == RES_NONE || o.res_mode == RES_ADD) && (o.act == ACT_NONE || o.act == ACT_SILU) && o.nsplit <= 1;
   if (o.tile >= 0) {
     tile = o.tile;
-  } else if (pw_ok && env_pw && env_pw[0] == '1' && 2.0 * M * ncols * cin_pad < 0.6e9) {
-    // OPT-IN only (VP_PW=1).  Measured on MI355X (round 2): the 32 encoder GEMMs take 662 us (fp16x3) / 390 us (fp16) through it
-    // against 474 / 330 us through the LDS-pipelined kernel: a fragment load touches 64 different rows (16 B each), which the
-    // texture path serialises, and the long-K projections (K = 1152 on 200 pixels) leave 24 waves on the whole GPU walking K alone
-    tile = 4;
   } else if (ncols <= 32) {
     tile = 3;
   } else if (ncols % 128 == 0 && (cdiv(M, 128) * (ncols / 128) >= 192 || (M <= 256 && ncols >= 2048))) {
@@ -356,7 +333,6 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
     if (min_steps > 0 && S >= 2 * min_steps) ns = std::max(1, std::min<int>(S / min_steps, (int)cdiv(128, blocks)));
   }
   pc->nsplit = std::min(ns, std::max(1, S));
-  if (tile == 4) pc->nsplit = 1;
 }
 
 void Engine::push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
@@ -404,12 +380,6 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   }
   const int M = p.H * p.W;
   p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
-  if (pc.tile == 109 || pc.tile == 110) {  // stream-K: one slab + flag per slot, shared by this engine's layers (they are serialised on its stream)
-    ensure_streamk_ws(std::max(pc.sk_slots, streamk_slots()));
-    p.partial = sk_slabs_;
-    p.sk_flags = sk_flags_;
-    p.sk_slots = pc.sk_slots;
-  }
   const int tile = pc.tile, bk = pc.bk;
   const bool sp = split();
   Op op;
@@ -422,11 +392,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     op.flops += 2.0 * M * 4.0 * cout_real * o.in2->Creal;
     op.bytes += esz * ((double)M * 4.0 * o.in2->Creal + (double)cout_real * o.in2->Creal);
   }
-  if (tile >= 200) {
-    const int shape = tile - 200;
-    op.kernel = std::string("conv3x3_region<") + (shape == 0 ? "10x40" : "16x32") + ",co" + std::to_string(region_co(shape, pc.CoutW)) + ">" + (pc.nsplit > 1 ? "+splitk" : "");
-    op.run = [p, shape, sp](hipStream_t st) { return launch_conv3x3_region(p, shape, sp, st); };
-  } else if (tile >= 100) {
+  if (tile >= 100) {
     int ht = tile - 100;
     // ---- optional per-layer tile autotune (VP_AUTOTUNE=1 enables; measured +-1 % on the frames-in-flight bench, so
     // the static heuristic is the default): time the tile shapes that share this weight packing and keep the fastest.  The K order per output is identical for every tile, so the choice never changes a result bit.
@@ -466,9 +432,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[2]);
       ht = best_c;
     }
-    if (ht >= 6 && ht <= 10) {
-      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 9 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
-      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : (ht == 8 ? "conv3x3_x3w4<co64,px128>" : (ht == 9 ? "conv3x3_x3sk<co128,px128>" : "conv3x3_x3sk8<co128,px256>")))) + (pc.nsplit > 1 ? "+splitk" : "");
+    if (ht >= 6 && ht <= 8) {
+      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
+      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -500,10 +466,6 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     } else {
       op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
     }
-  } else if (tile == 4) {
-    if (!pw_gemm_supported(p)) throw std::invalid_argument("pointwise kernel (tile 4): 1x1, stride 1, bias + {none, SiLU} + optional residual add, NHWC: " + name);
-    op.kernel = std::string("pw_gemm<") + (sp ? "x3>" : "x1>");
-    op.run = [p, sp](hipStream_t st) { return launch_pw_gemm(p, sp, st); };
   } else if (tile == 6) {  // its weights are packed in its own layout (add_convT*): no other kernel may take this launch
     if (!gemm_dma_supported(p, sp))
       throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
@@ -549,9 +511,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   if (ks == 3 && cstride == 1 && in->H >= 8 && in->W >= 16) {
     static const char* env = std::getenv("VP_CONV3X3");
     const bool force_v1 = (env && std::strcmp(env, "v1") == 0) || (o.tile >= 0 && o.tile < 100);
-    if (o.tile >= 200) {
-      halo = -1;  // region kernel, selected below
-    } else if (o.tile >= 100) {
+    if (o.tile >= 100) {
       halo = o.tile - 100;
     } else if (!force_v1) {
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
@@ -589,57 +549,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         (void)wgs8;
       }
     }
-    // parity mode, stream-K (kernels_conv3x3_x3.hip shape 9, round 3): the 8x16 x 128-channel tiles' K loops dealt in equal chunk-step
-    // ranges to 2 x #CU persistent workgroups.  VP_STREAMK: 0 = never, 1 = the layers of shapes 6 / 7 (default), 2 = also every other
-    // plain 128-channel-tiled layer with at least two chunk steps per slot (decode_layer_5; the split-K layers of the small maps).
-    if (split() && o.tile < 0 && halo >= 0 && ncols % 128 == 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 &&
-        (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE) {
-      static const char* envsk = std::getenv("VP_STREAMK");
-      const int level = envsk ? std::atoi(envsk) : 0;
-      const long long steps = (long long)((in->H + 7) / 8) * ((in->W + 15) / 16) * (ncols / 128) * (cin_pad / 32);
-      if (level == 1 && (halo == 6 || halo == 7)) halo = 9;
-      else if (level == 2 && (halo == 1 || halo == 3 || halo == 6 || halo == 7) && steps >= 2LL * streamk_slots()) halo = 9;
-      else if (level == 3 && halo == 6) halo = 10;   // the 8-wave shape's layers on one 8-wave slot per CU
-    }
-    if (halo >= 6 && halo <= 10 && !split()) throw std::invalid_argument("halo tiles 6 - 9 are fp16x3 kernels: " + name);
+    if (halo >= 6 && halo <= 8 && !split()) throw std::invalid_argument("halo tiles 6 - 8 are fp16x3 kernels: " + name);
   }
-  // ---- small map + long K (neck layers at 20x40 / 40x80, AutoDrive head at 16x32): region kernel
-  // (kernels_conv3x3_region.hip; tile 200 + shape).  VP_FP16 engines only: the fp16x3 planes do not fit its LDS plan.
-  int region = -1;
-  if (o.tile >= 200 && (split() || ks != 3 || cstride != 1)) throw std::invalid_argument("region kernel: 3x3 stride 1, VP_FP16 only: " + name);
-  if (ks == 3 && cstride == 1 && !split() && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !o.logits_out) {
-    static const char* renv = std::getenv("VP_REGION");
-    if (o.tile >= 200) {
-      region = o.tile - 200;
-      if (region > 1 || !region_shape_fits(region, in->H, in->W)) throw std::invalid_argument("region kernel: map does not tile into regions: " + name);
-    } else if (o.tile < 0 && renv && renv[0] == '1' && cin_pad >= 256 && M <= 3200) {
-      // opt-in (VP_REGION=1): measured 161 -> 142 us on the four neck layers alone (single-stream latency -1 %), but its
-      // 117 KiB of LDS per workgroup keeps other streams' kernels off the CU: 1278 -> 1230 frames/s with 3 frames in
-      // flight.  These layers are bound by ~120 MB of L2 / Infinity-Cache traffic each (weights x regions + fp32 split-K
-      // partials written and re-read), whatever the tiling.
-      if (region_shape_fits(0, in->H, in->W)) region = 0;
-      else if (region_shape_fits(1, in->H, in->W)) region = 1;
-    }
-  }
-  if (region >= 0) {
-    halo = 0;  // same weight packing as the patch kernel: [cin/32][tap][CoutW][32]
-    pc.tile = 200 + region;
-    pc.bk = 32;
-    pc.CoutW = round_up(ncols, 32);
-    const int KC = cin_pad / 32;
-    const long long blocks = (long long)region_count(region, in->H, in->W) * (pc.CoutW / region_co(region, pc.CoutW));
-    // one workgroup per CU: split K until the machine is covered once, at least two chunks per slice, partials <= 24 MB
-    int ns = 1;
-    if (o.nsplit > 0) {
-      ns = o.nsplit;
-    } else {
-      ns = (int)std::max<long long>(1, 256 / std::max<long long>(1, blocks));
-      ns = std::min(ns, std::max(1, KC / 2));
-      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
-      while (ns > 1 && ns * slice_mb > 24.0) --ns;
-    }
-    pc.nsplit = std::max(1, std::min(ns, KC));
-  } else if (halo >= 0) {
+  if (halo >= 0) {
     pc.tile = 100 + halo;
     pc.bk = 32;
     pc.CoutW = round_up(ncols, halo_tile_co(halo));
@@ -677,11 +589,6 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
     if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
-    if (halo == 9 || halo == 10) {  // stream-K: the slots carry the K split (the operator entry passes a slot count as `nsplit`: small test grids)
-      pc.nsplit = 1;
-      pc.sk_slots = o.nsplit >= 8 ? o.nsplit / 8 * 8 : streamk_slots() / (halo == 10 ? 2 : 1) / 8 * 8;
-    }
-    if (halo == 7 && blocks >= 160 && o.nsplit <= 0) pc.nsplit = 1;
     // 64-channel tiles of the parity mode: the pipelined kernel's 64-channel shape (halo tile 8: same tiles, same split factor as
     // halo tile 3, three workgroups per CU).  Measured on MI355X (SceneSeg, us, halo tile 3 -> tile 8): decode_layer_0..3 70.5 /
     // 48.1 / 82.6 / 60.2 -> 77.9 / 54.6 / 90.2 / 65.6, decode_layer_5 98.6 -> 106.5, decode_layer_9 (128 -> 64 channels on
@@ -708,7 +615,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-        const int ci_sw = (halo >= 6 && halo <= 10) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
+        const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;

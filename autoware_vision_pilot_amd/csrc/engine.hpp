@@ -171,13 +171,10 @@ class Engine {
     half_t* w_lo = nullptr;
     float* bias = nullptr;
     int CoutW = 0, tile = 0, bk = 32, nsplit = 1;
-    int sk_slots = 0;  // stream-K (tile 109): persistent workgroups
   };
   void construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base);
   void release();  // frees every device / host resource; idempotent (destructor and failed construction)
   void* dalloc(size_t bytes, bool zero = true);
-  int streamk_slots() const;
-  void ensure_streamk_ws(int slots);
   const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)
   template <class T>
   T* dupload(const std::vector<T>& v);
@@ -249,11 +246,6 @@ class Engine {
   int h_frame_slot_ = 0;
   hipEvent_t h_frame_ev_[2] = {nullptr, nullptr};  // recorded behind the H2D that reads a slot; awaited before the slot is rewritten
   bool pinned_staging_ = true;
-
-  // stream-K slabs / flags (one set per engine)
-  float* sk_slabs_ = nullptr;
-  unsigned* sk_flags_ = nullptr;
-  int sk_cap_ = 0;
 
   // split-K scratch
   std::vector<float**> partial_slots_;

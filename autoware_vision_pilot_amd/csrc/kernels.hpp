@@ -111,29 +111,20 @@ struct FusionParams {
   int Creal_out;
 };
 
-// pointwise 1x1 for the small encoder GEMMs (kernels_pw.hip): fragments straight from global memory, no LDS operand path
-bool pw_gemm_supported(const ConvGemmParams& p);
-hipError_t launch_pw_gemm(const ConvGemmParams& p, bool split, hipStream_t st);
-// tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px, 4 = pointwise kernel (64co x 128px) ; bk = 32 | 64
+// tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px ; bk = 32 | 64
 hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st);
 int conv_tile_co(int tile);
 int conv_tile_px(int tile);
 // 3x3 halo kernel (kernels_conv3x3.hip); weights packed [cin/32][9][CoutW][32].
 // halo tile ids: 0 = 128co x 16x16 px, 1 = 128co x 8x16, 2 = 64co x 16x16, 3 = 64co x 8x16, 4 = 32co x 8x16
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st);
-// halo tiles 6 - 9: the pipelined fp16x3 kernels (kernels_conv3x3_x3.hip); conv + bias + {GELU, none}, NHWC; 9 = stream-K
+// halo tiles 6 - 8: the pipelined fp16x3 kernels (kernels_conv3x3_x3.hip); conv + bias + {GELU, none}, NHWC
 bool conv3x3_x3_supported(const ConvGemmParams& p, int shape);
-size_t conv3x3_sk_slab_bytes();  // shape 9 (stream-K): fp32 slab per persistent workgroup
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st);
 int halo_tile_co(int tile);
 int halo_tile_px(int tile);
 int halo_tile_th(int tile);
 
-// small-map / long-K 3x3 (kernels_conv3x3_region.hip): shape 0 = 10x40 regions, 1 = 16x32 regions
-hipError_t launch_conv3x3_region(const ConvGemmParams& p, int shape, bool split, hipStream_t st);
-bool region_shape_fits(int shape, int H, int W);
-int region_count(int shape, int H, int W);
-int region_co(int shape, int CoutW);
 // last convolution of a head: 3x3, 64 / 128 channels -> <= 4 logit channels, fp32 NCHW + fused decode (kernels_head.hip); weights packed
 // as for halo tile 4; zeros = the engine's zero page (>= 16 bytes of zeros in device memory)
 bool head_conv_supported(const ConvGemmParams& p);

@@ -320,7 +320,6 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
 
 // tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px
 hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st) {
-  if (tile == 4) return launch_pw_gemm(p, split, st);
 #define VP_CASE(T, CO, PX, WCO, WPX)                                                          \
   if (tile == T) {                                                                            \
     if (bk == 64) return split ? launch_cfg<64, CO, PX, WCO, WPX, true>(p, st) : launch_cfg<64, CO, PX, WCO, WPX, false>(p, st); \
@@ -334,7 +333,7 @@ hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool spli
   return hipErrorInvalidValue;
 }
 
-int conv_tile_co(int tile) { return tile == 0 ? 128 : (tile == 3 ? 32 : 64); }  // tile 4 (pointwise kernel): 64
+int conv_tile_co(int tile) { return tile == 0 ? 128 : (tile == 3 ? 32 : 64); }
 int conv_tile_px(int tile) { return tile == 2 ? 64 : 128; }
 
 }  // namespace vp

@@ -48,6 +48,7 @@ _SIGS = {
     "vp_get_resize_mode": (C.c_int, [_P]),
     "vp_resample_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
     "vp_gpu_id": (C.c_int, [_P]),
+    "vp_device_count": (C.c_int, []),
     "vp_host_logits_current": (C.c_int, [_P]),
     "vp_input_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),

@@ -121,7 +121,6 @@ int main(int argc, char** argv) {
     if (!quick) bad |= conv_logits(0, 64, 1, 17, 20);
   }
   if (!skip_conv && !quick) {
-    bad |= conv(0, 0, 64, 40, 10, 40, 3, 1, 200, -1, 2);  // region kernel
     bad |= conv(0, 0, 96, 33, 16, 32, 3, 0, 201, -1, 1);
   }
 

@@ -42,10 +42,10 @@ CASES = [
     (64, 48, 10, 12, 2, 1, 0, 0),      # ConvTranspose2d k2 s2 -> pixel shuffle
     (64, 3, 24, 40, 3, 0, 0, 0),       # final-layer-like, 3 output channels
     (3, 32, 8, 8, 3, 0, 0, 0),         # fewer input channels than one K block
-    (96, 72, 20, 40, 3, 0, 1, 0),      # region kernel shapes (kernels_conv3x3_region.hip): two 10x40 regions
-    (64, 40, 40, 80, 3, 0, 0, 0),      # eight 10x40 regions, ragged channel tile
-    (160, 33, 16, 32, 3, 0, 1, 0),     # one 16x32 region (AutoDrive P5 maps)
-    (64, 32, 32, 64, 3, 0, 0, 0),      # four 16x32 regions
+    (96, 72, 20, 40, 3, 0, 1, 0),      # neck-like small maps
+    (64, 40, 40, 80, 3, 0, 0, 0),      # ragged channel tile
+    (160, 33, 16, 32, 3, 0, 1, 0),     # AutoDrive P5 maps
+    (64, 32, 32, 64, 3, 0, 0, 0),
     (16, 96, 40, 64, 1, 0, 2, 0),      # MBConv expand, one 32-channel K block (pointwise kernel)
     (672, 112, 20, 40, 1, 0, 0, 1),    # MBConv project with residual, 21 K blocks (odd), ragged channel tile
     (320, 1280, 10, 20, 1, 0, 2, 0),   # features[8]
@@ -69,15 +69,8 @@ def test_conv_op_matches_torch(case, precision):
     ref = _reference(x, wt, b, ks, mode, act, res, res_mode, fp16=(precision == 0))
     tol = 1.5e-3 if precision == 0 else 2e-5  # fp16: one output rounding (2^-11) + accumulation order
     cfgs = [(-1, -1, -1), (0, 32, 1), (1, 32, 2), (2, 32, 3), (3, 32, 1), (0, 64, 1), (2, 64, 2)]
-    if ks == 1 and mode == 0 and act in (0, 2) and res_mode in (0, 1):  # LDS-free pointwise kernel (kernels_pw.hip)
-        cfgs += [(4, -1, 1)]
     if ks == 3 and mode == 0 and h >= 8 and w >= 16:  # LDS-halo 3x3 kernel tiles (kernels_conv3x3.hip)
         cfgs += [(100, -1, 1), (101, -1, 2), (102, -1, 1), (103, -1, 3), (104, -1, 1)]
-    if ks == 3 and mode == 0 and res_mode == 0 and precision == 0:  # region kernel: fp16 engines, maps that tile into regions
-        if h % 10 == 0 and w % 40 == 0:
-            cfgs += [(200, -1, 1), (200, -1, 2)]
-        if h % 16 == 0 and w % 32 == 0:
-            cfgs += [(201, -1, 1), (201, -1, 3)]
     for tile, bk, nsplit in cfgs:
         got = lib.op_conv2d(x, wt, b, ks=ks, mode=mode, act=act, res=res, res_mode=res_mode, precision=precision, tile=tile, bk=bk,
                             nsplit=nsplit)
@@ -111,36 +104,6 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
     for tile in (106, 107):   # parity-mode kernels only (the single-plane form of the 8-wave shape was measured slower and removed)
         with pytest.raises(lib.VpError):
             lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=tile, nsplit=1)
-    # stream-K (shape 9): slot counts from "whole tiles only" to the engine's own 2 x #CU (most slots cut a tile or stay empty at these
-    # sizes); only the fp32 summation order of a cut tile differs from the tile-per-workgroup kernel; deterministic
-    for tile in (109, 110):     # the 4-wave shape on two slots per CU, the 8-wave shape on one
-        for slots in (8, 48, 136, -1):
-            sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=tile, nsplit=slots)
-            assert (np.abs(sk - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5, (tile, slots)
-            assert np.abs(sk - got).max() <= 4e-6 * max(1.0, np.abs(got).max()), (tile, slots)
-            assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=tile, nsplit=slots)), (tile, slots)
-
-
-def test_stream_k_hand_off_at_layer_size():
-    """The stream-K hand-off (fp32 slabs + flags between workgroups, other CUs, other XCDs) on a decoder-sized layer -- 80x160, 256 -> 256
-    channels: 200 tiles x 8 chunks on 512 slots, EVERY slot cuts a tile -- with the engine's real slot count.  The frame changes between
-    the passes and every pass is checked in full, so a slab or flag left over from the previous pass (a stale L1 / L2 line on the
-    owner's side, a flag that overtook its slab) shows up as the previous frame's partial sums; the passes run back to back with
-    another layer-sized launch in between (consumer caches warm, uneven load)."""
-    from autoware_vision_pilot_amd import lib
-
-    rng = np.random.default_rng(5)
-    cin = cout = 256
-    wt = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9)))
-    b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
-    xs = [rng.standard_normal((cin, 80, 160), dtype=np.float32) * np.float32(s) for s in (1.0, 0.3, 2.0)]
-    refs = [lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1) for x in xs]
-    for tile in (109, 110):
-        got = lib.op_conv2d_repeat(xs, wt, b, ks=3, act=1, precision=1, tile=tile, rounds=4)
-        for r, outs in enumerate(got):
-            for i, (o, ref) in enumerate(zip(outs, refs)):
-                assert np.abs(o - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max()), (tile, r, i)
-                assert np.array_equal(o, got[0][i]), (tile, r, i)
 
 
 def test_conv_op_transpose_detecting():

@@ -33,6 +33,7 @@
 //             wave of each per SIMD -- they drift out of phase, so one workgroup's prologue / chunk hand-over / epilogue
 //             (exact GELU + split: ~1000 VALU instructions per wave, 64 KiB of stores) runs under the other's MFMAs.
 //   8 "x3w4c64": shape 7 on 64-channel tiles (53 KB, three workgroups per CU).
+//   9 "x3sk": shape 7, PERSISTENT, with the K loops of the tiles dealt STREAM-K (below);  10 "x3sk8": shape 6 likewise (one slot per CU).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -55,12 +56,27 @@ namespace vp {
 // SPLITK: grid carries p.nsplit K slices per tile; a slice covers the input chunks [KC * z / nsplit, KC * (z + 1) / nsplit) and
 // writes its fp32 accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip) sums the slices in the
 // fixed order z = 0..nsplit-1 and applies bias / activation / (hi, lo) split -- the small-map neck layers (20x40, 40x80).
-// Stream-K over these tiles (persistent workgroups, the tiles' K loops cut into equal chunk-step ranges, fp32 slab hand-off to the tile's
-// owner) was built, verified on the MI355X and measured in round 3: it removes the tile-quantisation tail (200 / 400 / 1600 tiles on 256 /
-// 512 slots) and changes nothing in the layer times (profiles/r03_streamk_layers.tsv) -- the big layers are bound chip-wide, not per
-// workgroup.  Kept out of the library: tools/dropped/kernels_conv3x3_x3_streamk.hip, DESIGN.md "tried and dropped".
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false>
+// STREAMK (round 3, shape 9): the grid is 2 x #CU workgroup SLOTS, not tiles.  The tiles are dealt to the eight XCDs as before (an
+// XCD's L2 sees a contiguous range of pixel tiles of one weight slice); inside an XCD group the tiles' K loops are laid end to
+// end, T tiles x KC input chunks, and cut into S = slots / 8 EQUAL contiguous ranges of chunk steps, so a slot works through
+// [tail of a tile][whole tiles][head of a tile] and every slot carries the same number of tap steps: the big decoder layers
+// are 400 / 800 / 1600 tiles of 16 / 8 / 4 chunks = 6400 chunk steps on 512 slots = 12.5 each, where the tile-per-workgroup
+// grids ran 1.56 / 3.125 tiles per slot in 2 / 4 rounds (22 % of the machine idle in the last one).
+// A slot that stops short of a tile's last chunk (only its LAST segment can) writes its fp32 accumulators to its 64 KiB slab of
+// p.partial in register order (1 KiB-per-wave-instruction linear stores) and raises its flag; the slot that holds the tile's LAST
+// chunk owns the tile: it adds the slabs of the lower-numbered slots that hold the tile's earlier chunks, in the fixed order
+// j-1, j-2, ..., and runs the epilogue.  A slot walks its segments from the last tile to the first: the slab is published first
+// (the owner needs it only at the end of its own range, a whole range later), the tile that waits on a slab comes last.  A slot
+// only ever waits on LOWER-numbered slots of its own group (lower blockIdx), so the wait cannot deadlock under in-order dispatch
+// even when other streams' kernels keep part of the grid from being resident; the spin is bounded anyway (the accumulators are
+// poisoned with NaN on time-out, which the engine's finite-logits probe reports).  Hand-off = MI355X_MICROARCH.md's recipe:
+// plain stores, every thread drains vmcnt, barrier, lane 0: agent-scope release fence + drained vmcnt + relaxed agent flag store;
+// owner: lane 0 polls relaxed, agent-scope acquire fence, barrier, plain loads; the owner clears the flag for the next launch.
+// Results differ from the tile-per-workgroup kernels only in the fp32 summation order of a cut tile (deterministic: the cuts
+// depend on the layer shape and the slot count alone).
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool STREAMK = false>
 __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
+  static_assert(!(SPLITK && STREAMK), "stream-K has its own fix-up path");
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
@@ -81,12 +97,28 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   const int n_px_tiles = tiles_x * ((p.H + TH - 1) / TH);
   const int n_co_tiles = p.CoutW / CO_TILE;
   const int KC_all = p.Cin >> 5;
-  int vid;  // XCD-aware workgroup -> tile map (see kernels_conv3x3.hip)
-  {
+  // ---- work of this workgroup.  Tile-per-workgroup grids: ONE segment = tile `vid` of the XCD-aware map (see kernels_conv3x3.hip),
+  // all chunks (or K slice zsplit).  Stream-K: the chunk-step range [sk_a, sk_b) of XCD group sk_g, whose tiles start at sk_t0.
+  int sk_g = 0, sk_j = 0, sk_S = 1, sk_t0 = 0, sk_a = 0, sk_b = 1;
+  long long sk_W = 0;
+  int vid0 = 0;
+  if constexpr (STREAMK) {
+    const int n_tiles = n_px_tiles * n_co_tiles, q = n_tiles >> 3, r = n_tiles & 7;
+    sk_g = blockIdx.x & 7;
+    sk_j = blockIdx.x >> 3;
+    sk_S = gridDim.x >> 3;
+    sk_t0 = sk_g < r ? sk_g * (q + 1) : r * (q + 1) + (sk_g - r) * q;
+    sk_W = (long long)(q + (sk_g < r ? 1 : 0)) * KC_all;
+    sk_a = (int)(sk_W * sk_j / sk_S);
+    sk_b = (int)(sk_W * (sk_j + 1) / sk_S);
+  } else {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    vid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
+  const int lt_last = STREAMK ? (sk_b - 1) / KC_all : 0;
+  const int nseg = STREAMK ? (sk_b > sk_a ? lt_last - sk_a / KC_all + 1 : 0) : 1;
 
+  // ---- per-thread constants that do not depend on the tile
   const int h_lds0 = (tid >> 2) * ROWB + (tid & 3) * 16;
   constexpr int NW = NTH / 64, WPIECES = W_BYTES / 1024 / NW;
   static_assert(W_BYTES % (1024 * NW) == 0, "weight tile splits into 1 KiB pieces per wave");
@@ -103,7 +135,21 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   const int a_swz = ((lane & 31) >> 2) & 3;
   const int a_ofs0 = (wco * 32 + (lane & 31)) * WROW + (((lane >> 5) ^ a_swz) << 4);  // K sub-step 1: chunk index ^ 2 -> ^ 32 bytes
 
-  int c_first = 0, KC = KC_all, zsplit = 0;
+  for (int seg = 0; seg < nseg; ++seg) {
+  // ---- this segment: tile, chunk range [c_first, c_first + KC), role
+  int vid = vid0, c_first = 0, KC = KC_all, zsplit = 0;
+  bool sk_producer = false, sk_consumer = false;
+  int sk_lt = 0;
+  if constexpr (STREAMK) {
+    sk_lt = lt_last - seg;  // last tile first (it is the one that may publish a slab), first tile last (it may wait for one)
+    const int t_lo = sk_lt * KC_all;
+    c_first = (sk_a > t_lo ? sk_a : t_lo) - t_lo;
+    const int c_end = (sk_b < t_lo + KC_all ? sk_b : t_lo + KC_all) - t_lo;
+    KC = c_end - c_first;
+    sk_producer = c_end < KC_all;
+    sk_consumer = !sk_producer && c_first > 0;
+    vid = sk_t0 + sk_lt;
+  }
   const int tile_px = vid % n_px_tiles, tile_rest = vid / n_px_tiles;
   const int tile_co = SPLITK ? tile_rest % n_co_tiles : tile_rest;
   if constexpr (SPLITK) {
@@ -345,6 +391,68 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     }
     return;
   }
+  if constexpr (STREAMK) {
+    constexpr int SLAB_V4 = MT * NT * 4 * NTH;  // f32x4 elements per slot: 64 KiB for the 128 x 128 tile
+    if (sk_producer) {
+      // the slab is in REGISTER order -- [accumulator group][thread] -- so the owner's thread t reads back exactly what the producer's
+      // thread t held, and every wave instruction moves 1 KiB of contiguous memory
+      f32x4_t* slab = reinterpret_cast<f32x4_t*>(p.partial) + (size_t)blockIdx.x * SLAB_V4 + tid;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4_t v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            slab[((i * NT + j) * 4 + g) * NTH] = v;
+          }
+      VP_DRAIN_VMEM();   // this thread's stores have reached the L2
+      __syncthreads();   // ... and so have everybody's; also: every wave is out of the K loop (LDS free for the next segment)
+      if (tid == 0) {
+        VP_FENCE_RELEASE_AGENT();
+        VP_DRAIN_VMEM();
+        VP_FLAG_STORE(p.sk_flags + blockIdx.x, 1u);
+      }
+      continue;
+    }
+    if (sk_consumer) {
+      const int t_lo = sk_lt * KC_all;
+      for (int jp = sk_j - 1; jp >= 0; --jp) {
+        const int ap = (int)(sk_W * jp / sk_S), bp = (int)(sk_W * (jp + 1) / sk_S);
+        if (bp <= t_lo) break;    // slot jp (and every lower one) ends before this tile starts
+        if (ap >= bp) continue;   // empty range: publishes nothing
+        const int pslot = (jp << 3) | sk_g;
+        if (tid == 0) {
+          unsigned spins = 0;
+          while (VP_FLAG_LOAD(p.sk_flags + pslot) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) break;  // ~ seconds: the producer never ran (see header); poisoned below
+          }
+          if (spins > (1u << 24)) VP_FLAG_STORE(p.sk_flags + gridDim.x, 1u);  // time-out word behind the flags
+          VP_FENCE_ACQUIRE_AGENT();
+          VP_FLAG_STORE(p.sk_flags + pslot, 0u);  // ready for the next launch (stream order separates the launches)
+        }
+        __syncthreads();
+        const f32x4_t* slab = reinterpret_cast<const f32x4_t*>(p.partial) + (size_t)pslot * SLAB_V4 + tid;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4_t v = slab[((i * NT + j) * 4 + g) * NTH];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][4 * g + r] += v[r];
+            }
+      }
+      if (VP_FLAG_LOAD(p.sk_flags + gridDim.x) != 0u) {  // a producer timed out (this launch or an earlier one): poison, loudly
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j][0] = __builtin_nanf("");
+      }
+    }
+  }
   __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
   const PixPatch<TW> pix{y0, x0, p.H, p.W};
 #pragma unroll
@@ -375,15 +483,18 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   static_assert(NTH % CPR == 0 && PX % RPI == 0, "row loop shape");
   const int c8 = tid % CPR, r0 = tid / CPR;
   const int co = co0 + c8 * 8;
-  if (co >= p.Ncols) return;
+  if (co < p.Ncols) {
 #pragma unroll 4
-  for (int r = r0; r < PX; r += RPI) {
-    const int m = pix(r);
-    if (m < 0) continue;
-    const size_t o = (size_t)m * p.Cstore + co;
-    *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
-    *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+    for (int r = r0; r < PX; r += RPI) {
+      const int m = pix(r);
+      if (m < 0) continue;
+      const size_t o = (size_t)m * p.Cstore + co;
+      *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
+      *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+    }
   }
+  if constexpr (STREAMK) __syncthreads();  // the stage is read out before the next segment's prologue overwrites it
+  }  // segment loop
 }
 
 // shape 8 ("x3w4c64"): 8x16 pixels x 64 channels, 4 waves of 32 channels x 64 pixels, 53 KB of LDS: THREE independent workgroups per CU.
@@ -393,9 +504,12 @@ bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
   const int co_tile = shape == 8 ? 64 : 128;
   if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
   const bool plain = p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
+  if (shape == 9 || shape == 10) return plain && p.nsplit == 1 && p.partial != nullptr && p.sk_flags != nullptr && p.sk_slots >= 8 && p.sk_slots % 8 == 0;
   if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
   return plain;
 }
+
+size_t conv3x3_sk_slab_bytes() { return (size_t)128 * 256 * sizeof(float); }  // the larger of the two stream-K tiles (shape 10)
 
 template <int CO, int TH, int WPX, bool HDB>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
@@ -413,13 +527,37 @@ static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   return sk ? launch_splitk_finish(p, st) : hipSuccess;
 }
 
+// shape 9: p.sk_slots persistent workgroups (a multiple of 8: two per CU), stream-K over the 8x16 x 128-channel tiles
+static hipError_t launch_x3_streamk(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds = 2 * (10 * 18 * 80) + 6 * (128 * 64);
+  const bool gelu = p.act == ACT_GELU;
+  auto k = gelu ? conv3x3_x3_kernel<128, 8, 2, 2, false, ACT_GELU, 0, false, true> : conv3x3_x3_kernel<128, 8, 2, 2, false, ACT_NONE, 0, false, true>;
+  static LdsAttrOnce attr_once[2];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(p.sk_slots), dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+// shape 10: p.sk_slots persistent 8-wave workgroups (one per CU), stream-K over the 16x16 x 128-channel tiles
+static hipError_t launch_x3_streamk_w8(const ConvGemmParams& p, hipStream_t st) {
+  constexpr int lds = 2 * 2 * (18 * 18 * 80) + 6 * (128 * 64);
+  const bool gelu = p.act == ACT_GELU;
+  auto k = gelu ? conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_GELU, 0, false, true> : conv3x3_x3_kernel<128, 16, 2, 4, true, ACT_NONE, 0, false, true>;
+  static LdsAttrOnce attr_once[2];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(p.sk_slots), dim3(512), lds, st, p);
+  return hipGetLastError();
+}
+
 // shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU;
-// shape 8: shape 7 on 64-channel tiles
+// shape 8: shape 7 on 64-channel tiles; shape 9: shape 7, persistent + stream-K
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
   if (!conv3x3_x3_supported(p, shape)) return hipErrorInvalidValue;
   if (shape == 6) return launch_x3_cfg<128, 16, 4, true>(p, st);
   if (shape == 7) return launch_x3_cfg<128, 8, 2, false>(p, st);
   if (shape == 8) return launch_x3_cfg<64, 8, 2, false>(p, st);
+  if (shape == 9) return launch_x3_streamk(p, st);
+  if (shape == 10) return launch_x3_streamk_w8(p, st);
   return hipErrorInvalidValue;
 }
 

@@ -1,7 +1,7 @@
 // Developer tool: ablation timing of the pipelined fp16x3 3x3 kernels (kernels_conv3x3_x3.hip) on decoder-layer shapes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x3_ablate.hip -o tools/_x3_ablate
 // ABL bits: 1 no global loads / LDS stores in the loop | 2 no MFMA | 4 no LDS fragment reads | 8 no barrier | 16 no epilogue | 256 __syncthreads()
-//           | 512 halo by LDS-DMA + zero page.
+//           (bit 512, the halo by LDS-DMA + zero page, was measured slower -- profiles/r02_x3_halo_dma_ab.txt -- and removed with its code path)
 //   _x3_ablate        ablation table;  _x3_ablate c   clock probe;  _x3_ablate b   barrier A/B (lds_dma.hpp)
 #include <cstdio>
 #include <vector>
@@ -15,7 +15,7 @@ namespace vp { hipError_t launch_splitk_finish(const ConvGemmParams&, hipStream_
 
 template <int TH, int WPX, bool HDB, int ABL>
 static float time_variant(const ConvGemmParams& p, int iters) {
-  constexpr int lds = (HDB ? 2 : 1) * 2 * (HDB ? (((TH + 2) * 18 * 5 + 63) / 64) * 1024 : (TH + 2) * 18 * 80) + 6 * (128 * 64);
+  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
   auto k = conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU, ABL>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / 128));
@@ -86,7 +86,7 @@ static void clock_probe(const char* name, int H, int W, int Cin, int Cout) {
   ConvGemmParams p{};
   p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
   p.act = ACT_GELU; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout; p.Creal = Cout; p.nsplit = 1; p.partial = reinterpret_cast<float*>(probe); p.zeros = bias_zero_page(bias);
-  constexpr int lds = (HDB ? 2 : 1) * 2 * (HDB ? (((TH + 2) * 18 * 5 + 63) / 64) * 1024 : (TH + 2) * 18 * 80) + 6 * (128 * 64);
+  constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
   auto k = conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU, ABL>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   dim3 grid(((H + TH - 1) / TH) * ((W + 15) / 16) * (Cout / 128));
@@ -131,8 +131,6 @@ int main(int argc, char** argv) {
     clock_probe<8, 2, false, 32 | 256>("w4 dec8 __syncthreads", 320, 640, 128, 128);
     clock_probe<8, 2, false, 32>("w4 dec6 lds barrier", 160, 320, 256, 256);
     clock_probe<8, 2, false, 32 | 256>("w4 dec6 __syncthreads", 160, 320, 256, 256);
-    clock_probe<16, 4, true, 32 | 512>("w8 dec4 halo by LDS-DMA + zero page", 80, 160, 512, 512);
-    clock_probe<16, 4, true, 32 | 512>("w8 dec6 halo by LDS-DMA + zero page", 160, 320, 256, 256);
     clock_probe<16, 4, true, 32 | 64>("w8 dec4 lds barrier, no halo staging", 80, 160, 512, 512);
     clock_probe<16, 4, true, 32 | 128>("w8 dec4 lds barrier, no weight DMA", 80, 160, 512, 512);
     return 0;
