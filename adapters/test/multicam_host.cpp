@@ -79,8 +79,7 @@ struct Shared {
     const int rc_ = (expr);                                                         \
     if (rc_ != VP_OK) {                                                             \
       std::fprintf(stderr, "rank %d: %s failed (%d): %s\n", rank, what, rc_, err); \
-      sh->failures++;                                                               \
-      return;                                                                       \
+      std::_Exit(1); /* the other ranks wait for this one in RCCL / at the rendezvous */ \
     }                                                                               \
   } while (0)
 
@@ -100,8 +99,7 @@ void camera_thread(Shared* sh, int rank) {
   for (int i = 0; i < 3; ++i) {
     if (vp_enqueue_multi(seg, heads, 1) != VP_OK || vp_gather(seg, comm, VP_GATHER_MASK) != VP_OK) {
       std::fprintf(stderr, "rank %d: warm-up failed: %s / %s\n", rank, vp_last_error(seg), vp_comm_last_error(comm));
-      sh->failures++;
-      return;
+      std::_Exit(1);
     }
   }
   CK(vp_sync(seg), "vp_sync");
@@ -112,8 +110,7 @@ void camera_thread(Shared* sh, int rank) {
     if (vp_upload_frame(seg, frame.data(), kFrameH, kFrameW, kFrameW * 3) != VP_OK || vp_enqueue_multi(seg, heads, 1) != VP_OK ||
         vp_gather(seg, comm, VP_GATHER_MASK) != VP_OK) {
       std::fprintf(stderr, "rank %d frame %d: %s / %s\n", rank, f, vp_last_error(seg), vp_comm_last_error(comm));
-      sh->failures++;
-      break;
+      std::_Exit(1);
     }
   }
   if (vp_sync(seg) != VP_OK) sh->failures++;

@@ -54,3 +54,44 @@ def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, engines, mtype, kind
     else:
         assert np.array_equal(tail.view(np.float32).reshape(80, 160), pre_post.egolanes_planes(lg)[0])
     eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
+
+
+@pytest.mark.gpu
+def test_multicam_host_cpp(tmp_path, state_dicts):
+    """adapters/test/multicam_host.cpp: the C++ multi-camera host (thread per GPU, no Python / torch in the process) -- SceneSeg +
+    Scene3D on a shared encoder per camera (vp_create + vp_create_shared + vp_enqueue_multi), per-frame RCCL all-gather of the
+    class maps behind the C ABI (vp_comm_*, vp_gather), world = min(visible GPUs, cameras).  Its own checks (every rank's gathered
+    buffer identical, each record the rank's own map) plus: every camera's gathered class map equals what the ctypes engine
+    computes from the frame the host dumped."""
+    import json
+
+    from autoware_vision_pilot_amd import lib, synthetic, weights as vw
+    from oracle import weights
+
+    _build()
+    sd_seg = state_dicts("sceneseg")
+    sd_3d = weights.share_backbone(dict(state_dicts("scene3d")), "scene3d", sd_seg, "sceneseg")
+    seg, s3d, dump = tmp_path / "seg.vpw", tmp_path / "s3d.vpw", tmp_path / "dump.bin"
+    seg.write_bytes(vw.pack_state_dict(sd_seg))
+    s3d.write_bytes(vw.pack_state_dict(sd_3d))
+    r = subprocess.run([os.path.join(ROOT, "adapters", "test", "multicam_host"), str(seg), str(s3d), "8", "6", str(dump)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ok"] is True and line["rccl_world"] == min(8, line["gpus_visible"]) and line["frames_per_s"] > 0
+    raw = np.fromfile(dump, dtype=np.uint8)
+    world, h, w = (int(v) for v in raw[:12].view(np.uint32))
+    assert world == line["rccl_world"]
+    eng = lib.Engine("sceneseg", seg.read_bytes(), precision="fp16x3")
+    eng.set_decode_mode(lib.VP_DECODE_CLASS_INDEX)
+    try:
+        off = 12
+        for cam in range(world):
+            frame = raw[off:off + h * w * 3].reshape(h, w, 3)
+            off += h * w * 3
+            got = raw[off:off + 320 * 640].reshape(320, 640)
+            off += 320 * 640
+            eng.infer(frame)
+            assert np.array_equal(got, eng.mask()), cam
+            assert len(np.unique(got)) > 1          # a real class map, not a constant
+    finally:
+        eng.close()
