@@ -107,6 +107,10 @@ Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) { return fold_
 Folded fold_conv_norm(const WeightBlob& blob, const std::string& p) { return fold_conv(blob, p + ".conv", p + ".norm", 1e-3f); }
 
 void split_half(float v, half_t* hi, half_t* lo) {
+  // Both precision modes carry weights on fp16 planes: a folded weight beyond the fp16 range (or non-finite) would load as inf and
+  // every result would silently be garbage.  (Small weights are safe: below 2^-14 the hi plane is subnormal and the lo plane picks up less,
+  // a loss of relative precision on values that contribute nothing at the 1e-3 bar.)
+  if (!(std::fabs(v) <= 65504.0f)) throw RangeError("weight " + std::to_string(v) + " is outside the fp16 range the matrix pipe carries (|w| <= 65504): re-scale the checkpoint");
   const half_t h = (half_t)v;
   *hi = h;
   *lo = (half_t)(v - (float)h);
@@ -187,6 +191,9 @@ void Engine::release() {
   if (h_logits_) hipHostFree(h_logits_);
   if (h_mask_) hipHostFree(h_mask_);
   if (h_frame_) hipHostFree(h_frame_);
+  if (h_status_) hipHostFree(h_status_);
+  h_status_ = nullptr;
+  d_status_ = nullptr;
   h_logits_ = nullptr;
   h_mask_ = nullptr;
   h_frame_ = nullptr;
@@ -1489,6 +1496,18 @@ void Engine::finish_plan() {
       op.run = [this](hipStream_t st) { return launch_decode_mask(d_logits_, out_c_, out_h_ * out_w_, decode_mode_, d_mask_, st); };
       ops_.push_back(std::move(op));
     }
+    // range probe: an activation that left the fp16 range surfaces in the logits as inf / NaN (kernels_misc.hip finite_probe_kernel)
+    d_status_ = static_cast<unsigned*>(dalloc(sizeof(unsigned), true));
+    VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_status_), sizeof(unsigned), hipHostMallocDefault));
+    *h_status_ = 0;
+    Op probe;
+    probe.name = "finite_probe";
+    probe.kernel = "finite_probe";
+    probe.bytes = 4.0 * out_c_ * out_h_ * out_w_;
+    probe.run = [this](hipStream_t st) {
+      return finite_check_ ? launch_finite_probe(d_logits_, (size_t)out_c_ * out_h_ * out_w_, d_status_, st) : hipSuccess;
+    };
+    ops_.push_back(std::move(probe));
   }
   // kernel tags of the non-GEMM launches (the conv ops set theirs in push_conv_op)
   auto ends_with = [](const std::string& s, const char* suf) {
@@ -1852,12 +1871,28 @@ void Engine::enqueue() {
   host_logits_valid_ = host_mask_valid_ = false;
 }
 
-void Engine::sync() { VP_HIP_CHECK(hipStreamSynchronize(stream_)); }
+void Engine::sync() {
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  check_status();
+}
+
+// The probe's verdict on the pass whose outputs were last fetched (enqueue_fetch copies the flag behind them).  Loud, once: the flag is
+// cleared so that the next frame is judged on its own.
+void Engine::check_status() {
+  if (!status_pending_ || !h_status_) return;
+  status_pending_ = false;
+  if (*h_status_ == 0) return;
+  *h_status_ = 0;
+  VP_HIP_CHECK(hipMemsetAsync(d_status_, 0, sizeof(unsigned), stream_));
+  throw RangeError("non-finite value (inf / NaN) in the network output: an activation left the fp16 range of the matrix pipe (|x| > 65504) "
+                   "or the input / weights were not finite; outputs of this frame are invalid");
+}
 
 void Engine::fetch_outputs() {
   if (!d_logits_) throw std::runtime_error("this engine has no outputs (batched encoder: fetch from its shared-prefix engines)");
   enqueue_fetch();
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  check_status();
 }
 
 // D2H of the outputs the caller selected (vp_set_outputs), asynchronous on the engine stream, into pinned host memory.
@@ -1868,6 +1903,10 @@ void Engine::enqueue_fetch() {
   if ((outputs_ & 2) && d_mask_) VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
   host_logits_valid_ = (outputs_ & 1) != 0;
   host_mask_valid_ = (outputs_ & 2) != 0;
+  if (finite_check_ && d_status_) {
+    VP_HIP_CHECK(hipMemcpyAsync(h_status_, d_status_, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+    status_pending_ = true;
+  }
 }
 
 // Lazy variants behind vp_logits / vp_mask_u8: an output de-selected with vp_set_outputs is fetched on first use.

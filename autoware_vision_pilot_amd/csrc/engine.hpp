@@ -44,6 +44,11 @@ std::vector<char> onnx_to_blob(const std::string& path);
 // Pillow's resample coefficient tables (engine.cpp): bounds [out][2], coefficients [out][ksize] with 22 fractional bits; returns ksize
 int pil_coeffs(int in_size, int out_size, int filter, std::vector<int>* bounds, std::vector<int>* kk);
 
+// a value left the representable range (vp_status VP_ERR_RANGE): a weight beyond fp16 at load, inf / NaN in a network's output
+struct RangeError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
 struct Act {
   std::string name;
   int Creal = 0, C = 0, H = 0, W = 0;
@@ -113,6 +118,15 @@ class Engine {
   }
   // stage vp_infer's H2D through a pinned double buffer owned by the engine (default on)
   void set_pinned_staging(bool on) { pinned_staging_ = on; }
+  // inf / NaN probe on the logits at the end of every pass (default on; a 3 us kernel): reported by the next synchronising call
+  void set_finite_check(bool on) {
+    if (on != finite_check_) {
+      finite_check_ = on;
+      graph_valid_ = false;
+      ++plan_epoch_;
+    }
+  }
+  void check_status();  // throws RangeError if the last fetched pass flagged a non-finite output
   void copy_outputs_device(void* logits_dst, void* mask_dst);
   void mask_resized(uint8_t* dst, int h, int w);
   void depth_resized(float* dst, int h, int w);
@@ -240,6 +254,9 @@ class Engine {
   bool decode_fused_ = false;  // the logits convolution writes d_mask_ in its epilogue: no separate decode launch
   int outputs_ = 3;  // vp_set_outputs: bit 0 logits, bit 1 mask copied to the host by vp_infer*
   bool host_logits_valid_ = false, host_mask_valid_ = false;
+  unsigned* d_status_ = nullptr;  // sticky non-finite flag written by the probe kernel
+  unsigned* h_status_ = nullptr;  // pinned copy, fetched with the outputs
+  bool finite_check_ = true, status_pending_ = false;
   // pinned staging of the caller's (pageable) frame: two slots
   uint8_t* h_frame_ = nullptr;
   size_t h_frame_cap_ = 0;

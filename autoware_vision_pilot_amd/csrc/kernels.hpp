@@ -158,6 +158,7 @@ hipError_t launch_resize_nearest(const uint8_t* src, int sw, const int* ytab, co
 hipError_t launch_resize_bilinear_f32(const float* src, int sw, const int* yi, const float* yf, const int* xi, const float* xf,
                                       int oh, int ow, float* dst, hipStream_t st);
 hipError_t launch_minmax_f32(const float* src, size_t n, unsigned* mm, hipStream_t st);
+hipError_t launch_finite_probe(const float* src, size_t n, unsigned* flag, hipStream_t st);  // *flag |= 1 if any inf / NaN (sticky)
 hipError_t launch_depth_colorize(const float* src, size_t n, const unsigned* mm, const uint8_t* lut, uint8_t* dst, hipStream_t st);
 hipError_t launch_viz_blend(const uint8_t* mask, int mw, const int* ytab, const int* xtab, const uint8_t* frame, int stride, int oh, int ow,
                             const uint8_t* lut, int frame_is_rgb, uint8_t* dst, hipStream_t st);

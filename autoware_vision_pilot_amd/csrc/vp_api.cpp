@@ -23,6 +23,9 @@ int guarded(vp_engine* e, F&& f) {
   } catch (const std::invalid_argument& ex) {
     e->err = ex.what();
     return VP_ERR_ARG;
+  } catch (const vp::RangeError& ex) {
+    e->err = ex.what();
+    return VP_ERR_RANGE;
   } catch (const std::exception& ex) {
     e->err = ex.what();
     return std::strncmp(ex.what(), "HIP error", 9) == 0 ? VP_ERR_HIP : VP_ERR_STATE;
@@ -47,6 +50,9 @@ int create_impl(vp_engine** out, int kind, const void* blob, size_t bytes, int p
     } catch (const std::invalid_argument& ex) {
       set_err(err, err_len, ex.what());
       return VP_ERR_ARG;
+    } catch (const vp::RangeError& ex) {   // a folded weight beyond the fp16 range
+      set_err(err, err_len, ex.what());
+      return VP_ERR_RANGE;
     } catch (const std::exception& ex) {
       set_err(err, err_len, ex.what());
       return std::strstr(ex.what(), "weight") ? VP_ERR_WEIGHTS : VP_ERR_HIP;
@@ -288,6 +294,9 @@ int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes)
 int vp_set_outputs(vp_engine* e, int outputs) {
   return guarded(e, [&](vp::Engine& g) { g.set_outputs(outputs); });
 }
+int vp_set_finite_check(vp_engine* e, int enable) {
+  return guarded(e, [&](vp::Engine& g) { g.set_finite_check(enable != 0); });
+}
 int vp_set_pinned_staging(vp_engine* e, int enable) {
   return guarded(e, [&](vp::Engine& g) { g.set_pinned_staging(enable != 0); });
 }
@@ -314,6 +323,7 @@ int vp_infer_multi(vp_engine* base, vp_engine* const* shared, int n_shared, cons
     g.enqueue_fetch();
     for (int i = 0; i < n_shared; ++i) shared[i]->impl->enqueue_fetch();
     g.sync();
+    for (int i = 0; i < n_shared; ++i) shared[i]->impl->check_status();
   });
 }
 int vp_enqueue_multi(vp_engine* base, vp_engine* const* shared, int n_shared) {

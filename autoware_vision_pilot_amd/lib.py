@@ -63,6 +63,7 @@ _SIGS = {
     "vp_frame_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_set_outputs": (C.c_int, [_P, C.c_int]),
     "vp_set_pinned_staging": (C.c_int, [_P, C.c_int]),
+    "vp_set_finite_check": (C.c_int, [_P, C.c_int]),
     "vp_infer_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vp_enqueue_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
     "vp_set_multi_fork": (C.c_int, [_P, C.c_int]),
@@ -114,6 +115,10 @@ _lib = None
 
 class VpError(RuntimeError):
     pass
+
+
+class VpRangeError(VpError):
+    """VP_ERR_RANGE: a weight beyond the fp16 range at load, or inf / NaN in a network's output (an activation left the fp16 range)."""
 
 
 def load():
@@ -193,7 +198,7 @@ class Engine:
         if rc != 0:
             self._h = C.c_void_p()
             msg = err.value.decode(errors="replace")
-            raise (ValueError if rc == -1 else VpError)(f"vp_create failed ({rc}): {msg}")
+            raise (ValueError if rc == -1 else VpRangeError if rc == -5 else VpError)(f"vp_create failed ({rc}): {msg}")
         self.kind = kind
 
     def close(self):
@@ -211,8 +216,12 @@ class Engine:
     def _ck(self, rc):
         if rc < 0:
             msg = self._lib.vp_last_error(self._h).decode(errors="replace")
-            raise (ValueError if rc == -1 else VpError)(f"libvp_hip error {rc}: {msg}")
+            raise (ValueError if rc == -1 else VpRangeError if rc == -5 else VpError)(f"libvp_hip error {rc}: {msg}")
         return rc
+
+    def set_finite_check(self, on):
+        """inf / NaN probe on the logits at the end of every pass (default on): VpRangeError from the synchronising call."""
+        self._ck(self._lib.vp_set_finite_check(self._h, int(bool(on))))
 
     # ---- configuration
     def set_input_format(self, pixel_format, plane_order):

@@ -45,7 +45,8 @@ extern "C" {
 
 typedef struct vp_engine vp_engine;
 
-enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_WEIGHTS = -2, VP_ERR_HIP = -3, VP_ERR_STATE = -4 };
+enum vp_status { VP_OK = 0, VP_ERR_ARG = -1, VP_ERR_WEIGHTS = -2, VP_ERR_HIP = -3, VP_ERR_STATE = -4,
+                 VP_ERR_RANGE = -5 /* a value left the fp16 range the matrix pipe carries: see vp_set_finite_check */ };
 
 /* VP_AUTODRIVE (BASELINE configs[4]): Models/model_components/autodrive/autodrive_network.py:32-36 --
  * shared backbone on the previous and the current frame (network input 1x3x512x1024, RGB planes), head -> three scalars
@@ -155,6 +156,14 @@ enum vp_output_bits { VP_OUT_LOGITS = 1, VP_OUT_MASK = 2 };
 int vp_set_outputs(vp_engine* e, int output_bits);
 /* vp_infer stages the caller's pageable frame through a pinned double buffer owned by the engine (default 1). */
 int vp_set_pinned_staging(vp_engine* e, int enable);
+/* RANGE GUARD.  Both precision modes compute on fp16 planes: VP_FP16X3 has fp32-class SIGNIFICAND (hi + lo) but fp16 EXPONENT range.
+ *   - at load: a BN-folded weight with |w| > 65504 (or non-finite) fails vp_create* with VP_ERR_RANGE instead of loading as inf;
+ *   - per frame: an activation beyond 65504 becomes inf and reaches the logits as inf / NaN; a probe kernel over the logits at the end
+ *     of every pass (3 us, default ON) raises a flag that travels with the outputs, and the call that synchronises on that pass --
+ *     vp_infer*, vp_fetch_outputs, vp_sync -- returns VP_ERR_RANGE (once per offending frame; the outputs of that frame are invalid).
+ * The reference computes in fp32 and has no such limit; networks whose activations stay below 65504 (trained, normalised ones do by
+ * orders of magnitude: |x| < 600 over the seeded sweeps of tests/test_gpu_parity_sweep.py) are unaffected.  enable = 0 drops the probe. */
+int vp_set_finite_check(vp_engine* e, int enable);
 
 /* ---- synchronous per-frame path (host buffers in, host buffers out) -------------------------------------- */
 int vp_infer(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes);

@@ -185,3 +185,57 @@ def _layer_kernels(eng):
         eng._ck(eng._lib.vp_layer_kernel(eng._h, i, ct.byref(tag)))
         out.append(tag.value.decode())
     return out
+
+
+def test_range_guard_is_loud_on_cpu(emu_lib):
+    """The parity mode has fp32-class significand but fp16 EXPONENT range.  (1) A folded weight beyond 65504 fails engine construction
+    with VP_ERR_RANGE (VpRangeError) instead of loading as inf.  (2) Weights scaled so that activations pass 65504: the probe on the
+    outputs turns the silent inf / NaN into VP_ERR_RANGE from the synchronous call -- once; the same engine then serves a frame again
+    (the error is per frame, not a poisoned engine) and raises again.  (3) With the probe switched off the garbage comes back silently:
+    that is what the guard is for."""
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+
+    sd = synthetic.make_autodrive_state_dict(5)
+    frame = synthetic.synthetic_frame(270, 480, 3)
+    big = dict(sd)
+    k = next(k for k in sd if k.endswith("p2.0.conv.weight"))
+    big[k] = sd[k] * np.float32(1e7)
+    with pytest.raises(emu_lib.VpRangeError, match="fp16 range"):
+        emu_lib.Engine("autodrive", vw.pack_state_dict(big), precision="fp16x3")
+    hot = dict(sd)
+    for key in sd:                       # every BatchNorm scale x 60: a few layers in, |x| > 65504
+        if key.endswith(".norm.weight"):
+            hot[key] = sd[key] * np.float32(60.0)
+    eng = emu_lib.Engine("autodrive", vw.pack_state_dict(hot), precision="fp16x3")
+    try:
+        for _ in range(2):
+            with pytest.raises(emu_lib.VpRangeError, match="non-finite"):
+                eng.infer(frame)
+        eng.set_finite_check(False)
+        eng.infer(frame)
+        assert not np.isfinite(eng.logits()).all()
+    finally:
+        eng.close()
+
+
+def test_kernel_plan_is_the_committed_one(emu_lib):
+    """WHICH kernel every layer of every network gets (vp_layer_kernel), both precisions, against tests/golden/kernel_plan.json: the
+    dispatch rules of engine.cpp (tile shapes, split-K, the pipelined / register-stationary / LDS-DMA kernels, fused decode) are host
+    code and untested as rules otherwise -- a wrong predicate silently picks a slower kernel.  Deliberate rule changes regenerate the file
+    with tools/dump_kernel_plan.py and show up as a reviewable diff."""
+    import json
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from dump_kernel_plan import kernel_plan
+
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_plan.json")))
+    got = kernel_plan(emu_lib)
+    assert sorted(got) == sorted(want)
+    for key in want:
+        diff = [(a, b) for a, b in zip(got[key], want[key]) if list(a) != list(b)]
+        assert len(got[key]) == len(want[key]) and not diff, f"{key}: {diff[:6]}"
+    # the rules this round relies on, spelled out (SceneSeg, parity mode)
+    seg = dict(tuple(r) for r in got["sceneseg/fp16x3"])
+    assert seg["SceneNeck.decode_layer_4"] == "conv3x3_x3w8<co128,px256>" and seg["SceneSegHead.decode_layer_8"] == "conv3x3_x3w4<co128,px128>"
+    assert seg["SceneSegHead.decode_layer_10"].startswith("head_conv3x3<c64,x3>+decode")
+    assert seg["SceneSegHead.upsample_layer_4"] == "convt_rs<k128,x3>" and seg["SceneNeck.upsample_layer_2+skip_link_layer_2"].startswith("gemm_dma<")
