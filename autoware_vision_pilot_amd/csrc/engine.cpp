@@ -1,17 +1,9 @@
-#include "engine.hpp"
-
-#include "conv_epilogue.hpp"
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
+// libvp_hip engine, part 1 of 3: weight container, BatchNorm folding, engine construction / release and the per-network PLAN
+// (backbone, context, neck, heads, AutoDrive).  Part 2 = engine_dispatch.cpp (which kernel a layer gets, weight packing), part 3 =
+// engine_io.cpp (frames in, graph replay, outputs out).
+#include "engine_internal.hpp"
 
 namespace vp {
-
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // ================================================================================================ WeightBlob
 void WeightBlob::parse(const void* blob, size_t bytes) {
@@ -58,14 +50,6 @@ const HostTensor& WeightBlob::get(const std::string& key) const {
 }
 
 // ======================================================================================== folding + packing
-namespace {
-
-constexpr float kBnEps = 1e-5f;  // torchvision efficientnet_b0 BatchNorm2d default
-
-struct Folded {
-  std::vector<float> w, b;
-  int cout = 0, cin = 0, k = 0;  // cin = per-group input channels
-};
 
 // conv(no bias) + BatchNorm(eval) -> conv with bias:  w' = w * g/sqrt(v+eps),  b' = beta - mean * g/sqrt(v+eps).
 // A blob converted from an ONNX file exported with do_constant_folding=True (Models/exports/convert_pytorch_to_onnx.py:
@@ -115,8 +99,6 @@ void split_half(float v, half_t* hi, half_t* lo) {
   *hi = h;
   *lo = (half_t)(v - (float)h);
 }
-
-}  // namespace
 
 // ==================================================================================================== Engine
 Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base, int frames, int frame_index)
@@ -263,13 +245,6 @@ const void* Engine::zero_page() {
   return d_zero_;
 }
 
-template <class T>
-T* Engine::dupload(const std::vector<T>& v) {
-  T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
-  VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-  return d;
-}
-
 Act* Engine::frame_view(const Act* a, int f) {
   if (a->frames <= 1) return const_cast<Act*>(a);
   auto v = std::make_unique<Act>(*a);
@@ -301,492 +276,6 @@ void Engine::upload_act(Act* a, const float* chw) {
   VP_HIP_CHECK(hipMemcpy(d, chw, (size_t)a->Creal * a->H * a->W * sizeof(float), hipMemcpyHostToDevice));
   VP_HIP_CHECK(launch_nchw_to_act(d, a->Creal, a->view(), stream_));
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-// ------------------------------------------------------------------------------------------- conv planning
-void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc) {
-  auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
-  int tile;
-  if (o.tile >= 0) {
-    tile = o.tile;
-  } else if (ncols <= 32) {
-    tile = 3;
-  } else if (ncols % 128 == 0 && (cdiv(M, 128) * (ncols / 128) >= 192 || (M <= 256 && ncols >= 2048))) {
-    tile = 0;  // second case: weight-dominated GEMMs on tiny maps (first up-sampling stage: 200 pixels x 5120 rows): 29 vs 36 us
-  } else if (cdiv(M, 128) * cdiv(ncols, 64) >= 128 || M >= 2048) {
-    tile = 1;
-  } else {
-    tile = 2;
-  }
-  pc->tile = tile;
-  pc->bk = o.bk > 0 ? o.bk : 64;  // 128-byte rows per load, half the K steps of BK=32
-  if (cin_pad % pc->bk != 0) pc->bk = 32;
-  pc->CoutW = round_up(ncols, conv_tile_co(tile));
-  const long long blocks = cdiv(M, conv_tile_px(tile)) * (pc->CoutW / conv_tile_co(tile));
-  const int S = ks * ks * (cin_pad / pc->bk);
-  int ns = 1;
-  if (o.nsplit > 0) {
-    ns = o.nsplit;
-  } else if (blocks < 128 && S >= 32) {  // split-K pays only for long K loops: it costs a second (finish) launch
-    ns = (int)std::min<long long>(cdiv(384, blocks), std::max(1, S / 8));
-    ns = std::max(1, std::min(ns, 32));
-  } else if (ks == 1 && blocks < 64) {
-    // long-K 1x1 GEMMs on small maps (the MBConv projections of stages 4-7: K = 480..1152 on 200-800 pixels, 12-42 workgroups
-    // walking 8-18 dependent staging steps): slices of >= 3 steps up to ~128 workgroups.  Measured (parity mode, per launch incl.
-    // the finish kernel): 25 -> 15 us on stages 6 / 7, 20 -> 15 on stage 5, SceneSeg single stream 2.076 -> 2.015 ms.
-    // VP_PROJ_SPLIT = minimum steps per slice (0 = never split).
-    const char* e = std::getenv("VP_PROJ_SPLIT");
-    const int min_steps = e ? std::atoi(e) : 3;
-    if (min_steps > 0 && S >= 2 * min_steps) ns = std::max(1, std::min<int>(S / min_steps, (int)cdiv(128, blocks)));
-  }
-  pc->nsplit = std::min(ns, std::max(1, S));
-}
-
-void Engine::push_conv_op(const std::string& name, const Act* in, const PackedConv& pc, int ks, int ncols, const ConvOpts& o, Act* out,
-                          int store_mode, int cout_real) {
-  ConvGemmParams p{};
-  const int cstride = std::max(1, o.stride);
-  p.in_hi = in->hi;
-  p.in_lo = in->lo;
-  p.H = in->H / cstride;  // output size (== input size for stride 1)
-  p.W = in->W / cstride;
-  p.stride = cstride;
-  p.Hin = in->H;
-  p.Win = in->W;
-  p.post_act = o.post_act;
-  p.Cin = in->C;
-  p.w_hi = pc.w_hi;
-  p.w_lo = pc.w_lo;
-  p.bias = pc.bias;
-  p.ks = ks;
-  p.Ncols = ncols;
-  p.CoutW = pc.CoutW;
-  p.act = (o.act >= ACT_GELU && o.act <= ACT_SIGMOID && !split()) ? (o.act | ACT_F16) : o.act;  // VP_FP16: reduced-instruction activations (common.hpp)
-  p.res_mode = o.res_mode;
-  p.res_hi = o.res ? o.res->hi : nullptr;
-  p.res_lo = o.res ? o.res->lo : nullptr;
-  p.store_mode = store_mode;
-  p.out_hi = out ? out->hi : nullptr;
-  p.out_lo = out ? out->lo : nullptr;
-  p.Cstore = out ? out->C : 0;
-  p.out_f32 = o.logits_out;
-  p.Creal = cout_real;
-  p.zeros = static_cast<const half_t*>(zero_page());
-  // the head's logits convolution decodes the mask in its epilogue (one launch and a 2.4 MB re-read less per network)
-  const bool fuse_decode = store_mode == STORE_NCHW_F32 && o.logits_out == d_logits_ && d_mask_ && cout_real <= 8 && ncols <= 32 && kind_ >= 0 &&
-                           kind_ != 4 && !(std::getenv("VP_FUSE_DECODE") && std::getenv("VP_FUSE_DECODE")[0] == '0');
-  if (fuse_decode) {
-    p.mask_out = d_mask_;
-    decode_fused_ = true;
-  }
-  p.nsplit = pc.nsplit;
-  if (o.in2) {
-    p.Cin2 = o.in2->C;
-    p.in2_delta_hi = o.in2->hi - in->hi;
-    p.in2_delta_lo = (in->lo && o.in2->lo) ? o.in2->lo - in->lo : 0;
-  }
-  const int M = p.H * p.W;
-  p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
-  // split-K layers finish in the workgroup that arrives last on a tile (conv_epilogue.hpp splitk_arrive_and_finish): one zeroed arrival
-  // counter per output tile (no tile is smaller than 64 pixels x 32 channels).  VP_SPLITK_FOLD=0 (developer knob, A/B timing): the
-  // separate splitk_finish_kernel launch.
-  static const char* env_fold = std::getenv("VP_SPLITK_FOLD");
-  if (pc.nsplit > 1 && !(env_fold && env_fold[0] == '0'))
-    p.tile_count = static_cast<unsigned*>(dalloc((size_t)((M + 63) / 64) * ((pc.CoutW + 31) / 32) * sizeof(unsigned), true));
-  const int tile = pc.tile, bk = pc.bk;
-  const bool sp = split();
-  Op op;
-  op.name = name;
-  op.flops = 2.0 * M * (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks;
-  const double esz = sp ? 4.0 : 2.0;
-  op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
-                    (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
-  if (o.in2) {  // fused skip-link: extra K columns read at every OUTPUT pixel
-    op.flops += 2.0 * M * 4.0 * cout_real * o.in2->Creal;
-    op.bytes += esz * ((double)M * 4.0 * o.in2->Creal + (double)cout_real * o.in2->Creal);
-  }
-  if (tile >= 100) {
-    int ht = tile - 100;
-    // ---- optional per-layer tile autotune (VP_AUTOTUNE=1 enables; measured +-1 % on the frames-in-flight bench, so
-    // the static heuristic is the default): time the tile shapes that share this weight packing and keep the fastest.  The K order per output is identical for every tile, so the choice never changes a result bit.
-    static const char* at_env = std::getenv("VP_AUTOTUNE");
-    const bool explicit_tile = o.tile >= 100;
-    if (!explicit_tile && at_env && at_env[0] == '1' && kind_ >= 0) {
-      std::vector<int> cand;
-      for (int c : {0, 1, 2, 3, 4}) {
-        if (sp && (c == 0 || c == 2)) continue;
-        if (pc.CoutW % halo_tile_co(c) != 0) continue;
-        if (halo_tile_co(c) > pc.CoutW) continue;
-        if (ncols <= 32 && c != 4) continue;
-        if (ncols > 32 && c == 4) continue;
-        cand.push_back(c);
-      }
-      // Cost = wall time of 6 launches spread over 3 streams: the engine is meant to run with several frames in
-      // flight, so what counts is the CU-time a tile shape consumes under contention, not its latency alone.
-      hipStream_t ts[3] = {stream_, nullptr, nullptr};
-      VP_HIP_CHECK(hipStreamCreateWithFlags(&ts[1], hipStreamNonBlocking));
-      VP_HIP_CHECK(hipStreamCreateWithFlags(&ts[2], hipStreamNonBlocking));
-      double best = 1e30;
-      int best_c = ht;
-      for (int c : cand) {
-        hipError_t e = launch_conv3x3_halo(p, c, sp, stream_);  // warm-up (also sets the LDS attribute)
-        if (e != hipSuccess) continue;
-        VP_HIP_CHECK(hipStreamSynchronize(stream_));
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int r = 0; r < 6 && e == hipSuccess; ++r) e = launch_conv3x3_halo(p, c, sp, ts[r % 3]);
-        for (hipStream_t s : ts) VP_HIP_CHECK(hipStreamSynchronize(s));
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        if (e == hipSuccess && us < best) {
-          best = us;
-          best_c = c;
-        }
-      }
-      hipStreamDestroy(ts[1]);
-      hipStreamDestroy(ts[2]);
-      ht = best_c;
-    }
-    if (ht >= 6 && ht <= 8) {
-      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
-      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
-      op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
-      ops_.push_back(std::move(op));
-      return;
-    }
-    // the heads' logits convolution: weights stationary in registers, 16x16x32 MFMA, LDS-DMA halo (kernels_head.hip); same weight
-    // packing as halo tile 4.  VP_HEAD_CONV=0 keeps the halo kernel.
-    if (ht == 4 && o.tile < 0 && head_conv_supported(p) && !(std::getenv("VP_HEAD_CONV") && std::getenv("VP_HEAD_CONV")[0] == '0')) {
-      const void* zeros = zero_page();
-      op.kernel = std::string("head_conv3x3<c") + std::to_string(p.Cin) + (sp ? ",x3>" : ",x1>") + (fuse_decode ? "+decode" : "");
-      op.run = [this, p, zeros, fuse_decode](hipStream_t st) {
-        ConvGemmParams q = p;
-        if (fuse_decode) q.decode_mode = decode_mode_;  // vp_set_decode_mode may change it between frames (it invalidates the graph)
-        return launch_head_conv(q, zeros, st);
-      };
-      ops_.push_back(std::move(op));
-      return;
-    }
-    // ",regepi": the register-GELU single-pass epilogue instantiation (same condition as launch_halo_cfg)
-    const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1;
-    op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
-                (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
-    if (fuse_decode) {
-      op.kernel += "+decode";
-      op.run = [this, p, ht, sp](hipStream_t st) {
-        ConvGemmParams q = p;
-        q.decode_mode = decode_mode_;  // vp_set_decode_mode may change it between frames (it invalidates the graph)
-        return launch_conv3x3_halo(q, ht, sp, st);
-      };
-    } else {
-      op.run = [p, ht, sp](hipStream_t st) { return launch_conv3x3_halo(p, ht, sp, st); };
-    }
-  } else if (tile == 6) {  // its weights are packed in its own layout (add_convT*): no other kernel may take this launch
-    if (!gemm_dma_supported(p, sp))
-      throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
-    op.kernel = std::string("gemm_dma<co256,px128,") + (sp ? "x3>" : "x1>") + (pc.nsplit > 1 ? "+splitk" : "");
-    op.run = [p](hipStream_t st) { return launch_gemm_dma(p, st); };
-  } else if (tile == 5 || (!(std::getenv("VP_CONVT_RS") && std::getenv("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
-    if (!convt_rs_supported(p, sp))
-      throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
-    op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
-    op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
-  } else {
-    const int epi = (ks == 1 && !sp) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
-    op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
-                std::to_string(conv_tile_px(tile)) + (sp ? ",x3" : ",x1") + (epi ? ",regepi" + std::to_string(epi) + ">" : ">") +
-                (pc.nsplit > 1 ? "+splitk" : "");
-    if (fuse_decode) {
-      op.kernel += "+decode";
-      op.run = [this, p, tile, bk, sp](hipStream_t st) {
-        ConvGemmParams q = p;
-        q.decode_mode = decode_mode_;
-        return launch_conv_gemm(q, tile, bk, sp, st);
-      };
-    } else {
-      op.run = [p, tile, bk, sp](hipStream_t st) { return launch_conv_gemm(p, tile, bk, sp, st); };
-    }
-  }
-  ops_.push_back(std::move(op));
-}
-
-// w: [cout][cin][ks][ks] fp32 (already BN-folded where applicable), b: [cout]
-Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout, int ks,
-                      const ConvOpts& o, Act* out_override) {
-  const int cin = in->Creal, cin_pad = in->C;
-  if (w.size() != (size_t)cout * cin * ks * ks) throw std::runtime_error("conv weight size mismatch: " + name);
-  const int cstride = std::max(1, o.stride);
-  if (cstride > 1 && (ks != 3 || in->H % cstride || in->W % cstride)) throw std::invalid_argument("strided conv: 3x3 on even maps only: " + name);
-  const int M = (in->H / cstride) * (in->W / cstride);
-  const int ncols = round_up(cout, 32);
-  PackedConv pc;
-  const int taps = ks * ks;
-  // ---- 3x3: LDS-resident halo kernel (kernels_conv3x3.hip) unless overridden (tile >= 100 selects a halo tile)
-  int halo = -1;
-  if (ks == 3 && cstride == 1 && in->H >= 8 && in->W >= 16) {
-    static const char* env = std::getenv("VP_CONV3X3");
-    const bool force_v1 = (env && std::strcmp(env, "v1") == 0) || (o.tile >= 0 && o.tile < 100);
-    if (o.tile >= 100) {
-      halo = o.tile - 100;
-    } else if (!force_v1) {
-      auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
-      const long long t256 = cdiv(in->H, 16) * cdiv(in->W, 16), t128 = cdiv(in->H, 8) * cdiv(in->W, 16);
-      if (ncols <= 32) {
-        halo = (std::getenv("VP_HEAD_TILE5") && t256 >= 400) ? 5 : 4;
-      } else if (ncols % 128 != 0) {
-        halo = (!split() && t256 * cdiv(ncols, 64) >= 400) ? 2 : 3;
-      } else {
-        halo = (!split() && t256 * (ncols / 128) >= 400) ? 0 : 1;
-        // fewer 128-channel tiles than CUs: 64-channel tiles double the workgroup count, so the layer needs no split-K
-        // (decode_layer_5: 46 us vs 57 us with a 3-way split) or half the split factor and half the fp32 partial
-        // traffic (neck layers at 20x40 / 40x80: -1..-5 us each; profiles/r01_splitk_ablation.txt)
-        if (halo == 1 && t128 * (ncols / 128) < 256) halo = 3;
-      }
-    }
-    if (halo >= 0 && split() && (halo == 0 || halo == 2)) halo += 1;
-    // parity mode, 128-channel tiles: the pipelined kernels of kernels_conv3x3_x3.hip -- halo tile 7 (8x16 patches, two
-    // independent workgroups per CU; also the split-K shape of the small-map layers) or 6 (16x16 patches, one 8-wave workgroup)
-    {
-      static const char* envx = std::getenv("VP_X3_TILE");  // developer knob: 0 = halo kernel, 6 / 7 = force that shape
-      auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
-      const long long wgs16 = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128), wgs8 = cdiv(in->H, 8) * cdiv(in->W, 16) * (ncols / 128);
-      // measured per layer (profiles/r02_layers_*): the 4-wave shape wins where the K loop is short (Cin <= 128: prologue and
-      // epilogue weigh most and two independent workgroups per CU overlap them), the 8-wave shape elsewhere (half the weight
-      // staging per MFMA)
-      const int want = envx ? std::atoi(envx) : (cin_pad <= 128 ? 7 : 6);
-      const bool plain = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
-      if (split() && o.tile < 0 && want != 0 && (halo == 1 || halo == 3) && ncols % 128 == 0 && !o.logits_out && !o.in2) {
-        // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured
-        // on MI355X, the 4-wave shape without split-K took 139 vs 100 us on decode_layer_5 (200 patches) and its split-K form
-        // (kernel support kept, tile 107 + nsplit) 63 vs 47 / 79 vs 70 us on decode_layer_1 / 3 (profiles/r02_splitk_x3w4.txt)
-        static const char* envw = std::getenv("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
-        if (plain && wgs16 >= (envw ? std::atoi(envw) : 160)) halo = want == 6 ? 6 : 7;
-        (void)wgs8;
-      }
-    }
-    if (halo >= 6 && halo <= 8 && !split()) throw std::invalid_argument("halo tiles 6 - 8 are fp16x3 kernels: " + name);
-  }
-  if (halo >= 0) {
-    pc.tile = 100 + halo;
-    pc.bk = 32;
-    pc.CoutW = round_up(ncols, halo_tile_co(halo));
-    const int KC = cin_pad / 32;
-    const long long blocks = (long long)((in->H + halo_tile_th(halo) - 1) / halo_tile_th(halo)) * ((in->W + 15) / 16) *
-                             (pc.CoutW / halo_tile_co(halo));
-    // split-K: aim at ONE machine-wide wave of workgroups (256); go towards two only while the K loop per slice stays
-    // long (> 6 chunks = 54 tap steps), and keep the fp32 partials (written + re-read by the finish kernel at
-    // ~4.5 TB/s) under ~24 MB.  Measured per layer in profiles/r01_splitk_ablation.txt.
-    int ns = 1;
-    if (o.nsplit > 0) {
-      ns = o.nsplit;
-    } else if (halo == 4 && o.logits_out && cout <= 4 && (cin_pad == 64 || cin_pad == 128) && o.res_mode == RES_NONE && o.act == ACT_NONE &&
-               cstride == 1 && !(std::getenv("VP_HEAD_CONV") && std::getenv("VP_HEAD_CONV")[0] == '0')) {
-      ns = 1;  // a head's logits convolution goes to kernels_head.hip (persistent workgroups: needs no split on any map size)
-    } else if (blocks < 256 && split()) {
-      // parity mode (measured per layer with VP_NSPLIT_FORCE = 1..16, profiles/r02_splitk_sweep_fp16x3.txt): ONE full round of
-      // workgroups at two per CU -- ns = floor(512 / blocks), at most one slice per input chunk.  A little past 512 (the fp16
-      // rule gave 540 / 600 workgroups on the 20x40 / 40x80 layers) a second, nearly empty round costs 10-20 % of the layer.
-      ns = (int)std::max<long long>(1, 512 / blocks);
-      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
-      while (ns > 2 && ns * slice_mb > 24.0) --ns;
-    } else if (blocks < 256) {
-      ns = (int)((256 + blocks - 1) / blocks);
-      while (KC / ns > 6 && blocks * ns < 512) ++ns;
-      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
-      while (ns > 2 && ns * slice_mb > 24.0) --ns;
-      ns = std::min(ns, std::max(1, KC / 2));
-    }
-    if (const char* e = std::getenv("VP_NSPLIT_PCT")) {  // developer knob (split-K sweeps): percentage applied to the heuristic's factor
-      if (o.nsplit <= 0 && ns > 1) ns = std::max(1, (int)(ns * std::atoi(e) / 100.0 + 0.5));
-    }
-    if (const char* e = std::getenv("VP_NSPLIT_FORCE")) {  // developer knob: one factor for every layer the heuristic splits
-      if (o.nsplit <= 0 && ns > 1) ns = std::max(1, std::atoi(e));
-    }
-    pc.nsplit = std::max(1, std::min(ns, KC));
-    if (halo == 6) pc.nsplit = 1;  // one 8-wave workgroup per CU, >= 160 tiles: no split-K shape
-    // 64-channel tiles of the parity mode: the pipelined kernel's 64-channel shape (halo tile 8: same tiles, same split factor as
-    // halo tile 3, three workgroups per CU).  Measured on MI355X (SceneSeg, us, halo tile 3 -> tile 8): decode_layer_0..3 70.5 /
-    // 48.1 / 82.6 / 60.2 -> 77.9 / 54.6 / 90.2 / 65.6, decode_layer_5 98.6 -> 106.5, decode_layer_9 (128 -> 64 channels on
-    // 320x640) 108.0 -> 102.2; 389 -> 381 frames/s with it everywhere.  So: only the short-K big-map case (as for tile 7);
-    // VP_X3_C64=1 wherever the epilogue fits (plain, or anything behind split-K), =0 nowhere.
-    if (halo == 3 && split() && o.tile < 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 && cstride == 1) {
-      const char* e8 = std::getenv("VP_X3_C64");
-      const bool plain8 = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
-      const bool fits = plain8 || pc.nsplit > 1;
-      const bool want8 = e8 ? e8[0] == '1' : (pc.nsplit == 1 && cin_pad <= 128 && M >= 65536);
-      if (fits && want8) {
-        halo = 8;
-        pc.tile = 108;
-      }
-    }
-  } else {
-    choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
-  }
-  std::vector<half_t> hi((size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci)
-      for (int t = 0; t < taps; ++t) {
-        const float v = w[((size_t)co * cin + ci) * taps + t];
-        // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
-        // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
-        // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-        const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
-        const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
-                                   : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
-        half_t h, l;
-        split_half(v, &h, &l);
-        hi[d] = h;
-        if (split()) lo[d] = l;
-      }
-  std::vector<float> bias(pc.CoutW, 0.0f);
-  for (int co = 0; co < cout; ++co) bias[co] = b[co];
-  pc.w_hi = dupload(hi);
-  pc.w_lo = split() ? dupload(lo) : nullptr;
-  pc.bias = dupload(bias);
-  Act* out = nullptr;
-  int store = STORE_NHWC;
-  if (o.logits_out) {
-    store = STORE_NCHW_F32;
-  } else {
-    out = out_override ? out_override : new_act(name, cout, in->H / cstride, in->W / cstride);
-  }
-  push_conv_op(name, in, pc, ks, ncols, o, out, store, cout);
-  return out;
-}
-
-// The small-map up-sampling GEMMs go to the LDS-DMA pipelined kernel (kernels_gemm_dma.hip; tile 6).  Measured per layer on
-// MI355X (SceneSeg neck, us, old -> new): parity mode 42.1 / 41.0 / 42.2 -> 37.9 / 37.7 / 37.7 and +2.8 % frames/s with three
-// frames in flight (fewer workgroups at a higher rate leave CUs to the other frames); fp16 30.4 / 23.4 / 25.4 -> 26.8 / 26.8 /
-// 21.7: the fp16 engines take it from 2048 pixels up only.  VP_GEMM_DMA=1: wherever the shape fits, =0: never.
-bool Engine::gemm_dma_wanted(int H, int W, int ncols, int cin_pad, int cin2_pad, int cstore) const {
-  const int M = H * W;
-  const char* e = std::getenv("VP_GEMM_DMA");
-  if (e && e[0] == '0') return false;
-  if (!split() && M < 2048 && !(e && e[0] == '1')) return false;
-  const char* rs = std::getenv("VP_CONVT_RS");  // the register-stationary kernel's shapes are its own (and keep the plain weight layout)
-  if (!(rs && rs[0] == '0') && convt_rs_shape_case(H, W, cin_pad, cin2_pad, ncols, cstore) != 0) return false;
-  return gemm_dma_shape_ok(M, ncols, cin_pad, cin2_pad, cstore);
-}
-
-// split-K factor of that kernel: towards ~160 workgroups while a slice keeps >= 8 K steps (VP_GEMM_DMA_NSPLIT: developer knob)
-int Engine::gemm_dma_nsplit(int M, int ncols, int kw) const {
-  if (const char* e = std::getenv("VP_GEMM_DMA_NSPLIT")) return std::max(1, std::atoi(e));
-  const int tiles = ((M + 127) / 128) * (ncols / 256), steps = kw / 32;
-  int ns = 1;
-  while (tiles * ns < 128 && steps / (ns + 1) >= 8) ++ns;
-  return ns;
-}
-
-// ConvTranspose2d(k2,s2): w [cin][cout][2][2] -> GEMM rows n = (dy*2+dx)*Cout_pad + co over input pixels.
-Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
-                       const ConvOpts& o) {
-  const int cin = in->Creal, cin_pad = in->C;
-  if (w.size() != (size_t)cin * cout * 4) throw std::runtime_error("convT weight size mismatch: " + name);
-  Act* out = new_act(name, cout, in->H * 2, in->W * 2);
-  const int cpad = out->C;
-  const int ncols = 4 * cpad;
-  PackedConv pc;
-  ConvOpts oo = o;
-  oo.pixel_shuffle = true;
-  // parity mode: 128-channel tiles with 32-channel K blocks (measured with VP_CONVT_TILE / VP_CONVT_BK over all tiles:
-  // upsample_layer_4 80.9 -> 62.5 us, upsample_layer_1 + skip 54.7 -> 41.6 us, the others unchanged)
-  if (split() && oo.tile < 0 && ncols % 128 == 0) {
-    oo.tile = 0;
-    if (oo.bk < 0) oo.bk = 32;
-  }
-  if (gemm_dma_wanted(in->H, in->W, ncols, cin_pad, 0, cpad) && o.tile < 0) {
-    oo.tile = 6;
-    oo.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad);
-  }
-  if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
-  if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
-  choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, oo, &pc);
-  if (pc.tile == 6 && !(gemm_dma_shape_ok(in->H * in->W, ncols, cin_pad, 0, cpad) && pc.CoutW == ncols))  // before the weights are packed in its layout
-    throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
-  std::vector<half_t> hi((size_t)pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
-  std::vector<float> bias(pc.CoutW, 0.0f);
-  for (int q = 0; q < 4; ++q)
-    for (int co = 0; co < cout; ++co) {
-      const int n = q * cpad + co;
-      bias[n] = b[co];
-      for (int ci = 0; ci < cin; ++ci) {
-        const float v = w[((size_t)ci * cout + co) * 4 + q];  // [ci][co][dy][dx], q = dy*2+dx
-        half_t h, l;
-        split_half(v, &h, &l);
-        const size_t d = pc.tile == 6 ? gemm_dma_pack_index(n, ci, cin_pad) : (size_t)n * cin_pad + ci;
-        hi[d] = h;
-        if (split()) lo[d] = l;
-      }
-    }
-  pc.w_hi = dupload(hi);
-  pc.w_lo = split() ? dupload(lo) : nullptr;
-  pc.bias = dupload(bias);
-  push_conv_op(name, in, pc, 1, ncols, o, out, STORE_SHUFFLE2, cout);
-  return out;
-}
-
-// d = ConvTranspose2d(k2,s2)(x) + Conv1x1(skip) in ONE GEMM (scene_neck.py:29-31 and the other up/skip pairs): the
-// skip conv's input channels are appended to the K axis (kernels_conv.hip, K extension), biases are summed.  The
-// intermediate up-sampled tensor is never written or re-read (it was the largest HBM stream of these layers) and the
-// skip-link launch disappears.  Falls back to the two-op form when a workgroup's channel tile would straddle
-// pixel-shuffle quadrants.
-Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_name, const Act* in, const Act* skip_in,
-                            const std::vector<float>& wt, const std::vector<float>& bt, const std::vector<float>& ws,
-                            const std::vector<float>& bs, int cout) {
-  const int cin = in->Creal, cin_pad = in->C, cs = skip_in->Creal, cs_pad = skip_in->C;
-  if (wt.size() != (size_t)cin * cout * 4) throw std::runtime_error("convT weight size mismatch: " + up_name);
-  if (ws.size() != (size_t)cout * cs) throw std::runtime_error("skip conv weight size mismatch: " + skip_name);
-  if (skip_in->H != in->H * 2 || skip_in->W != in->W * 2) throw std::runtime_error("skip tensor size mismatch: " + skip_name);
-  static const char* env = std::getenv("VP_FUSE_SKIP");
-  const int cpad = round_up(cout, 32);
-  const int ncols = 4 * cpad;
-  ConvOpts o;
-  o.in2 = skip_in;
-  if ((cin_pad | cs_pad) % 64 != 0) o.bk = 32;  // K steps must not straddle the two tensors
-  if (split() && ncols % 128 == 0) {  // parity mode: see add_convT
-    o.tile = 0;
-    o.bk = 32;
-  }
-  if (gemm_dma_wanted(in->H, in->W, ncols, cin_pad, cs_pad, cpad)) {
-    o.tile = 6;
-    o.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad + cs_pad);
-  }
-  if (const char* e = std::getenv("VP_CONVT_TILE")) o.tile = std::atoi(e);
-  PackedConv pc;
-  choose_conv_cfg(in->H * in->W, ncols, cin_pad + cs_pad, 1, o, &pc);
-  if (pc.tile == 6 && !(gemm_dma_shape_ok(in->H * in->W, ncols, cin_pad, cs_pad, cpad) && pc.CoutW == ncols))
-    throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): shape not covered: " + up_name);
-  const bool fusable = (cpad % conv_tile_co(pc.tile) == 0 && !(env && env[0] == '0')) || pc.tile == 6;
-  if (!fusable) {
-    Act* u = add_convT(up_name, in, wt, bt, cout, ConvOpts{});
-    ConvOpts so;
-    so.res_mode = RES_ADD;
-    so.res = u;
-    add_conv(skip_name, skip_in, ws, bs, cout, 1, so, u);
-    return u;
-  }
-  Act* out = new_act(up_name, cout, in->H * 2, in->W * 2);
-  const int kw = cin_pad + cs_pad;
-  std::vector<half_t> hi((size_t)pc.CoutW * kw, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
-  std::vector<float> bias(pc.CoutW, 0.0f);
-  for (int q = 0; q < 4; ++q)
-    for (int co = 0; co < cout; ++co) {
-      const int n = q * cpad + co;
-      bias[n] = bt[co] + bs[co];
-      for (int k = 0; k < cin + cs; ++k) {
-        const float v = k < cin ? wt[((size_t)k * cout + co) * 4 + q] : ws[(size_t)co * cs + (k - cin)];
-        const size_t col = k < cin ? k : cin_pad + (k - cin);
-        half_t h, l;
-        split_half(v, &h, &l);
-        const size_t d = pc.tile == 6 ? gemm_dma_pack_index(n, (int)col, kw) : (size_t)n * kw + col;
-        hi[d] = h;
-        if (split()) lo[d] = l;
-      }
-    }
-  pc.w_hi = dupload(hi);
-  pc.w_lo = split() ? dupload(lo) : nullptr;
-  pc.bias = dupload(bias);
-  push_conv_op(up_name + "+" + skip_name.substr(skip_name.rfind('.') == std::string::npos ? 0 : skip_name.rfind('.') + 1), in, pc, 1, ncols, o,
-               out, STORE_SHUFFLE2, cout);
-  return out;
 }
 
 // ------------------------------------------------------------------------------------------------ backbone
@@ -1534,624 +1023,6 @@ void Engine::finish_plan() {
   }
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
   VP_HIP_CHECK(hipDeviceSynchronize());
-}
-
-// ------------------------------------------------------------------------------------------ frame handling
-void Engine::set_input_format(int pixel_format, int plane_order) {
-  if (pixel_format < 0 || pixel_format > 1 || plane_order < 0 || plane_order > 1) throw std::invalid_argument("bad input format");
-  if (pixel_format != pixel_format_ || plane_order != plane_order_) { graph_valid_ = false; ++plan_epoch_; }
-  pixel_format_ = pixel_format;
-  plane_order_ = plane_order;
-}
-void Engine::set_decode_mode(int mode) {
-  if (mode < 0 || mode > 2) throw std::invalid_argument("bad decode mode");
-  if (mode != decode_mode_) { graph_valid_ = false; ++plan_epoch_; }
-  decode_mode_ = mode;
-}
-
-// 11-bit fixed-point bilinear taps -- must stay bit-identical to oracle/pre_post.py linear_taps_u8.
-static void linear_taps_u8(int src, int dst, std::vector<int>* tab) {
-  tab->resize((size_t)dst * 4);
-  const double scale = (double)src / (double)dst;
-  for (int d = 0; d < dst; ++d) {
-    float f = (float)(((double)d + 0.5) * scale - 0.5);
-    int s = (int)std::floor(f);
-    f -= (float)s;
-    if (s < 0) {
-      f = 0.0f;
-      s = 0;
-    }
-    if (s >= src - 1) {
-      f = 0.0f;
-      s = src - 1;
-    }
-    (*tab)[4 * d + 0] = s;
-    (*tab)[4 * d + 1] = std::min(s + 1, src - 1);
-    (*tab)[4 * d + 2] = (int)std::nearbyint((1.0f - f) * 2048.0f);
-    (*tab)[4 * d + 3] = (int)std::nearbyint(f * 2048.0f);
-  }
-}
-
-// Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) in the same double arithmetic, operation for
-// operation (restated and pinned against PIL in oracle/pre_post.py pil_resample_coeffs): filter support scaled by the
-// down-scaling factor, taps normalised to sum 1, quantised to 22 fractional bits.  filter: 1 = BILINEAR, 2 = BICUBIC (a = -0.5).
-#pragma clang fp contract(off)
-int pil_coeffs(int in_size, int out_size, int filter, std::vector<int>* bounds, std::vector<int>* kk) {
-  auto weight = [filter](double x) -> double {
-    if (x < 0.0) x = -x;
-    if (filter == 1) return x < 1.0 ? 1.0 - x : 0.0;
-    const double a = -0.5;
-    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
-    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
-    return 0.0;
-  };
-  double filterscale = (double)in_size / out_size;
-  const double scale = filterscale;
-  if (filterscale < 1.0) filterscale = 1.0;
-  const double support = (filter == 1 ? 1.0 : 2.0) * filterscale;
-  const int ksize = (int)std::ceil(support) * 2 + 1;
-  bounds->assign((size_t)out_size * 2, 0);
-  kk->assign((size_t)out_size * ksize, 0);
-  std::vector<double> k(ksize);
-  const double ss = 1.0 / filterscale;
-  for (int xx = 0; xx < out_size; ++xx) {
-    const double center = (xx + 0.5) * scale;
-    double ww = 0.0;
-    int xmin = (int)(center - support + 0.5);
-    if (xmin < 0) xmin = 0;
-    int xmax = (int)(center + support + 0.5);
-    if (xmax > in_size) xmax = in_size;
-    xmax -= xmin;
-    for (int x = 0; x < xmax; ++x) {
-      const double w = weight((x + xmin - center + 0.5) * ss);
-      k[x] = w;
-      ww += w;
-    }
-    for (int x = 0; x < xmax; ++x) {
-      if (ww != 0.0) k[x] /= ww;
-      (*kk)[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << 22)) : (int)(0.5 + k[x] * (1 << 22));
-    }
-    (*bounds)[2 * xx] = xmin;
-    (*bounds)[2 * xx + 1] = xmax;
-  }
-  return ksize;
-}
-
-PilResampleParams Engine::pil_params(const PreprocessParams& pp) const {
-  PilResampleParams q{};
-  q.frame = pp.frame;
-  q.stride = pp.stride;
-  q.in_h = frame_h_;
-  q.in_w = frame_w_;
-  q.out_h = pp.out_h;
-  q.out_w = pp.out_w;
-  q.hb = d_pil_hb_;
-  q.hk = d_pil_hk_;
-  q.hks = pil_hks_;
-  q.vb = d_pil_vb_;
-  q.vk = d_pil_vk_;
-  q.vks = pil_vks_;
-  q.tmp = d_pil_tmp_;
-  for (int c = 0; c < 3; ++c) {
-    q.src_c[c] = pp.src_c[c];
-    q.mean[c] = pp.mean[c];
-    q.stdv[c] = pp.stdv[c];
-  }
-  q.out = pp.out;
-  return q;
-}
-
-void Engine::set_resize_mode(int mode) {
-  if (mode < 0 || mode > 2) throw std::invalid_argument("resize mode: 0 = cv::resize INTER_LINEAR model, 1 = PIL BILINEAR, 2 = PIL BICUBIC");
-  if (base_) throw std::invalid_argument("shared engine: the base engine owns the frame path");
-  if (mode != resize_mode_) {
-    resize_mode_ = mode;
-    tab_h_ = tab_w_ = 0;
-    graph_valid_ = false;
-    ++plan_epoch_;
-  }
-}
-
-void Engine::ensure_tables(int h, int w) {
-  if (h == tab_h_ && w == tab_w_) return;
-  if (resize_mode_ != 0) {  // Pillow's resample: per-output tap tables for both passes + the u8 image between them
-    std::vector<int> hb, hk, vb, vk;
-    pil_hks_ = pil_coeffs(w, net_w(), resize_mode_, &hb, &hk);
-    pil_vks_ = pil_coeffs(h, net_h(), resize_mode_, &vb, &vk);
-    VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    d_pil_hb_ = dupload(hb);
-    d_pil_hk_ = dupload(hk);
-    d_pil_vb_ = dupload(vb);
-    d_pil_vk_ = dupload(vk);
-    d_pil_tmp_ = static_cast<uint8_t*>(dalloc((size_t)h * net_w() * 3, false));
-    tab_h_ = h;
-    tab_w_ = w;
-    return;
-  }
-  std::vector<int> xt, yt;
-  linear_taps_u8(w, net_w(), &xt);
-  linear_taps_u8(h, net_h(), &yt);
-  if (!d_xtab_) {
-    d_xtab_ = static_cast<int*>(dalloc(net_w() * 4 * sizeof(int)));
-    d_ytab_ = static_cast<int*>(dalloc(net_h() * 4 * sizeof(int)));
-  }
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  VP_HIP_CHECK(hipMemcpy(d_xtab_, xt.data(), xt.size() * sizeof(int), hipMemcpyHostToDevice));
-  VP_HIP_CHECK(hipMemcpy(d_ytab_, yt.data(), yt.size() * sizeof(int), hipMemcpyHostToDevice));
-  tab_h_ = h;
-  tab_w_ = w;
-}
-
-void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int index) {
-  if (base_) throw std::invalid_argument("shared engine: frames go to the base engine (vp_infer on the base, then vp_infer_shared)");
-  if (!frame || h < 2 || w < 2 || stride < 3 * w) throw std::invalid_argument("bad frame geometry");
-  if (index < 0 || index >= frames_) throw std::invalid_argument("frame index out of range");
-  VP_HIP_CHECK(hipSetDevice(gpu_));
-  const size_t need = (size_t)h * stride;
-  if ((h != frame_h_ || w != frame_w_ || stride != frame_stride_) && frames_ > 1 && index != 0 && frame_h_ != 0)
-    throw std::invalid_argument("batched encoder: all frames of a pass share one geometry (upload slot 0 first to change it)");
-  if (need * frames_ > frame_cap_) {
-    VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    d_frame_ = static_cast<uint8_t*>(dalloc(need * frames_, true));
-    frame_cap_ = need * frames_;
-    { graph_valid_ = false; ++plan_epoch_; }
-  }
-  if (h != frame_h_ || w != frame_w_ || stride != frame_stride_) { graph_valid_ = false; ++plan_epoch_; }
-  ensure_tables(h, w);
-  frame_h_ = h;
-  frame_w_ = w;
-  frame_stride_ = stride;
-  // A strided view (cv::Mat ROI, numpy slice) guarantees only (h-1)*stride + 3*w readable bytes: the tail of the last row
-  // belongs to the parent image or to nobody.  Packed frames go as one copy, views row by row (hipMemcpy2D).
-  // The caller's buffer is pageable (cv::Mat); the copy is staged through this engine's pinned buffer so the transfer
-  // itself is one DMA that overlaps other engines' kernels (the reference does the same H2D: tensorrt_backend.cpp:184-186).
-  uint8_t* dst = d_frame_ + (size_t)index * need;
-  const size_t packed = (size_t)(h - 1) * stride + (size_t)3 * w;
-  if (pinned_staging_) {
-    if (need > h_frame_cap_) {
-      VP_HIP_CHECK(hipStreamSynchronize(stream_));
-      if (h_frame_) hipHostFree(h_frame_);
-      h_frame_ = nullptr;
-      VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_frame_), need * 2, hipHostMallocDefault));  // two slots: frame n+1 is staged while n flies
-      h_frame_cap_ = need;
-    }
-    h_frame_slot_ ^= 1;
-    uint8_t* slot = h_frame_ + (size_t)h_frame_slot_ * h_frame_cap_;
-    // A pinned source makes the H2D below truly asynchronous: the copy that last read this slot (two uploads ago) may still be
-    // queued behind earlier frames' graphs.  Its event orders this host write behind it.
-    if (!h_frame_ev_[h_frame_slot_]) VP_HIP_CHECK(hipEventCreateWithFlags(&h_frame_ev_[h_frame_slot_], hipEventDisableTiming));
-    else VP_HIP_CHECK(hipEventSynchronize(h_frame_ev_[h_frame_slot_]));
-    if (stride == 3 * w) {
-      std::memcpy(slot, frame, packed);
-    } else {
-      for (int y = 0; y < h; ++y) std::memcpy(slot + (size_t)y * stride, frame + (size_t)y * stride, (size_t)3 * w);
-    }
-    VP_HIP_CHECK(hipMemcpyAsync(dst, slot, packed, hipMemcpyHostToDevice, stream_));
-    VP_HIP_CHECK(hipEventRecord(h_frame_ev_[h_frame_slot_], stream_));
-  } else if (stride == 3 * w) {
-    VP_HIP_CHECK(hipMemcpyAsync(dst, frame, packed, hipMemcpyHostToDevice, stream_));
-  } else {
-    VP_HIP_CHECK(hipMemcpy2DAsync(dst, stride, frame, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, stream_));
-  }
-  if (input_is_tensor_) { graph_valid_ = false; ++plan_epoch_; }
-  input_is_tensor_ = false;
-}
-
-void Engine::upload_tensor(const float* nchw) {
-  if (base_) throw std::invalid_argument("shared engine: tensors go to the base engine");
-  if (frames_ > 1) throw std::invalid_argument("batched encoder: frames only (vp_upload_frame_n)");
-  if (!nchw) throw std::invalid_argument("null tensor");
-  VP_HIP_CHECK(hipSetDevice(gpu_));
-  VP_HIP_CHECK(hipMemcpyAsync(d_input_, nchw, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyHostToDevice, stream_));
-  if (!input_is_tensor_) { graph_valid_ = false; ++plan_epoch_; }
-  input_is_tensor_ = true;
-}
-
-void Engine::run_ops(hipStream_t st, size_t begin, size_t end) {
-  for (size_t i = begin; i < end; ++i) {
-    hipError_t e = ops_[i].run(st);
-    if (e != hipSuccess) throw std::runtime_error("launch failed in layer '" + ops_[i].name + "': " + hipGetErrorString(e));
-  }
-}
-void Engine::run_eager() { run_ops(stream_, input_is_tensor_ ? first_net_op_ : 0, ops_.size()); }
-
-// One frame through this engine AND its shared-prefix heads as ONE graph launch on this engine's stream (so every stream-order
-// guarantee of the separate vp_enqueue calls holds).  Inside the graph the heads that consume only the backbone (shared level 1:
-// Scene3D, EgoLanes on a SceneSeg base) are forked onto side streams right behind the backbone and joined at the end: a single
-// frame's two or three decoders overlap (the small-map neck layers and the 200-tile big layers leave CUs idle on their own).
-// Same kernels, same arguments, same results as base.enqueue() followed by head.enqueue().
-void Engine::enqueue_multi(const std::vector<Engine*>& heads) {
-  VP_HIP_CHECK(hipSetDevice(gpu_));
-  if (base_) throw std::invalid_argument("enqueue_multi: call it on the engine that owns the encoder");
-  for (Engine* h : heads)
-    if (!h || h->base_ != this || h->stream_ != stream_) throw std::invalid_argument("enqueue_multi: every head must be a shared-prefix engine of this engine");
-  bool plain = !multi_fork_ || !use_graph_ || !warmed_ || kind_ == 4 || frames_ > 1 || n_fork_ops_ == 0 || heads.empty();
-  for (Engine* h : heads) plain = plain || !h->warmed_ || !h->use_graph_;
-  if (plain) {  // first frames (eager warm-up), graph replay switched off, or nothing to fork
-    enqueue();
-    for (Engine* h : heads) h->enqueue();
-    return;
-  }
-  if (!input_is_tensor_ && !d_frame_) throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
-  std::vector<std::pair<const Engine*, unsigned long long>> key{{this, plan_epoch_}};
-  for (Engine* h : heads) key.emplace_back(h, h->plan_epoch_);
-  if (!multi_exec_ || key != multi_key_) {
-    if (multi_exec_) hipGraphExecDestroy(multi_exec_);
-    if (multi_graph_) hipGraphDestroy(multi_graph_);
-    multi_exec_ = nullptr;
-    multi_graph_ = nullptr;
-    size_t n_side = 0;
-    for (Engine* h : heads) n_side += h->shared_level_ == 1 ? 1 : 0;
-    while (side_streams_.size() < n_side) {
-      hipStream_t s = nullptr;
-      VP_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-      side_streams_.push_back(s);
-    }
-    while (side_events_.size() < n_side + 1) {
-      hipEvent_t e = nullptr;
-      VP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      side_events_.push_back(e);
-    }
-    VP_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-    try {
-      const size_t first = input_is_tensor_ ? first_net_op_ : 0;
-      run_ops(stream_, first, n_fork_ops_);
-      VP_HIP_CHECK(hipEventRecord(side_events_[0], stream_));
-      size_t si = 0;
-      for (Engine* h : heads)
-        if (h->shared_level_ == 1) {
-          VP_HIP_CHECK(hipStreamWaitEvent(side_streams_[si], side_events_[0], 0));
-          h->run_ops(side_streams_[si], 0, h->ops_.size());
-          VP_HIP_CHECK(hipEventRecord(side_events_[1 + si], side_streams_[si]));
-          ++si;
-        }
-      run_ops(stream_, n_fork_ops_, ops_.size());
-      for (Engine* h : heads)
-        if (h->shared_level_ != 1) h->run_ops(stream_, 0, h->ops_.size());  // needs this engine's context + neck: behind them, in order
-      for (size_t i = 0; i < si; ++i) VP_HIP_CHECK(hipStreamWaitEvent(stream_, side_events_[1 + i], 0));
-    } catch (...) {
-      hipGraph_t g = nullptr;
-      hipStreamEndCapture(stream_, &g);
-      if (g) hipGraphDestroy(g);
-      throw;
-    }
-    VP_HIP_CHECK(hipStreamEndCapture(stream_, &multi_graph_));
-    VP_HIP_CHECK(hipGraphInstantiate(&multi_exec_, multi_graph_, nullptr, nullptr, 0));
-    multi_key_ = key;
-  }
-  VP_HIP_CHECK(hipGraphLaunch(multi_exec_, stream_));
-  have_outputs_ = true;
-  host_logits_valid_ = host_mask_valid_ = false;
-  for (Engine* h : heads) {
-    h->have_outputs_ = true;
-    h->host_logits_valid_ = h->host_mask_valid_ = false;
-  }
-}
-
-void Engine::capture_graph() {
-  if (graph_exec_) {
-    hipGraphExecDestroy(graph_exec_);
-    graph_exec_ = nullptr;
-  }
-  if (graph_) {
-    hipGraphDestroy(graph_);
-    graph_ = nullptr;
-  }
-  VP_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-  try {
-    run_eager();
-  } catch (...) {
-    hipGraph_t g = nullptr;
-    hipStreamEndCapture(stream_, &g);
-    if (g) hipGraphDestroy(g);
-    throw;
-  }
-  VP_HIP_CHECK(hipStreamEndCapture(stream_, &graph_));
-  VP_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
-  graph_valid_ = true;
-}
-
-void Engine::enqueue() {
-  VP_HIP_CHECK(hipSetDevice(gpu_));
-  if (base_) {
-    if (!base_->have_outputs_) throw std::runtime_error("shared engine: run the base engine on a frame first");
-  } else if (!input_is_tensor_ && !d_frame_) {
-    throw std::runtime_error("no frame resident: call vp_upload_frame / vp_infer first");
-  }
-  if (kind_ == 4 && !ad_primed_) prime_previous();  // first frame of a stream: previous := current
-  if (!warmed_) {  // first pass is eager: sets kernel attributes and surfaces launch errors with layer names
-    run_eager();
-    VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    warmed_ = true;
-    have_outputs_ = true;
-    host_logits_valid_ = host_mask_valid_ = false;
-    if (!use_graph_ || kind_ == 4) return;  // AutoDrive carries state (feature shift): a frame must run exactly once
-  }
-  if (use_graph_) {
-    if (!graph_valid_) capture_graph();
-    VP_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_));
-  } else {
-    run_eager();
-  }
-  have_outputs_ = true;
-  host_logits_valid_ = host_mask_valid_ = false;
-}
-
-void Engine::sync() {
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  check_status();
-}
-
-// The probe's verdict on the pass whose outputs were last fetched (enqueue_fetch copies the flag behind them).  Loud, once: the flag is
-// cleared so that the next frame is judged on its own.
-void Engine::check_status() {
-  if (!status_pending_ || !h_status_) return;
-  status_pending_ = false;
-  if (*h_status_ == 0) return;
-  *h_status_ = 0;
-  VP_HIP_CHECK(hipMemsetAsync(d_status_, 0, sizeof(unsigned), stream_));
-  throw RangeError("non-finite value (inf / NaN) in the network output: an activation left the fp16 range of the matrix pipe (|x| > 65504) "
-                   "or the input / weights were not finite; outputs of this frame are invalid");
-}
-
-void Engine::fetch_outputs() {
-  if (!d_logits_) throw std::runtime_error("this engine has no outputs (batched encoder: fetch from its shared-prefix engines)");
-  enqueue_fetch();
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  check_status();
-}
-
-// D2H of the outputs the caller selected (vp_set_outputs), asynchronous on the engine stream, into pinned host memory.
-void Engine::enqueue_fetch() {
-  if (!d_logits_) throw std::runtime_error("this engine has no outputs (batched encoder: fetch from its shared-prefix engines)");
-  if (outputs_ & 1)
-    VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
-  if ((outputs_ & 2) && d_mask_) VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
-  host_logits_valid_ = (outputs_ & 1) != 0;
-  host_mask_valid_ = (outputs_ & 2) != 0;
-  if (finite_check_ && d_status_) {
-    VP_HIP_CHECK(hipMemcpyAsync(h_status_, d_status_, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
-    status_pending_ = true;
-  }
-}
-
-// Lazy variants behind vp_logits / vp_mask_u8: an output de-selected with vp_set_outputs is fetched on first use.
-const float* Engine::host_logits() {
-  if (!host_logits_valid_ && d_logits_ && have_outputs_) {
-    VP_HIP_CHECK(hipSetDevice(gpu_));
-    VP_HIP_CHECK(hipMemcpyAsync(h_logits_, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    host_logits_valid_ = true;
-  }
-  return h_logits_;
-}
-const uint8_t* Engine::host_mask() {
-  if (!host_mask_valid_ && d_mask_ && have_outputs_) {
-    VP_HIP_CHECK(hipSetDevice(gpu_));
-    VP_HIP_CHECK(hipMemcpyAsync(h_mask_, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToHost, stream_));
-    VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    host_mask_valid_ = true;
-  }
-  return h_mask_;
-}
-
-void Engine::copy_outputs_device(void* logits_dst, void* mask_dst) {
-  if (logits_dst)
-    VP_HIP_CHECK(hipMemcpyAsync(logits_dst, d_logits_, (size_t)out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToDevice, stream_));
-  if (mask_dst) VP_HIP_CHECK(hipMemcpyAsync(mask_dst, d_mask_, (size_t)out_h_ * out_w_, hipMemcpyDeviceToDevice, stream_));
-}
-
-void Engine::read_input_tensor(float* dst) {
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  VP_HIP_CHECK(hipMemcpy(dst, d_input_, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyDeviceToHost));
-}
-
-// OpenCV resizeNN index table (oracle/pre_post.py nearest_index)
-static void nearest_tab(int src, int dst, int* tab) {
-  const double inv = (double)dst / (double)src;
-  const double ifx = 1.0 / inv;
-  for (int d = 0; d < dst; ++d) tab[d] = std::min((int)std::floor(d * ifx), src - 1);
-}
-static void linear_taps_f32(int src, int dst, int* idx, float* wgt) {
-  const double scale = (double)src / (double)dst;
-  for (int d = 0; d < dst; ++d) {
-    float f = (float)(((double)d + 0.5) * scale - 0.5);
-    int s = (int)std::floor(f);
-    f -= (float)s;
-    if (s < 0) {
-      f = 0.0f;
-      s = 0;
-    }
-    if (s >= src - 1) {
-      f = 0.0f;
-      s = src - 1;
-    }
-    idx[2 * d] = s;
-    idx[2 * d + 1] = std::min(s + 1, src - 1);
-    wgt[2 * d] = 1.0f - f;
-    wgt[2 * d + 1] = f;
-  }
-}
-
-void Engine::mask_resized(uint8_t* dst, int h, int w) {
-  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
-  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
-  const size_t need = (size_t)h * w, tabn = (size_t)(h + w);
-  if (need > resize_cap_) {
-    d_resize_out_ = dalloc(std::max(need, (size_t)4 * h * w), false);
-    resize_cap_ = std::max(need, (size_t)4 * h * w);
-  }
-  if (tabn * 4 > rs_tab_cap_) {
-    d_rs_tab_ = static_cast<int*>(dalloc(tabn * 4 * sizeof(int), false));
-    rs_tab_cap_ = tabn * 4;
-  }
-  std::vector<int> tab(h + w);
-  nearest_tab(out_h_, h, tab.data());
-  nearest_tab(out_w_, w, tab.data() + h);
-  VP_HIP_CHECK(hipMemcpyAsync(d_rs_tab_, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-  VP_HIP_CHECK(launch_resize_nearest(d_mask_, out_w_, d_rs_tab_, d_rs_tab_ + h, h, w, static_cast<uint8_t*>(d_resize_out_), stream_));
-  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, need, hipMemcpyDeviceToHost, stream_));
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-// MasksVisualizationEngine::visualize on the device: the mask of the LAST inference, coloured, nearest-resized to the frame
-// that produced it and blended 50/50 with that (still resident) frame; BGR8 out, frame size.
-void Engine::visualize_mask(int viz_type, uint8_t* dst, int dst_h, int dst_w) {
-  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
-  if (!dst || viz_type < 0 || viz_type > 2) throw std::invalid_argument("bad visualisation request");
-  if (!d_frame_ || input_is_tensor_ || base_) throw std::runtime_error("visualize_mask needs the frame path (vp_infer) on a base engine");
-  const int h = frame_h_, w = frame_w_;
-  // The blend writes h*w*3 bytes: the caller's buffer must have the geometry of the frame that was inferred last (the
-  // reference takes the size from original_image itself, masks_visualization_engine.cpp:19-27, so it cannot mismatch).
-  if (dst_h != h || dst_w != w)
-    throw std::invalid_argument("visualize_mask: destination is " + std::to_string(dst_w) + "x" + std::to_string(dst_h) +
-                                " but the last inferred frame was " + std::to_string(w) + "x" + std::to_string(h));
-  if (!d_viz_lut_) {
-    // createColorMask (masks_visualization_engine.cpp:41-58), BGR
-    std::vector<uint8_t> lut(3 * 256 * 3, 0);
-    for (int v = 1; v < 256; ++v) { lut[(0 * 256 + v) * 3 + 2] = 255; }                          // "scene": 1..255 -> (0,0,255)
-    const uint8_t dom0[3] = {255, 93, 61}, dom255[3] = {145, 28, 255};                            // "domain"
-    for (int c = 0; c < 3; ++c) { lut[(1 * 256 + 0) * 3 + c] = dom0[c]; lut[(1 * 256 + 255) * 3 + c] = dom255[c]; }
-    const uint8_t ego[3][3] = {{255, 0, 0}, {255, 0, 200}, {0, 153, 0}};                          // "egolanes": labels 0,1,2
-    for (int v = 0; v < 3; ++v)
-      for (int c = 0; c < 3; ++c) lut[(2 * 256 + v) * 3 + c] = ego[v][c];
-    d_viz_lut_ = dupload(lut);
-  }
-  const size_t need = (size_t)3 * h * w, tabn = (size_t)(h + w);
-  if (need > resize_cap_) {
-    d_resize_out_ = dalloc(std::max(need, (size_t)4 * h * w), false);
-    resize_cap_ = std::max(need, (size_t)4 * h * w);
-  }
-  if (tabn * 4 > rs_tab_cap_) {
-    d_rs_tab_ = static_cast<int*>(dalloc(tabn * 4 * sizeof(int), false));
-    rs_tab_cap_ = tabn * 4;
-  }
-  std::vector<int> tab(h + w);
-  nearest_tab(out_h_, h, tab.data());
-  nearest_tab(out_w_, w, tab.data() + h);
-  VP_HIP_CHECK(hipMemcpyAsync(d_rs_tab_, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-  VP_HIP_CHECK(launch_viz_blend(d_mask_, out_w_, d_rs_tab_, d_rs_tab_ + h, d_frame_, frame_stride_, h, w, d_viz_lut_ + (size_t)viz_type * 768,
-                                pixel_format_ == 1, static_cast<uint8_t*>(d_resize_out_), stream_));
-  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, need, hipMemcpyDeviceToHost, stream_));
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-void Engine::resize_depth_on_device(int h, int w) {
-  const size_t need = (size_t)4 * h * w, tabn = (size_t)4 * (h + w);
-  if (need > resize_cap_) {
-    d_resize_out_ = dalloc(need, false);
-    resize_cap_ = need;
-  }
-  if (tabn > rs_tab_cap_) {
-    d_rs_tab_ = static_cast<int*>(dalloc(tabn * sizeof(int), false));
-    rs_tab_cap_ = tabn;
-  }
-  // host tap tables are members: they must outlive the asynchronous copies (every caller syncs the stream before returning)
-  std::vector<int>& idx = rs_idx_host_;
-  std::vector<float>& wgt = rs_wgt_host_;
-  idx.assign(2 * (h + w), 0);
-  wgt.assign(2 * (h + w), 0.f);
-  linear_taps_f32(out_h_, h, idx.data(), wgt.data());
-  linear_taps_f32(out_w_, w, idx.data() + 2 * h, wgt.data() + 2 * h);
-  int* d_idx = d_rs_tab_;
-  float* d_wgt = reinterpret_cast<float*>(d_rs_tab_ + 2 * (h + w));
-  VP_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-  VP_HIP_CHECK(hipMemcpyAsync(d_wgt, wgt.data(), wgt.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-  VP_HIP_CHECK(launch_resize_bilinear_f32(d_logits_, out_w_, d_idx, d_wgt, d_idx + 2 * h, d_wgt + 2 * h, h, w,
-                                          static_cast<float*>(d_resize_out_), stream_));
-}
-
-void Engine::depth_resized(float* dst, int h, int w) {
-  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
-  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
-  resize_depth_on_device(h, w);
-  VP_HIP_CHECK(hipMemcpyAsync(dst, d_resize_out_, (size_t)4 * h * w, hipMemcpyDeviceToHost, stream_));
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-// DepthVisualizationEngine::visualize (depth_visualization_engine.cpp:9-26) on the device: plane 0 of the logits,
-// bilinear-resized to h x w (what the depth topic carries, run_model_node.cpp:100-104), min-max normalised to u8 and
-// mapped through COLORMAP_VIRIDIS; BGR8 out.
-void Engine::visualize_depth(uint8_t* dst, int h, int w) {
-  if (!have_outputs_) throw std::runtime_error("Inference has not been run yet");
-  if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad visualisation target");
-  static const uint8_t kViridisBgr[256 * 3] = {
-#include "viridis_lut.inc"
-  };
-  if (!d_viridis_) {
-    d_viridis_ = dupload(std::vector<uint8_t>(kViridisBgr, kViridisBgr + sizeof(kViridisBgr)));
-    d_minmax_ = static_cast<unsigned*>(dalloc(2 * sizeof(unsigned), false));
-  }
-  const size_t n = (size_t)h * w;
-  if (3 * n > depth_viz_cap_) {
-    d_depth_viz_ = dalloc(3 * n, false);
-    depth_viz_cap_ = 3 * n;
-  }
-  resize_depth_on_device(h, w);
-  static const unsigned kInit[2] = {0xFFFFFFFFu, 0u};
-  VP_HIP_CHECK(hipMemcpyAsync(d_minmax_, kInit, sizeof(kInit), hipMemcpyHostToDevice, stream_));
-  VP_HIP_CHECK(launch_minmax_f32(static_cast<const float*>(d_resize_out_), n, d_minmax_, stream_));
-  VP_HIP_CHECK(launch_depth_colorize(static_cast<const float*>(d_resize_out_), n, d_minmax_, d_viridis_, static_cast<uint8_t*>(d_depth_viz_), stream_));
-  VP_HIP_CHECK(hipMemcpyAsync(dst, d_depth_viz_, 3 * n, hipMemcpyDeviceToHost, stream_));
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
-// -------------------------------------------------------------------------------------------------- timing
-void Engine::timer_begin() { VP_HIP_CHECK(hipEventRecord(ev0_, stream_)); }
-float Engine::timer_end() {
-  VP_HIP_CHECK(hipEventRecord(ev1_, stream_));
-  VP_HIP_CHECK(hipEventSynchronize(ev1_));
-  float ms = 0.f;
-  VP_HIP_CHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
-  return ms;
-}
-
-int Engine::profile_layers(int iters, float* ms, int cap) {
-  const size_t first = input_is_tensor_ ? first_net_op_ : 0;
-  const int n = (int)ops_.size();
-  if (cap < n) throw std::invalid_argument("profile buffer too small");
-  if (base_) {
-    if (!base_->have_outputs_) throw std::runtime_error("shared engine: run the base engine on a frame first");
-  } else if (!input_is_tensor_ && !d_frame_) {
-    throw std::runtime_error("no frame resident");
-  }
-  std::vector<hipEvent_t> ev(n + 1);
-  for (auto& e : ev) VP_HIP_CHECK(hipEventCreate(&e));
-  std::vector<double> acc(n, 0.0);
-  for (int it = 0; it < iters + 1; ++it) {  // iteration 0 is a warm-up
-    for (int i = (int)first; i < n; ++i) {
-      VP_HIP_CHECK(hipEventRecord(ev[i], stream_));
-      hipError_t e = ops_[i].run(stream_);
-      if (e != hipSuccess) throw std::runtime_error("launch failed in layer '" + ops_[i].name + "'");
-    }
-    VP_HIP_CHECK(hipEventRecord(ev[n], stream_));
-    VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    if (it == 0) continue;
-    for (int i = (int)first; i < n; ++i) {
-      float t = 0.f;
-      VP_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
-      acc[i] += t;
-    }
-  }
-  for (int i = 0; i < n; ++i) ms[i] = (float)(acc[i] / std::max(1, iters));
-  for (auto& e : ev) hipEventDestroy(e);
-  warmed_ = true;
-  have_outputs_ = true;
-  return n;
-}
-
-void Engine::read_act(int i, float* dst) {
-  if (i < 0 || i >= (int)acts_.size()) throw std::invalid_argument("tensor index out of range");
-  const Act& a = *acts_[i];
-  const size_t n = (size_t)a.Creal * a.H * a.W;
-  float* d = nullptr;
-  VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  VP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
-  hipError_t e = launch_act_to_nchw(a.view(), a.Creal, d, stream_);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream_);
-  if (e == hipSuccess) e = hipMemcpy(dst, d, n * sizeof(float), hipMemcpyDeviceToHost);
-  hipFree(d);
-  VP_HIP_CHECK(e);
 }
 
 }  // namespace vp

@@ -58,10 +58,25 @@ def workload_gflop(kinds):
     return sum(FRAME_GFLOP[k] for k in kinds) - BACKBONE_GFLOP * (len(kinds) - 1)
 
 
+def kernel_source_hash():
+    """sha256 over the device sources of libvp_hip.so (csrc/*.hip, *.hpp): tools/pmc_summarize.py stamps the PMC file with it, and a
+    file taken on other sources is ignored (roofline.traffic = null) instead of going silently stale."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "autoware_vision_pilot_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(tag):
     """HBM-side bytes per launch of the kernel instantiation behind ``tag`` from the committed rocprofv3 PMC passes
     (profiles/r0N_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
-    1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  None if not profiled."""
+    1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  The file must carry the hash of
+    the CURRENT kernel sources (kernel_source_hash); None if not profiled on them."""
     m8 = re.match(r"conv3x3_x3w(8|4)<", tag)
     m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
     if m8:
@@ -76,11 +91,14 @@ def pmc_traffic(tag):
         else:
             pat = (rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'}, "
                    rf"\d, (true|false), {m.group(5) or 0}>")
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
-        ks = json.load(open(path))["kernels"]
+        doc = json.load(open(path))
+        if doc.get("source_hash") != kernel_source_hash():
+            continue  # counters taken on OTHER kernel sources say nothing about the kernels this run timed
+        ks = doc["kernels"]
         hit = [v for k, v in ks.items() if re.search(pat, k)]
         n = sum(v["launches_seen"] for v in hit)
         if not n:
@@ -193,11 +211,26 @@ def main():
     Camera.fork = not args.no_fork
     Camera.fork_all = args.fork_all
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: one rank per GPU, launched here (the driver's torch.distributed.run form sets the
+        # same variables and comes in through the branch below); rank 0 prints the JSON line on the inherited stdout
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.dup2(json_out.fileno(), 1)
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        raise SystemExit(max(p.wait() for p in procs))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -337,6 +370,64 @@ def main():
             for h in c.heads:
                 h.set_outputs(True, True)
 
+    # ---- north_star's target configuration beside the metric's: SceneSeg + Scene3D (shared encoder) + EgoLanes on one camera.
+    # EgoLanes owns its backbone (ego_lanes_network.py:14-15 builds its own Backbone; its checkpoint carries other encoder weights) and
+    # is fed RGB planes (onnxruntime_engine.cpp:80-100): a SECOND base engine with its own weights, stream and preprocess, not a head
+    # grafted onto SceneSeg's encoder.  957.6 GFLOP per frame.  N = 1 only.
+    three = None
+    if args.workload == "seg+3d" and not args.no_secondary and world == 1:
+        ego_blob = vw.pack_state_dict(synthetic.make_state_dict("egolanes", SEEDS["egolanes"]))
+        egos = []
+        for _ in range(nstreams):
+            e = lib.Engine("egolanes", ego_blob, precision=args.precision, gpu_id=local_rank)
+            e.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB)
+            e.upload_frame(frame)
+            for _ in range(2):
+                e.enqueue()
+            e.sync()
+            egos.append(e)
+
+        def run3(slots, steps):
+            for c, e in slots:
+                c.sync()
+                e.sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                c, e = slots[i % len(slots)]
+                c.enqueue()
+                e.enqueue()
+            for c, e in slots:
+                c.sync()
+                e.sync()
+            return time.perf_counter() - t0
+
+        slots = list(zip(cams, egos))
+        for c in cams:
+            c.set_fork(False)
+        run3(slots, 30)
+        k3 = max(60, int(math.ceil(1.15 * args.min_seconds / (run3(slots, 20) / 20))))
+        el3 = run3(slots, k3)
+        cams[0].set_fork(True)           # one camera, one frame at a time: Scene3D forked behind the encoder, EgoLanes on its own stream
+        lat3 = []
+        for i in range(10 + max(20, args.latency_iters // 2)):
+            t1 = time.perf_counter()
+            cams[0].enqueue()
+            egos[0].enqueue()
+            cams[0].sync()
+            egos[0].sync()
+            if i >= 10:
+                lat3.append((time.perf_counter() - t1) * 1e3)
+        cams[0].set_fork(False)
+        g3 = workload_gflop(kinds) + FRAME_GFLOP["egolanes"]
+        three = {"three_heads_fps": round(k3 / el3, 2), "three_heads_p50_ms": round(float(np.percentile(lat3, 50)), 4),
+                 "three_heads_gflop_per_frame": round(g3, 1),
+                 "three_heads_whole_frame_frac": round(g3 * (k3 / el3) / 1e3 / PEAK_FP16_TFLOPS, 4),
+                 "three_heads_note": ("BASELINE configs[2] / north_star target: SceneSeg + Scene3D on a shared encoder + EgoLanes on ITS OWN "
+                                      "backbone weights and RGB-plane preprocess (a second base engine on its own stream), one 1280x720 "
+                                      f"camera, {args.precision}; fps with {nstreams} cameras in flight, p50 one frame at a time")}
+        for e in egos:
+            e.close()
+
     # ---- roofline of the dominant kernel family of the REPORTED precision: per-launch HIP events (eager replay, one stream)
     out = None
     if rank == 0:
@@ -422,7 +513,10 @@ def main():
                            "(vp_enqueue_multi / vp_infer_multi, the default) -- same kernels, bit-identical results"
                            + ("" if Camera.fork else "; --no-fork: forking disabled everywhere")),
             "roofline": roofline,
+            "rccl_world": world if args.gather else 0,
         }
+        if three is not None:
+            out.update(three)
         if h2h is not None:
             out["host_to_host_fps"] = round(h2h["fps"], 2)
             out["host_to_host_p50_ms"] = round(h2h["p50"], 4)

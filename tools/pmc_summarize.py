@@ -42,6 +42,9 @@ for k in sorted(set(fetch) | set(write)):
     out["kernels"][name] = {"launches_seen": max(len(fv), len(wv)),
                             "fetch_bytes": round(sum(fv) / max(1, len(fv)) * 1024.0 * f_factor),
                             "write_bytes": round(sum(wv) / max(1, len(wv)) * 1024.0 * w_factor)}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_hash: bench.py ignores a PMC file taken on other kernel sources)
+out["source_hash"] = bench.kernel_source_hash()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["calibration"]))
 for k, v in sorted(out["kernels"].items(), key=lambda kv: -(kv[1]["fetch_bytes"] + kv[1]["write_bytes"]) * kv[1]["launches_seen"])[:12]:
