@@ -69,10 +69,6 @@ struct ConvGemmParams {
   int decode_mode;
   // >= 16 bytes of zeros in device memory (the engine's zero page): LDS-DMA source for pixels outside the map (kernels_conv3x3_x3.hip)
   const half_t* zeros;
-  // split-K without a finish launch: one arrival counter per output tile (zero between launches).  The workgroup that arrives LAST on
-  // a tile sums the nsplit partial slabs in the fixed order z = 0..nsplit-1 and runs the epilogue (conv_epilogue.hpp splitk_arrive_and_finish);
-  // nullptr = separate splitk_finish_kernel launch
-  unsigned* tile_count;
 };
 
 // nn.GELU() (exact erf form, scene_neck.py:8).  ~300 M activations per frame: libm's erff (~45 VALU ops, branchy)

@@ -16,7 +16,6 @@
 #include <type_traits>
 
 #include "kernels.hpp"
-#include "lds_dma.hpp"
 
 namespace vp {
 
@@ -172,54 +171,6 @@ __device__ __forceinline__ void epilogue_rows(const ConvGemmParams& p, const cha
       float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
       epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1);
     }
-  }
-}
-
-// Split-K WITHOUT a finish launch.  Every workgroup of a split layer calls this (all NTH threads) after it has stored its fp32 partial tile to
-// p.partial[z][pixel][CoutW]: it takes a ticket on the tile's arrival counter; the workgroup that arrives LAST (ticket nsplit - 1) adds the
-// nsplit slabs of the tile in the FIXED order z = 0 .. nsplit-1 -- its own included, read back from memory, so the sum does not depend on
-// who arrived last: bit-identical to splitk_finish_kernel -- and runs the shared epilogue (bias, activation, residual, (hi, lo) split, any
-// store mode).  The separate finish kernel cost 5-9 us per layer inside the replayed graph (launch boundary + a grid that re-reads every
-// slab; 11 encoder + 14 decoder launches per SceneSeg + Scene3D frame, profiles/r03_trace_sceneseg_fp16x3_single_stream.tsv); here the
-// tail is one tile's slabs (<= 0.3 MB, L2 / Infinity-Cache resident) read by a workgroup that is already on the machine.
-// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility"): plain stores; every thread drains vmcnt; barrier; lane 0: agent-scope
-// release fence + drained vmcnt + relaxed agent-scope ticket; the last arriver: agent-scope acquire fence, barrier, plain loads.  It also
-// clears the counter for the next launch.  PixMap(r) = linear pixel of tile row r, or -1 outside the map.
-template <int NTH, int PXT, class PixMap>
-__device__ __forceinline__ void splitk_arrive_and_finish(const ConvGemmParams& p, int tile_id, const PixMap& pix, int co0, int co_n, int M) {
-  __shared__ int sk_last;
-  VP_DRAIN_VMEM();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    VP_FENCE_RELEASE_AGENT();
-    VP_DRAIN_VMEM();
-    const unsigned ticket = VP_FLAG_ADD(p.tile_count + tile_id, 1u);
-    const int last = ticket == (unsigned)p.nsplit - 1u;
-    if (last) {
-      VP_FENCE_ACQUIRE_AGENT();
-      VP_FLAG_STORE(p.tile_count + tile_id, 0u);
-    }
-    sk_last = last;
-  }
-  __syncthreads();
-  if (!sk_last) return;
-  const int groups = co_n >> 3;
-  for (int idx = threadIdx.x; idx < PXT * groups; idx += NTH) {
-    const int r = idx / groups, co = co0 + (idx - r * groups) * 8;
-    const int m = pix(r);
-    if (m < 0 || co >= p.Ncols) continue;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.nsplit; ++z) {
-      const float* src = p.partial + ((size_t)z * M + m) * p.CoutW + co;
-      const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(src), q1 = *reinterpret_cast<const f32x4_t*>(src + 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] += q0[k];
-        v[4 + k] += q1[k];
-      }
-    }
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
-    epilogue_store8(p, M, m, co, v, b0, b1);
   }
 }
 

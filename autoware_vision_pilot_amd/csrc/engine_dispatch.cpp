@@ -89,12 +89,6 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   }
   const int M = p.H * p.W;
   p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
-  // split-K layers finish in the workgroup that arrives last on a tile (conv_epilogue.hpp splitk_arrive_and_finish): one zeroed arrival
-  // counter per output tile (no tile is smaller than 64 pixels x 32 channels).  VP_SPLITK_FOLD=0 (developer knob, A/B timing): the
-  // separate splitk_finish_kernel launch.
-  static const char* env_fold = std::getenv("VP_SPLITK_FOLD");
-  if (pc.nsplit > 1 && !(env_fold && env_fold[0] == '0'))
-    p.tile_count = static_cast<unsigned*>(dalloc((size_t)((M + 63) / 64) * ((pc.CoutW + 31) / 32) * sizeof(unsigned), true));
   const int tile = pc.tile, bk = pc.bk;
   const bool sp = split();
   Op op;

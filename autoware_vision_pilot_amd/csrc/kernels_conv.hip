@@ -257,7 +257,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   } else {
 #pragma unroll
     for (int i = 0; i < MT; ++i) epilogue_pass<PX_TILE, WCO, NT>(p, smem, acc[i], co0 + i * WCO * 32, wco, wpx, pix, M, zsplit);
-    if (p.nsplit > 1 && p.tile_count != nullptr) splitk_arrive_and_finish<256, PX_TILE>(p, tile_px + n_px_tiles * tile_co, pix, co0, CO_TILE, M);
   }
 }
 
@@ -315,7 +314,7 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (p.nsplit > 1 && p.tile_count == nullptr) e = launch_splitk_finish(p, st);
+  if (p.nsplit > 1) e = launch_splitk_finish(p, st);
   return e;
 }
 

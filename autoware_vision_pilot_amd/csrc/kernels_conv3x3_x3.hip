@@ -343,7 +343,6 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
           *reinterpret_cast<f32x4_t*>(row + (i * WCO + wco) * 32 + 8 * g) = v;
         }
     }
-    if (p.tile_count != nullptr) splitk_arrive_and_finish<NTH, PX>(p, tile_px + n_px_tiles * tile_co, pixs, co0, CO_TILE, M);
     return;
   }
   __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
@@ -411,7 +410,7 @@ static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return (sk && p.tile_count == nullptr) ? launch_splitk_finish(p, st) : hipSuccess;
+  return sk ? launch_splitk_finish(p, st) : hipSuccess;
 }
 
 // shape 6: 16x16 pixels, 8 waves, one workgroup per CU; shape 7: 8x16 pixels, 4 waves, two independent workgroups per CU;

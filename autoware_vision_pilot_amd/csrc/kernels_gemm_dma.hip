@@ -212,7 +212,6 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (p.tile_count != nullptr) splitk_arrive_and_finish<512, PX_T>(p, tile_px + n_px_tiles * tile_co, PixLinear{m0, M}, co0, CO_T, M);
     return;
   }
   // the bias is added in the accumulator layout, BEFORE the row loop: a register loaded from global memory and used inside the
@@ -299,7 +298,7 @@ hipError_t launch_gemm_dma_cfg(const ConvGemmParams& p, hipStream_t st) {
   const int M = p.H * p.W;
   hipLaunchKernelGGL(k, dim3(((M + 127) / 128) * (p.Ncols / 256) * p.nsplit), dim3(512), lds, st, p);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && p.nsplit > 1 && p.tile_count == nullptr) e = launch_splitk_finish(p, st);
+  if (e == hipSuccess && p.nsplit > 1) e = launch_splitk_finish(p, st);
   return e;
 }
 }  // namespace

@@ -15,17 +15,4 @@
 // tile the other waves are about to read); ds_write / ds_read are drained by lgkmcnt(0); the "memory" clobber keeps the
 // compiler from moving memory operations across.
 #define VP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// ---- hand-off between workgroups (stream-K slabs, split-K "last arriver"): MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
-// inter-workgroup visibility".  Per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores.
-//   producer: plain stores; VP_DRAIN_VMEM() in every thread; __syncthreads(); ONE lane: VP_FENCE_RELEASE_AGENT(); VP_DRAIN_VMEM();
-//             VP_FLAG_STORE(flag, v)
-//   consumer: ONE lane polls VP_FLAG_LOAD(flag); VP_FENCE_ACQUIRE_AGENT(); __syncthreads(); plain loads
-// VP_DRAIN_VMEM is INLINE ASM on purpose: a __builtin_amdgcn_s_waitcnt in front of the release lets the compiler prove the wave's vmcnt
-// scoreboard empty and drop the wait behind buffer_wbl2, so the flag can overtake the write-back (ROCm 7.2 hazard, same section).
-#define VP_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define VP_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
-#define VP_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-#define VP_FLAG_STORE(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define VP_FLAG_LOAD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define VP_FLAG_ADD(P, V) __hip_atomic_fetch_add((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif

@@ -472,45 +472,6 @@ int vp_tensor_read(vp_engine* e, int i, float* dst) {
   return guarded(e, [&](vp::Engine& g) { g.read_act(i, dst); });
 }
 
-// mode-0 convolution of n_in inputs, `rounds` times over, through ONE engine (one plan, one workspace): out[round][input].  What a
-// single-shot entry cannot show: state a kernel leaves behind for its next launch (stream-K slabs and flags).
-int vp_op_conv2d_repeat(int gpu_id, int precision, const float* in, int n_in, int rounds, int cin, int h, int w, const float* weight,
-                        const float* bias, int cout, int ks, int act, int tile, int bk, int nsplit, float* out, char* err, size_t err_len) {
-  if (!in || !weight || !bias || !out || cin < 1 || cout < 1 || h < 1 || w < 1 || n_in < 1 || rounds < 1) {
-    set_err(err, err_len, "bad argument");
-    return VP_ERR_ARG;
-  }
-  try {
-    vp::Engine g(-1, nullptr, precision, gpu_id);
-    vp::Act* a = g.new_act("in", cin, h, w);
-    vp::ConvOpts o;
-    o.act = act;
-    o.tile = tile;
-    o.bk = bk;
-    o.nsplit = nsplit;
-    const size_t wn = (size_t)cin * cout * ks * ks, in_n = (size_t)cin * h * w, out_n = (size_t)cout * h * w;
-    vp::Act* y = g.add_conv("op", a, std::vector<float>(weight, weight + wn), std::vector<float>(bias, bias + cout), cout, ks, o);
-    int idx = -1;
-    for (size_t i = 0; i < g.acts().size(); ++i)
-      if (g.acts()[i].get() == y) idx = (int)i;
-    for (int r = 0; r < rounds; ++r)
-      for (int i = 0; i < n_in; ++i) {
-        g.upload_act(a, in + (size_t)i * in_n);
-        g.run_eager();
-        g.run_eager();  // back to back: the second launch starts on the first one's flags and slabs
-        g.sync();
-        g.read_act(idx, out + ((size_t)r * n_in + i) * out_n);
-      }
-    return VP_OK;
-  } catch (const std::invalid_argument& ex) {
-    set_err(err, err_len, ex.what());
-    return VP_ERR_ARG;
-  } catch (const std::exception& ex) {
-    set_err(err, err_len, ex.what());
-    return VP_ERR_HIP;
-  }
-}
-
 int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out, char* err,
                  size_t err_len) {

@@ -87,8 +87,6 @@ _SIGS = {
     "vp_tensor_read": (C.c_int, [_P, C.c_int, _P]),
     "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
-    "vp_op_conv2d_repeat": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
     "vp_version": (C.c_char_p, []),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
@@ -518,24 +516,6 @@ def op_conv2d(x, weight, bias, ks=3, mode=0, act=0, res=None, res_mode=0, precis
                           _ptr(r) if r is not None else None, tile, bk, nsplit, _ptr(out), err, len(err))
     if rc != 0:
         raise VpError(f"vp_op_conv2d failed ({rc}): {err.value.decode(errors='replace')}")
-    return out
-
-
-def op_conv2d_repeat(xs, weight, bias, ks=3, act=0, precision=VP_FP16, tile=-1, bk=-1, nsplit=-1, rounds=2, gpu_id=0):
-    """vp_op_conv2d_repeat: the conv operator on every input of `xs`, `rounds` times over, through ONE plan and workspace.
-    Returns out[round][input] (arrays [Cout][h][w])."""
-    lib = load()
-    x = np.ascontiguousarray(np.stack(xs), dtype=np.float32)
-    weight = np.ascontiguousarray(weight, dtype=np.float32)
-    bias = np.ascontiguousarray(bias, dtype=np.float32)
-    n, cin, h, w = x.shape
-    cout = weight.shape[0]
-    out = np.empty((rounds, n, cout, h, w), dtype=np.float32)
-    err = C.create_string_buffer(512)
-    rc = lib.vp_op_conv2d_repeat(gpu_id, precision, _ptr(x), n, rounds, cin, h, w, _ptr(weight), _ptr(bias), cout, ks, act, tile, bk, nsplit,
-                                 _ptr(out), err, len(err))
-    if rc != 0:
-        raise VpError(f"vp_op_conv2d_repeat failed ({rc}): {err.value.decode(errors='replace')}")
     return out
 
 

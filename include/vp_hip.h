@@ -268,12 +268,6 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,
                  char* err, size_t err_len);
 
-/* the mode-0 operator on n_in inputs ([n_in][Cin][h][w]), `rounds` times over, through ONE plan and workspace; out is
- * [rounds][n_in][Cout][h][w].  Tests of what a kernel leaves behind for its next launch (stream-K slabs and flags). */
-int vp_op_conv2d_repeat(int gpu_id, int precision, const float* in, int n_in, int rounds, int cin, int h, int w, const float* weight,
-                        const float* bias, int cout, int ks, int act, int tile, int bk, int nsplit, float* out, char* err,
-                        size_t err_len);
-
 const char* vp_version(void);
 
 #ifdef __cplusplus

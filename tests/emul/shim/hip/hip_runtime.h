@@ -448,16 +448,9 @@ F4 mfma_16x16x32_f16(H8 a, H8 b, F4 c) {
 #define VP_GLOBAL_LOAD_LDS16(G, L) std::memcpy(reinterpret_cast<char*>(L) + 16 * (threadIdx.x & 63), reinterpret_cast<const char*>(G), 16)
 #define VP_WAIT_VMCNT(N) ((void)0)
 #define VP_LDS_BARRIER() __syncthreads()
-// hand-off between workgroups (lds_dma.hpp): workgroups run on different OS threads here, so the flag carries the ordering itself
-#define VP_DRAIN_VMEM() ((void)0)
-#define VP_FENCE_RELEASE_AGENT() __atomic_thread_fence(__ATOMIC_RELEASE)
-#define VP_FENCE_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_ACQUIRE)
-#define VP_FLAG_STORE(P, V) __atomic_store_n((P), (V), __ATOMIC_RELEASE)
-#define VP_FLAG_LOAD(P) __atomic_load_n((P), __ATOMIC_ACQUIRE)
-#define VP_FLAG_ADD(P, V) __atomic_fetch_add((P), (V), __ATOMIC_ACQ_REL)
 #define __builtin_amdgcn_s_memrealtime() 0ull
 #define __builtin_amdgcn_wave_barrier() emu::sync_wave()  // lanes of a wave run in lockstep on the device; here they must meet
-#define __builtin_amdgcn_s_sleep(x) std::this_thread::yield()
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0u
 
 #define threadIdx (emu::cur->tid)

@@ -204,23 +204,3 @@ def test_gemm_dma_kernel(emu_lib, precision, monkeypatch):
     monkeypatch.setenv("VP_GEMM_DMA", "1")
     with pytest.raises(emu_lib.VpError):
         _case(emu_lib, 256, 96, 9, 15, 2, 1, 0, 0, precision, [(6, -1, 1)], seed=55)                # 4 * 96 rows: not a multiple of 256
-
-
-
-
-def test_splitk_fold_leaves_no_state(emu_lib):
-    """Split-K finishes in the workgroup that arrives last on a tile (conv_epilogue.hpp splitk_arrive_and_finish): arrival counters
-    back at zero after every launch, no slab of the previous frame in the next frame's sums -- one plan, three frames, two rounds,
-    each launch issued twice back to back; every split kernel (halo tiles, the pipelined 4-wave shape, the generic GEMM)."""
-    rng = np.random.default_rng(61)
-    xs = [rng.standard_normal((96, 12, 18), dtype=np.float32) * np.float32(s) for s in (1.0, 0.25, 3.0)]
-    wt = rng.standard_normal((128, 96, 3, 3), dtype=np.float32) * np.float32(0.05)
-    b = rng.standard_normal((128,), dtype=np.float32) * np.float32(0.1)
-    for tile, ns in ((101, 3), (103, 2), (107, 3), (108, 3), (1, 2)):
-        refs = [emu_lib.op_conv2d(v, wt, b, ks=3, act=1, precision=1, tile=tile, nsplit=1) for v in xs]
-        outs = emu_lib.op_conv2d_repeat(xs, wt, b, ks=3, act=1, precision=1, tile=tile, nsplit=ns, rounds=2)
-        for r in range(2):
-            for o, ref in zip(outs[r], refs):
-                assert np.abs(o - ref).max() <= 4e-6 * max(1.0, np.abs(ref).max()), (tile, r)
-        for i in range(3):
-            assert np.array_equal(outs[0][i], outs[1][i]), tile

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Developer tool: what would perfect hiding of the encoder buy in the several-cameras mode?  SceneSeg + Scene3D, parity mode, three
+cameras in flight: (a) the full frame (encoder + both decoders), (b) the two decoders alone on resident encoder taps -- a second Scene3D
+decoder (other weights) stands in for SceneSeg's (a shared engine with SceneSeg's own context / neck would share those too); 397 + 397
+against 367 + 397 GFLOP -- and (c) the encoder alone.  (b) is the rate at which the decoders leave the machine when no encoder launch
+competes with them."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: F401,E402
+import torch  # noqa: F401,E402
+
+from autoware_vision_pilot_amd import lib, synthetic, weights as vw  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
+sd_seg = synthetic.make_state_dict("sceneseg", 0)
+sd_a = synthetic.share_backbone(synthetic.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")
+sd_b = synthetic.share_backbone(synthetic.make_state_dict("scene3d", 7), "scene3d", sd_seg, "sceneseg")
+b_seg, b_a, b_b = (vw.pack_state_dict(s) for s in (sd_seg, sd_a, sd_b))
+frame = synthetic.synthetic_frame(720, 1280, 1)
+groups = []
+for _ in range(3):
+    base = lib.Engine("sceneseg", b_seg, precision=prec)
+    base.set_multi_fork(False)
+    ha = lib.Engine("scene3d", b_a, precision=prec, base=base)
+    hb = lib.Engine("scene3d", b_b, precision=prec, base=base)
+    base.upload_frame(frame)
+    for _ in range(2):
+        base.enqueue_multi([ha])
+    base.sync()
+    for _ in range(2):
+        ha.enqueue()
+        hb.enqueue()
+    base.sync()
+    groups.append((base, ha, hb))
+
+
+def timed(fn, n):
+    for g in groups:
+        g[0].sync()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(groups[i % 3])
+    for g in groups:
+        g[0].sync()
+    return (time.perf_counter() - t0) / n
+
+
+legs = (("full frame (SceneSeg + Scene3D, shared encoder)", lambda g: g[0].enqueue_multi([g[1]])),
+        ("two decoders alone (Scene3D x 2 on resident taps)", lambda g: (g[1].enqueue(), g[2].enqueue())),
+        ("encoder + SceneSeg decoder (base engine alone)", lambda g: g[0].enqueue()))
+for name, fn in legs:
+    timed(fn, 60)
+    dt = timed(fn, 600)
+    print(f"{name}: {1.0 / dt:.1f} per s = {dt * 1e6:.1f} us each, three in flight, {prec}")
