@@ -59,16 +59,15 @@ def workload_gflop(kinds):
 
 
 def kernel_source_hash():
-    """sha256 over the device sources of libvp_hip.so (csrc/*.hip, *.hpp): tools/pmc_summarize.py stamps the PMC file with it, and a
-    file taken on other sources is ignored (roofline.traffic = null) instead of going silently stale."""
-    import glob
+    """sha256 over the sources the 3x3 convolution kernels -- the roofline kernels -- are built from: tools/pmc_summarize.py stamps the
+    PMC file with it, and a file taken on other sources is ignored (roofline.traffic = null) instead of going silently stale."""
     import hashlib
 
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "autoware_vision_pilot_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in ("kernels_conv3x3_x3.hip", "kernels_conv3x3.hip", "conv_epilogue.hpp", "lds_dma.hpp", "common.hpp"):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -1,0 +1,70 @@
+// Developer tool: is the fp16 matrix pipe of THIS GPU clock-limited by power?  A bare v_mfma_f32_32x32x16_f16 loop (random fp16 operands,
+// 2 waves per SIMD, 4 independent accumulators per wave: the pipe issues back to back) on N of the 256 CUs, N = 32 .. 256: TFLOP/s, TFLOP/s
+// per active CU and the shader clock read inside the kernel (s_memtime ticks against the 100 MHz s_memrealtime).  If the chip holds its
+// clock, TFLOP/s grows linearly with N at 9.8 TFLOP/s per CU (2.4 GHz x 4 SIMDs x 1024 FLOP/cycle); if it is power-limited, the clock
+// falls as N grows and the last CUs add little -- the regime in which filling idle CUs (stream-K, more frames in flight) cannot pay.
+// Also: the same loop with all-zero operands (no toggling -> no throttle) as the control.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_power.hip -o tools/_mfma_power
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512, 2) void mfma_loop(const h8* src, float* out, long long* clk, int iters) {
+  const h8 a = src[threadIdx.x], b = src[512 + threadIdx.x];
+  f16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  const long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c3, 0, 0, 0);
+  }
+  const long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  float s = 0;
+  for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
+}
+
+int main() {
+  float* out;
+  long long* clk;
+  h8* src;
+  hipMalloc(&out, 256 * 512 * 4);
+  hipMallocManaged(&clk, 16);
+  hipMalloc(&src, 1024 * sizeof(h8));
+  std::vector<_Float16> h(1024 * 8);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int zero = 0; zero < 2; ++zero) {
+    unsigned s = 12345;
+    for (auto& v : h) {
+      s = s * 1664525u + 1013904223u;
+      v = zero ? (_Float16)0.0f : (_Float16)(((int)(s >> 9) % 2001 - 1000) * 0.001f);
+    }
+    hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    std::printf("# %s operands\n# active_CUs\tms\tTFLOP/s\tTFLOP/s_per_CU\tshader_clock_MHz\n", zero ? "all-zero" : "random fp16");
+    for (int n : {32, 64, 128, 192, 200, 224, 256}) {
+      const int iters = 40000;
+      hipLaunchKernelGGL(mfma_loop, dim3(n), dim3(512), 0, 0, src, out, clk, 4000);
+      hipDeviceSynchronize();
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(mfma_loop, dim3(n), dim3(512), 0, 0, src, out, clk, iters);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double flop = (double)n * 8 * iters * 4 * 32 * 32 * 16 * 2;
+      std::printf("%d\t%.3f\t%.1f\t%.2f\t%.0f\n", n, ms, flop / ms * 1e-9, flop / ms * 1e-9 / n, (double)clk[0] / clk[1] * 100.0);
+    }
+  }
+  return 0;
+}
