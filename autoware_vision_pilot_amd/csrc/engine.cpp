@@ -333,7 +333,15 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       const int cin = bi == 0 ? S.cin : S.cout, stride = bi == 0 ? S.s : 1, cexp = cin * S.e;
       int j = 0;
       const Act* y = x;
-      if (S.e != 1) {
+      // parity mode, one frame per pass: expand 1x1 -> depthwise (+ pool) as ONE launch, the expanded tensor never leaves the CU
+      // (kernels_mbconv.hip).  VP_MBCONV_FUSE=0 (developer knob, A/B timing): the two launches.
+      static const char* env_mb = std::getenv("VP_MBCONV_FUSE");
+      const bool fuse_front = S.e != 1 && split() && N == 1 && !(env_mb && env_mb[0] == '0');
+      Folded f_exp;
+      if (fuse_front) {
+        f_exp = fold_conv_bn(blob, bp + std::to_string(j));
+        ++j;
+      } else if (S.e != 1) {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         ConvOpts o;
         o.act = ACT_SILU;
@@ -362,6 +370,36 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           for (int t = 0; t < kk; ++t) wk[(size_t)t * z->C + c] = f.w[(size_t)c * kk + t];
           bk[c] = f.b[c];
         }
+        if (fuse_front) {
+          if (f_exp.cout != cexp || f_exp.cin != cin || f_exp.k != 1) throw std::runtime_error("expand conv shape mismatch: " + bp);
+          std::vector<half_t> wh((size_t)z->C * x->C, (half_t)0.0f), wlo(wh.size(), (half_t)0.0f);
+          std::vector<float> be(z->C, 0.0f);
+          for (int co = 0; co < cexp; ++co) {
+            for (int ci = 0; ci < cin; ++ci) split_half(f_exp.w[(size_t)co * cin + ci], &wh[(size_t)co * x->C + ci], &wlo[(size_t)co * x->C + ci]);
+            be[co] = f_exp.b[co];
+          }
+          MbFrontParams mp{};
+          mp.in = x->view();
+          mp.w_hi = dupload(wh);
+          mp.w_lo = dupload(wlo);
+          mp.b_exp = dupload(be);
+          mp.w_dw = dupload(wk);
+          mp.b_dw = dupload(bk);
+          mp.out = z->view();
+          mp.k = S.k;
+          mp.stride = stride;
+          mp.sums = sums;
+          mp.replicas = se_rep;
+          if (!mbconv_front_supported(mp)) throw std::runtime_error("fused MBConv front: unsupported shape: " + bp);
+          Op op;
+          op.name = bp + "0+" + std::to_string(j);   // expand + depthwise
+          op.flops = 2.0 * cexp * cin * x->H * x->W + 2.0 * kk * cexp * z->H * z->W;
+          op.bytes = 4.0 * (x->elems() + z->elems());
+          op.kernel = std::string("mbconv_front<k") + std::to_string(S.k) + ",s" + std::to_string(stride) + ">";
+          op.run = [mp](hipStream_t st) { return launch_mbconv_front(mp, st); };
+          ops_.push_back(std::move(op));
+          ++j;
+        } else {
         DwParams dp{};
         dp.in = ActView{y->hi, y->lo, y->H / N, y->W, y->C};   // per-frame geometry; the kernel's grid.z walks the frames
         dp.out = ActView{z->hi, z->lo, z->H / N, z->W, z->C};
@@ -381,6 +419,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         op.run = [dp](hipStream_t st) { return launch_dwconv(dp, st); };
         ops_.push_back(std::move(op));
         ++j;
+        }
       }
       // squeeze-excite -> per-frame scaled projection weights
       SeParams se{};

@@ -56,6 +56,20 @@ struct DwParams {
   int frames;
 };
 
+// MBConv front half in one launch (kernels_mbconv.hip): expand 1x1 + SiLU -> depthwise k x k / stride + SiLU -> SE pool sums
+struct MbFrontParams {
+  ActView in;           // block input, H x W x Cin_pad, (hi, lo)
+  const half_t* w_hi;   // expand weights [Cexp_pad][Cin_pad], BN folded, (hi, lo); zero rows / columns in the padding
+  const half_t* w_lo;
+  const float* b_exp;   // [Cexp_pad]
+  const float* w_dw;    // [k*k][Cexp_pad] fp32, BN folded
+  const float* b_dw;    // [Cexp_pad]
+  ActView out;          // H/stride x W/stride x Cexp_pad, (hi, lo)
+  int k, stride;
+  unsigned long long* sums;  // [replicas][Cexp_pad] fixed-point channel sums (as DwParams)
+  int replicas;
+};
+
 struct PoolParams {
   ActView in;
   float* partial;  // [nslab][C]
@@ -142,6 +156,8 @@ hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st);  // both passes
 hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
+bool mbconv_front_supported(const MbFrontParams& p);
+hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
 hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st);
 // The fused average pool spreads its atomics over `replicas` rows: same-address atomics serialise in L2 (measured:

@@ -1,0 +1,211 @@
+// MBConv front half in ONE launch: expand 1x1 (+BN +SiLU) -> depthwise k x k / stride s (+BN +SiLU) -> squeeze-excite pool sums
+// (torchvision efficientnet_b0().features[1..7], MBConv.block[0..1] + the average pool of block[2]; Models/model_components/backbone.py:9-22).
+//
+// The encoder is 0.4 % of a frame's FLOPs and a third of one camera's latency: a chain of ~56 dependent launches of 5-20 us inside the
+// replayed graph (profiles/r03_trace_sceneseg_fp16x3_single_stream.tsv), and with several cameras in flight it still costs ~250 us of
+// every 2.5 ms frame (profiles/r03_encoder_hiding_bound.txt).  The expanded tensor (6 x the block's input channels) is the largest
+// tensor of every block, written by one launch and read back by the next.  Here it never leaves the CU:
+//   1. a workgroup owns an output patch (8x16 pixels at stride 1, 4x16 at stride 2) x 32 expanded channels; the input patch under it
+//      -- (TH-1) s + k rows x (TW-1) s + k columns: the depthwise halo -- is expanded by an MFMA GEMM (halo pixels x Cin -> 32
+//      channels, 32-channel input chunks staged global -> LDS, 3 MFMAs per product as everywhere in the parity mode): the halo is
+//      RECOMPUTED by neighbouring workgroups (1.4x / 1.9x of the expand FLOPs at k = 3 / 5, nothing at the encoder's scale);
+//   2. bias + SiLU in registers, pixels outside the image forced to ZERO (the depthwise pads its INPUT, i.e. the expanded tensor, with
+//      zeros -- not with expand(0)), the fp32 tile goes to LDS over the dead staging buffers;
+//   3. the depthwise taps read that tile, bias + SiLU, (hi, lo) store, per-channel pool sums as 2^24 fixed-point int64 (LDS atomics, then
+//      one global atomic per channel and workgroup into a replica row: integer adds, bit-deterministic) -- the same arithmetic, tap order
+//      and pool protocol as dwconv_pool_kernel (kernels_backbone.hip), whose launch this replaces together with the expand GEMM's.
+// The depthwise sees the expand output in fp32 instead of its (hi, lo) rounding: a hair closer to the oracle, not bit-identical to the
+// two-launch path.  fp16x3 engines, one frame per pass (the batched encoder and the fp16 engines keep the two launches).
+#include "act_io.hpp"
+#include "conv_epilogue.hpp"
+
+namespace vp {
+
+template <int K, int S>
+struct MbTile {
+  static constexpr int TH = S == 1 ? 8 : 4, TW = 16;
+  static constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, HPX = IH * IW;
+  static constexpr int NF = (HPX + 31) / 32;          // 32-pixel MFMA column tiles of the halo
+  static constexpr int NFW = (NF + 3) / 4;            // per wave (4 waves)
+  static constexpr int XPITCH = 80;                   // bytes per staged pixel row (32 channels fp16 + 16: conflict-free ds_read_b128)
+  static constexpr int X_BYTES = NF * 32 * XPITCH;    // one plane of the input chunk
+  static constexpr int W_BYTES = 32 * XPITCH;         // one plane of the weight chunk (32 expanded channels x 32 input channels)
+  static constexpr int EPITCH = 32 * 4 + 16;          // bytes per expanded pixel row (32 channels fp32 + 16)
+  static constexpr int E_BYTES = HPX * EPITCH;
+  static constexpr int STAGE = 2 * X_BYTES + 2 * W_BYTES;
+  static constexpr int MAIN = STAGE > E_BYTES ? STAGE : E_BYTES;   // the expanded tile overlays the staging buffers
+  static constexpr int LDS = MAIN + K * K * 32 * 4 + 32 * 8;       // + depthwise filter slice + pool accumulators
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
+  using T = MbTile<K, S>;
+  constexpr int TH = T::TH, TW = T::TW, IW = T::IW, HPX = T::HPX, NF = T::NF, NFW = T::NFW, XP = T::XPITCH, EP = T::EPITCH;
+  constexpr int pad = (K - 1) / 2;
+  extern __shared__ unsigned char dw_smem[];
+  unsigned char* const xs_hi = dw_smem;
+  unsigned char* const xs_lo = xs_hi + T::X_BYTES;
+  unsigned char* const ws_hi = xs_lo + T::X_BYTES;
+  unsigned char* const ws_lo = ws_hi + T::W_BYTES;
+  unsigned char* const es = dw_smem;                                             // [HPX][EP] fp32, after the GEMM
+  float* const wl = reinterpret_cast<float*>(dw_smem + T::MAIN);                 // [K*K][32]
+  unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(dw_smem + T::MAIN + K * K * 32 * 4);  // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int OW = p.out.W, OH = p.out.H;
+  const int tiles_x = (OW + TW - 1) / TW;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int oy0 = tyi * TH, ox0 = txi * TW;
+  const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;   // image coordinates of halo pixel (0, 0)
+  const int c0 = blockIdx.y * 32;                       // first expanded channel of this workgroup
+  const int Cin = p.in.C, Cexp = p.out.C;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  // depthwise filter slice + pool accumulators (read after several barriers)
+  for (int i = tid; i < K * K * 8; i += 256) {
+    const int tp = i >> 3, j = i & 7;
+    *reinterpret_cast<f32x4_t*>(wl + tp * 32 + j * 4) = *reinterpret_cast<const f32x4_t*>(p.w_dw + (size_t)tp * Cexp + c0 + j * 4);
+  }
+  if (tid < 32) red64[tid] = 0ull;
+
+  // ---- 1: expand GEMM over the halo patch.  A = weights (32 expanded channels x 16 k), B = pixels (32 halo pixels x 16 k); a lane's
+  // 16 accumulators of a tile are channels 8 g + 4 (lane >> 5) + r (g, r = 0..3) of halo pixel 32 f + (lane & 31).
+  f32x16_t acc[NFW];
+#pragma unroll
+  for (int j = 0; j < NFW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+  const int KC = Cin >> 5;
+  for (int c = 0; c < KC; ++c) {
+    // stage chunk c: every 16-byte piece (8 channels of one halo pixel, one plane) by one thread; outside the image / past the patch: zeros
+    for (int q = tid; q < NF * 32 * 4; q += 256) {
+      const int hp = q >> 2, part = q & 3;
+      const int hy = hp / IW, hx = hp - hy * IW;
+      const int gy = iy0 + hy, gx = ix0 + hx;
+      const bool ok = hp < HPX && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W;
+      const size_t off = ((size_t)(ok ? gy : 0) * p.in.W + (ok ? gx : 0)) * Cin + c * 32 + part * 8;
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(p.in.hi + off), vl = *reinterpret_cast<const u32x4*>(p.in.lo + off);
+      *reinterpret_cast<u32x4*>(xs_hi + hp * XP + part * 16) = ok ? vh : zero4;
+      *reinterpret_cast<u32x4*>(xs_lo + hp * XP + part * 16) = ok ? vl : zero4;
+    }
+    if (tid < 128) {  // 32 rows x 4 pieces per plane
+      const int row = tid >> 2, part = tid & 3;
+      const size_t off = (size_t)(c0 + row) * Cin + c * 32 + part * 8;
+      *reinterpret_cast<u32x4*>(ws_hi + row * XP + part * 16) = *reinterpret_cast<const u32x4*>(p.w_hi + off);
+      *reinterpret_cast<u32x4*>(ws_lo + row * XP + part * 16) = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const int fo = (lane & 31) * XP + ss * 32 + (lane >> 5) * 16;
+      const h8_t a_hi = *reinterpret_cast<const h8_t*>(ws_hi + fo), a_lo = *reinterpret_cast<const h8_t*>(ws_lo + fo);
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) {
+        const int f = wave + 4 * j;
+        if (f < NF) {
+          const h8_t b_hi = *reinterpret_cast<const h8_t*>(xs_hi + f * 32 * XP + fo), b_lo = *reinterpret_cast<const h8_t*>(xs_lo + f * 32 * XP + fo);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // the chunk is consumed: the next one (or the expanded tile) may overwrite it
+  }
+
+  // ---- 2: bias + SiLU, zero outside the image, fp32 tile -> LDS (over the staging buffers)
+  {
+    f32x4_t be[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) be[g] = *reinterpret_cast<const f32x4_t*>(p.b_exp + c0 + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+      const int f = wave + 4 * j;
+      const int hp = f * 32 + (lane & 31);
+      if (f < NF && hp < HPX) {
+        const int hy = hp / IW, hx = hp - hy * IW;
+        const bool in_img = (unsigned)(iy0 + hy) < (unsigned)p.in.H && (unsigned)(ix0 + hx) < (unsigned)p.in.W;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4_t v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = in_img ? silu_f(acc[j][4 * g + r] + be[g][r]) : 0.0f;
+          *reinterpret_cast<f32x4_t*>(es + hp * EP + (8 * g + 4 * (lane >> 5)) * 4) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3: depthwise + SiLU + store + pool.  Item = (output pixel of the patch, channel octet): 128 x 4 (stride 1) or 64 x 4 items.
+  constexpr int ITEMS = TH * TW * 4;
+  for (int it = tid; it < ITEMS; it += 256) {
+    const int og = it & 3, pl = it >> 2;
+    const int ty = pl / TW, tx = pl - ty * TW;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy >= OH || ox >= OW) continue;
+    const int cc = c0 + og * 8;
+    float a8[8];
+    {
+      const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.b_dw + cc), b1 = *reinterpret_cast<const f32x4_t*>(p.b_dw + cc + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a8[i] = b0[i];
+        a8[4 + i] = b1[i];
+      }
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const unsigned char* src = es + ((ty * S + ky) * IW + (tx * S + kx)) * EP + og * 32;
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src), v1 = *reinterpret_cast<const f32x4_t*>(src + 16);
+        const float* wk = wl + (ky * K + kx) * 32 + og * 8;
+        const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wk), w1 = *reinterpret_cast<const f32x4_t*>(wk + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a8[i] = fmaf(v0[i], w0[i], a8[i]);
+          a8[4 + i] = fmaf(v1[i], w1[i], a8[4 + i]);
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a8[i] = silu_f(a8[i]);
+    store8(p.out, ((size_t)oy * OW + ox) * Cexp + cc, a8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&red64[og * 8 + i], (unsigned long long)(long long)__float2ll_rn(a8[i] * 16777216.0f));
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const unsigned long long v = red64[tid];
+    if (v != 0ull) atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * Cexp + c0 + tid, v);
+  }
+}
+
+bool mbconv_front_supported(const MbFrontParams& p) {
+  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.w_dw && p.b_dw && p.sums && (p.k == 3 || p.k == 5) &&
+         (p.stride == 1 || p.stride == 2) && (p.in.C & 31) == 0 && (p.out.C & 31) == 0 && p.replicas >= 1 && (p.replicas & (p.replicas - 1)) == 0 &&
+         p.out.H == p.in.H / p.stride && p.out.W == p.in.W / p.stride && p.in.H % p.stride == 0 && p.in.W % p.stride == 0;
+}
+
+template <int K, int S>
+static hipError_t launch_mb(const MbFrontParams& p, hipStream_t st) {
+  using T = MbTile<K, S>;
+  static_assert(T::LDS <= 160 * 1024, "LDS budget");
+  static LdsAttrOnce once;
+  auto k = mbconv_front_kernel<K, S>;
+  if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(k), T::LDS); e != hipSuccess) return e;
+  const dim3 grid(((p.out.H + T::TH - 1) / T::TH) * ((p.out.W + T::TW - 1) / T::TW), p.out.C / 32);
+  hipLaunchKernelGGL(k, grid, dim3(256), T::LDS, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st) {
+  if (!mbconv_front_supported(p)) return hipErrorInvalidValue;
+  if (p.k == 3 && p.stride == 1) return launch_mb<3, 1>(p, st);
+  if (p.k == 5 && p.stride == 1) return launch_mb<5, 1>(p, st);
+  if (p.k == 3 && p.stride == 2) return launch_mb<3, 2>(p, st);
+  return launch_mb<5, 2>(p, st);
+}
+
+}  // namespace vp

@@ -89,6 +89,15 @@ int emu_dwconv_batched(void* in_hi, void* in_lo, int H, int W, int C, void* out_
   DwParams p{view(in_hi, in_lo, H, W, C), view(out_hi, out_lo, OH, OW, C), w, b, k, stride, sums, replicas, frames};
   return launch_dwconv(p, nullptr);
 }
+int emu_mbconv_front(void* in_hi, void* in_lo, int H, int W, int Cin, const void* w_hi, const void* w_lo, const float* b_exp, const float* w_dw,
+                     const float* b_dw, void* out_hi, void* out_lo, int Cexp, int k, int stride, unsigned long long* sums, int replicas) {
+  MbFrontParams p{};
+  p.in = view(in_hi, in_lo, H, W, Cin);
+  p.w_hi = static_cast<const half_t*>(w_hi); p.w_lo = static_cast<const half_t*>(w_lo); p.b_exp = b_exp; p.w_dw = w_dw; p.b_dw = b_dw;
+  p.out = view(out_hi, out_lo, H / stride, W / stride, Cexp);
+  p.k = k; p.stride = stride; p.sums = sums; p.replicas = replicas;
+  return launch_mbconv_front(p, nullptr);
+}
 int emu_se_gate_scale(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1,
                       const float* w, void* out_hi, void* out_lo, int rows, const float* w2, const float* b2, int frames) {
   SeParams p{};

@@ -21,6 +21,7 @@ extern "C" {
 int emu_stem(const float*, int, int, const float*, const float*, void*, void*);
 int emu_dwconv(void*, void*, int, int, int, void*, void*, int, int, const float*, const float*, int, int, unsigned long long*, int);
 int emu_se_gate_scale(const unsigned long long*, int, int, int, int, float, const float*, const float*, const float*, void*, void*, int, const float*, const float*, int);
+int emu_mbconv_front(void*, void*, int, int, int, const void*, const void*, const float*, const float*, const float*, void*, void*, int, int, int, unsigned long long*, int);
 int emu_fc(const float*, const float*, const float*, float*, int, int, int);
 int emu_pool_partial(void*, void*, int, int, int, float*, int);
 int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
@@ -120,9 +121,6 @@ int main(int argc, char** argv) {
     bad |= conv_logits(1, 128, 3, quick ? 5 : 9, quick ? 17 : 33);
     if (!quick) bad |= conv_logits(0, 64, 1, 17, 20);
   }
-  if (!skip_conv && !quick) {
-    bad |= conv(0, 0, 96, 33, 16, 32, 3, 0, 201, -1, 1);
-  }
 
   {  // encoder pieces
     const int H = 18, W = 28;
@@ -141,6 +139,14 @@ int main(int argc, char** argv) {
         std::vector<half_t> ph((size_t)64 * C), pl(ph.size());
         bad |= emu_se_gate_scale(sums.data(), 8, C, C, 6, 1.0f / (oh * ow), w1.data(), b1.data(), pw.data(), ph.data(), split ? pl.data() : nullptr, 64, w2.data(), b2.data(), 1);
       }
+    // fused MBConv front (kernels_mbconv.hip): staging buffers rewritten per K chunk, the fp32 tile laid over them, LDS pool atomics
+    for (int cfg = 0; cfg < (quick ? 1 : 2); ++cfg) {
+      const int k = cfg ? 5 : 3, stride = cfg ? 2 : 1, cin = 64, cexp = 96, h = 10, ww = 18, oh = h / stride, ow = ww / stride;
+      std::vector<half_t> ih = rnd16((size_t)h * ww * cin), il = rnd16(ih.size()), wh = rnd16((size_t)cexp * cin), wl = rnd16(wh.size()), oh_((size_t)oh * ow * cexp), ol_(oh_.size());
+      std::vector<float> be = rnd(cexp, 0.1f), wk = rnd((size_t)k * k * cexp, 0.3f), bb = rnd(cexp, 0.1f);
+      std::vector<unsigned long long> sums(4 * cexp, 0ull);
+      bad |= emu_mbconv_front(ih.data(), il.data(), h, ww, cin, wh.data(), wl.data(), be.data(), wk.data(), bb.data(), oh_.data(), ol_.data(), cexp, k, stride, sums.data(), 4);
+    }
     std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
     bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);
     std::vector<half_t> ph = rnd16(10 * 20 * 96), pl = rnd16(ph.size());

@@ -210,6 +210,45 @@ def test_depthwise_pool_kernel(emu, C, k, stride, H, W):
     assert _rel(o16.astype(np.float32).transpose(2, 0, 1), want16) <= 2e-3
 
 
+@pytest.mark.parametrize("cin,cexp,k,stride,H,W", [(16, 96, 3, 2, 16, 32), (24, 144, 3, 1, 11, 21), (40, 240, 5, 1, 9, 18), (24, 144, 5, 2, 18, 22), (80, 480, 3, 1, 8, 16)])
+def test_mbconv_front_kernel(emu, cin, cexp, k, stride, H, W):
+    """kernels_mbconv.hip: expand 1x1 + SiLU -> depthwise k x k / stride + SiLU -> pool sums in ONE launch (the expanded tensor never leaves
+    the CU; the depthwise halo is re-expanded by neighbouring workgroups) against the two torch ops: all four (k, stride) instantiations,
+    channel counts padded to 32 (16 -> 32, 24 -> 32, 40 -> 64; 144 -> 160, 240 -> 256), several 32-channel K chunks, maps that are not a
+    multiple of the patch, the zero padding of the EXPANDED tensor at the border (expand(0) = SiLU(bias) != 0 there), pad channels exactly 0."""
+    rng = np.random.default_rng(cin * 7 + k)
+    cinp, cexpp = (cin + 31) // 32 * 32, (cexp + 31) // 32 * 32
+    x = rng.standard_normal((cin, H, W)).astype(np.float32)
+    we = (rng.standard_normal((cexp, cin, 1, 1)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    be = (rng.standard_normal(cexp) * 0.3).astype(np.float32)
+    wd = (rng.standard_normal((cexp, 1, k, k)) * 0.4).astype(np.float32)
+    bd = (rng.standard_normal(cexp) * 0.1).astype(np.float32)
+    xh, xl = split16(nhwc(x, cinp))
+    xin = torch.from_numpy((xh.astype(np.float32) + xl.astype(np.float32)).transpose(2, 0, 1)[:cin])[None]
+    wp = np.zeros((cexpp, cinp), np.float32)
+    wp[:cexp, :cin] = we[:, :, 0, 0]
+    wh, wlo = split16(wp)
+    w_used = torch.from_numpy((wh.astype(np.float32) + wlo.astype(np.float32))[:cexp, :cin])[:, :, None, None]
+    e = F.silu(F.conv2d(xin.double(), w_used.double(), torch.from_numpy(be).double()))
+    want = F.silu(F.conv2d(e, torch.from_numpy(wd).double(), torch.from_numpy(bd).double(), stride=stride, padding=k // 2, groups=cexp))[0].float().numpy()
+    OH, OW = want.shape[1:]
+    assert (OH, OW) == (H // stride, W // stride)
+    bep, bdp = np.zeros(cexpp, np.float32), np.zeros(cexpp, np.float32)
+    bep[:cexp], bdp[:cexp] = be, bd
+    wk = np.zeros((k * k, cexpp), np.float32)
+    wk[:, :cexp] = wd.reshape(cexp, k * k).T
+    oh, ol = np.full((OH, OW, cexpp), 7, np.float16), np.full((OH, OW, cexpp), 7, np.float16)
+    replicas = 4
+    sums = np.zeros((replicas, cexpp), dtype=np.uint64)
+    assert emu.emu_mbconv_front(ptr(xh), ptr(xl), H, W, cinp, ptr(wh), ptr(wlo), ptr(bep), ptr(wk), ptr(bdp), ptr(oh), ptr(ol), cexpp, k, stride,
+                                ptr(sums), replicas) == 0
+    got = (oh.astype(np.float32) + ol.astype(np.float32)).transpose(2, 0, 1)
+    assert _rel(got[:cexp], want) <= 3e-6
+    assert not got[cexp:].any()                                   # pad channels stay exactly zero
+    pooled = sums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
+    assert np.abs(pooled - got.astype(np.float64).sum(axis=(1, 2))).max() <= 1e-4
+
+
 def test_squeeze_excite_kernel(emu):
     """se_gate_scale: means from the replica rows -> squeeze FC -> SiLU -> excite FC -> sigmoid gate folded into the projection
     weights' K axis (pad channels gated to 0), one launch; wide (sq = 48, C = 1152: 5 K segments per unit) and narrow (sq = 4:
