@@ -77,25 +77,51 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
   const int KC = Cin >> 5;
+  // staging plan: 16-byte piece i of this thread = (halo pixel, 8-channel part) q = tid + 256 i of a chunk; element offset of the piece in
+  // chunk 0, or -1 (outside the image / past the patch: zeros).  The pieces of chunk c + 1 are REQUESTED before the MFMAs of chunk c and
+  // parked in registers: the loop is a latency chain (load -> LDS -> barrier -> fragments -> MFMA) of 1-6 links, one per 32 input channels
+  constexpr int PCS = (NF * 32 * 4 + 255) / 256;
+  int x_off[PCS];
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    const int q = tid + 256 * i, hp = q >> 2, part = q & 3;
+    const int hy = hp / IW, hx = hp - hy * IW;
+    const int gy = iy0 + hy, gx = ix0 + hx;
+    const bool ok = q < NF * 32 * 4 && hp < HPX && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W;
+    x_off[i] = ok ? (gy * p.in.W + gx) * Cin + part * 8 : -1;
+  }
+  const int w_row = tid >> 2, w_part = tid & 3;
+  const size_t w_off0 = (size_t)(c0 + (w_row & 31)) * Cin + w_part * 8;
+  u32x4 rx_hi[PCS], rx_lo[PCS], rw_hi = zero4, rw_lo = zero4;
+#define VP_MB_LOAD(C)                                                                                  \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < PCS; ++i) {                                                  \
+      const int o_ = (x_off[i] >= 0 ? x_off[i] : 0) + (C) * 32;                                        \
+      const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in.hi + o_), vl_ = *reinterpret_cast<const u32x4*>(p.in.lo + o_); \
+      rx_hi[i] = x_off[i] >= 0 ? vh_ : zero4;                                                          \
+      rx_lo[i] = x_off[i] >= 0 ? vl_ : zero4;                                                          \
+    }                                                                                                  \
+    if (tid < 128) {                                                                                   \
+      rw_hi = *reinterpret_cast<const u32x4*>(p.w_hi + w_off0 + (C) * 32);                             \
+      rw_lo = *reinterpret_cast<const u32x4*>(p.w_lo + w_off0 + (C) * 32);                             \
+    }                                                                                                  \
+  }
+  VP_MB_LOAD(0)
   for (int c = 0; c < KC; ++c) {
-    // stage chunk c: every 16-byte piece (8 channels of one halo pixel, one plane) by one thread; outside the image / past the patch: zeros
-    for (int q = tid; q < NF * 32 * 4; q += 256) {
-      const int hp = q >> 2, part = q & 3;
-      const int hy = hp / IW, hx = hp - hy * IW;
-      const int gy = iy0 + hy, gx = ix0 + hx;
-      const bool ok = hp < HPX && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W;
-      const size_t off = ((size_t)(ok ? gy : 0) * p.in.W + (ok ? gx : 0)) * Cin + c * 32 + part * 8;
-      const u32x4 vh = *reinterpret_cast<const u32x4*>(p.in.hi + off), vl = *reinterpret_cast<const u32x4*>(p.in.lo + off);
-      *reinterpret_cast<u32x4*>(xs_hi + hp * XP + part * 16) = ok ? vh : zero4;
-      *reinterpret_cast<u32x4*>(xs_lo + hp * XP + part * 16) = ok ? vl : zero4;
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+      const int q = tid + 256 * i;
+      if (q < NF * 32 * 4) {
+        *reinterpret_cast<u32x4*>(xs_hi + (q >> 2) * XP + (q & 3) * 16) = rx_hi[i];
+        *reinterpret_cast<u32x4*>(xs_lo + (q >> 2) * XP + (q & 3) * 16) = rx_lo[i];
+      }
     }
     if (tid < 128) {  // 32 rows x 4 pieces per plane
-      const int row = tid >> 2, part = tid & 3;
-      const size_t off = (size_t)(c0 + row) * Cin + c * 32 + part * 8;
-      *reinterpret_cast<u32x4*>(ws_hi + row * XP + part * 16) = *reinterpret_cast<const u32x4*>(p.w_hi + off);
-      *reinterpret_cast<u32x4*>(ws_lo + row * XP + part * 16) = *reinterpret_cast<const u32x4*>(p.w_lo + off);
+      *reinterpret_cast<u32x4*>(ws_hi + w_row * XP + w_part * 16) = rw_hi;
+      *reinterpret_cast<u32x4*>(ws_lo + w_row * XP + w_part * 16) = rw_lo;
     }
     __syncthreads();
+    if (c + 1 < KC) VP_MB_LOAD(c + 1)
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       const int fo = (lane & 31) * XP + ss * 32 + (lane >> 5) * 16;
@@ -113,6 +139,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     }
     __syncthreads();  // the chunk is consumed: the next one (or the expanded tile) may overwrite it
   }
+#undef VP_MB_LOAD
 
   // ---- 2: bias + SiLU, zero outside the image, fp32 tile -> LDS (over the staging buffers)
   {
