@@ -88,7 +88,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     p.in2_delta_lo = (in->lo && o.in2->lo) ? o.in2->lo - in->lo : 0;
   }
   const int M = p.H * p.W;
-  p.partial = pc.nsplit > 1 ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
+  p.partial = (pc.nsplit > 1 || pc.tile == 111) ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
   const int tile = pc.tile, bk = pc.bk;
   const bool sp = split();
   Op op;
@@ -140,6 +140,13 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       hipStreamDestroy(ts[1]);
       hipStreamDestroy(ts[2]);
       ht = best_c;
+    }
+    if (ht == 11) {
+      if (!conv3x3_map_supported(p)) throw std::invalid_argument("halo tile 11 (map kernel): 3x3 stride 1, fp16x3, 20x40 regions: " + name);
+      op.kernel = "conv3x3_map<co32,px800,x3>+splitk";
+      op.run = [p](hipStream_t st) { return launch_conv3x3_map(p, st); };
+      ops_.push_back(std::move(op));
+      return;
     }
     if (ht >= 6 && ht <= 8) {
       if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
@@ -258,12 +265,32 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         (void)wgs8;
       }
     }
+    // parity mode, small maps of the neck (20x40 / 40x80 pixels, long K): one workgroup = a 32-channel weight slab x a K slice x ALL pixels
+    // of a 20x40 region (kernels_conv3x3_map.hip, halo tile 11): the 8x16 tiles re-stream the weights once per pixel tile and are bound by
+    // that traffic.  Any epilogue (it always ends in the finish kernel).  VP_MAP3X3=0 (developer knob, A/B timing): the tiled kernels.
+    {
+      static const char* envm = std::getenv("VP_MAP3X3");
+      const bool on = !(envm && envm[0] == '0');
+      if (o.tile == 111 || (on && split() && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && cin_pad >= 256 &&
+                            conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
+        halo = 11;
+    }
+    if (halo == 11 && (!split() || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
+      throw std::invalid_argument("halo tile 11 (map kernel): fp16x3, maps that tile into 20x40 regions, >= 32 input channels: " + name);
     if (halo >= 6 && halo <= 8 && !split()) throw std::invalid_argument("halo tiles 6 - 8 are fp16x3 kernels: " + name);
   }
   if (halo >= 0) {
     pc.tile = 100 + halo;
     pc.bk = 32;
     pc.CoutW = round_up(ncols, halo_tile_co(halo));
+    if (halo == 11) {  // map kernel: K slices until ~one workgroup per CU (it is a one-workgroup-per-CU kernel), fp32 slabs <= 24 MB
+      const int regions = (in->H / 20) * (in->W / 40), n_co = pc.CoutW / 32, KS = cin_pad / 16;
+      int ns = o.nsplit > 0 ? o.nsplit : std::max(1, (int)std::lround(256.0 / (regions * n_co)));
+      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
+      while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
+      pc.bk = 16;
+      pc.nsplit = std::max(1, std::min(ns, std::max(1, KS / 2)));
+    } else {
     const int KC = cin_pad / 32;
     const long long blocks = (long long)((in->H + halo_tile_th(halo) - 1) / halo_tile_th(halo)) * ((in->W + 15) / 16) *
                              (pc.CoutW / halo_tile_co(halo));
@@ -313,6 +340,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         pc.tile = 108;
       }
     }
+    }
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }
@@ -325,7 +353,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
         const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
-        const size_t d = halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
+        const size_t d = halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)
+                         : halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;
         split_half(v, &h, &l);

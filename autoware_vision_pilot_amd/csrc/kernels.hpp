@@ -139,6 +139,12 @@ int halo_tile_co(int tile);
 int halo_tile_px(int tile);
 int halo_tile_th(int tile);
 
+// small-map 3x3 of the parity mode (kernels_conv3x3_map.hip; halo tile id 11): a workgroup = 32 output channels x a K slice x all 800 pixels of a
+// 20x40 region; weights packed by conv3x3_map_pack_index; always finishes through splitk_finish_kernel (p.partial required, nsplit >= 1)
+bool conv3x3_map_shape_ok(int H, int W, int cin_pad, int coutw);
+size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad);
+bool conv3x3_map_supported(const ConvGemmParams& p);
+hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st);
 // last convolution of a head: 3x3, 64 / 128 channels -> <= 4 logit channels, fp32 NCHW + fused decode (kernels_head.hip); weights packed
 // as for halo tile 4; zeros = the engine's zero page (>= 16 bytes of zeros in device memory)
 bool head_conv_supported(const ConvGemmParams& p);

@@ -1,0 +1,187 @@
+// 3x3 / stride 1 / pad 1 convolution of the PARITY mode on the SMALL maps of the neck (20x40 and 40x80 pixels, 512-1280 input channels):
+// one workgroup = one WEIGHT SLAB (32 output channels x a K slice) held against ALL pixels of a 20x40 region.
+//
+// decode_layer_0..3 are 61 GFLOP of the 367 of a network and a quarter of its decoder time (70 / 47 / 82 / 60 us, 0.07-0.11 of the
+// matrix peak, round 2): on 800 / 3200 pixels the 8x16-pixel tiles of kernels_conv3x3.hip re-stream the whole weight tensor once per
+// pixel tile -- 35 MB of (hi, lo) weights x 7 tiles on decode_layer_0, ~250 MB through the L2s for a 5 MB fp32 tensor -- and that
+// traffic, not the matrix pipe, is their bound.  Turned round here:
+//   * a workgroup (8 waves) owns a REGION of 20x40 = 800 pixels (25 MFMA pixel tiles; the 20x40 maps are one region, the 40x80 maps
+//     four) x 32 output channels x a slice of the input channels, so every weight byte is fetched by R = 1 (4) workgroups instead of 7
+//     (25) and the input by Cout / 32 of them; the fp32 accumulators of the whole region stay in registers (wave w: pixel tiles w,
+//     w + 8, w + 16 (, 24): 48-64 registers);
+//   * K advances in steps of 16 input channels (one MFMA K sub-step): the region's halo image, 22x42 pixels x 32 B x (hi, lo) = 59 KB,
+//     and the step's nine 32x16 weight tiles, 18 KB, are DOUBLE-buffered in LDS (155 KB: one workgroup per CU) and filled by LDS-DMA
+//     (global_load_lds_dwordx4) one step ahead, under the current step's 108 MFMAs per wave; pixels outside the map come from the zero
+//     page; one LDS-only barrier per step;
+//   * 32-byte rows: the two 16-byte slots of a row are XOR-swizzled by bit 3 of the row index, applied to the GLOBAL address a lane
+//     supplies (the DMA itself is linear), so the fixed 16-lane groups of ds_read_b128 hit sixteen distinct bank slots; the weights
+//     are packed on the host in that LDS image order, one contiguous 9 KB block per (channel tile, step, plane);
+//   * a tap is an LDS address offset, as in the other 3x3 kernels; the swizzle bit of a fragment read is recomputed per tap (4 VALU
+//     instructions per read);
+//   * output: fp32 partial sums straight from the accumulators to p.partial[z][pixel][CoutW]; splitk_finish_kernel (kernels_conv.hip)
+//     sums the K slices in z order and applies bias / activation / (hi, lo) split, as for every split layer.
+// Same products, a different summation order than the tiled kernels (per K slice: channels in steps of 16, taps inside).
+#include "conv_epilogue.hpp"
+#include "lds_dma.hpp"
+
+namespace vp {
+
+namespace mapk {
+constexpr int RH = 20, RW = 40, RPX = RH * RW;          // region
+constexpr int HW = RW + 2, HH = RH + 2, HPX = HH * HW;   // its halo image: 22 x 42 = 924 pixels
+constexpr int NF = RPX / 32;                             // 25 pixel tiles of 32
+constexpr int HROWS = (HPX + 31) / 32 * 32;              // rows per plane incl. the padding of the last DMA group (928)
+constexpr int H_PLANE = HROWS * 32, W_PLANE = 9 * 32 * 32;  // bytes: halo plane (29 696), weight plane of one step (9 216)
+constexpr int H_BUF = 2 * H_PLANE, W_BUF = 2 * W_PLANE;  // (hi, lo)
+constexpr int LDS = 2 * H_BUF + 2 * W_BUF;               // 155 648
+constexpr int NHI = HROWS / 32, NWI = W_PLANE / 1024;    // DMA instructions per plane: 29 halo, 9 weights
+constexpr int NINSTR = 2 * NHI + 2 * NWI;                // 76 per step
+constexpr int IPW = (NINSTR + 7) / 8;                    // per wave: 10
+static_assert(RPX % 32 == 0 && LDS <= 160 * 1024, "region / LDS plan");
+}  // namespace mapk
+
+__global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParams p) {
+  using namespace mapk;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo0 = smem;                 // [2 buffers][2 planes][H_PLANE]
+  char* const wgt0 = smem + 2 * H_BUF;      // [2 buffers][2 planes][W_PLANE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int regions_x = p.W / RW, n_regions = regions_x * (p.H / RH), n_co = p.CoutW >> 5;
+  int vid;  // XCD-aware map: the workgroups that share a weight slab (the regions of one channel tile and K slice) are consecutive
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int region = vid % n_regions, rest = vid / n_regions;
+  const int tile_co = rest % n_co, zsplit = rest / n_co;
+  const int ry0 = (region / regions_x) * RH, rx0 = (region % regions_x) * RW;
+  const int KS_all = p.Cin >> 4;  // steps of 16 input channels
+  const int s_first = (int)(((long long)KS_all * zsplit) / p.nsplit);
+  const int KS = (int)(((long long)KS_all * (zsplit + 1)) / p.nsplit) - s_first;
+
+  // ---- DMA plan of this wave: instruction ii = wave + 8 i of a step.  [0, 2 NHI): halo, plane ii / NHI, rows 32 g .. 32 g + 31 (lane l:
+  // row 32 g + (l >> 1), stored slot l & 1 = logical slot (l & 1) ^ bit 3 of the row); [2 NHI, NINSTR): weights, linear (host-packed image)
+  int h_goff[IPW];   // halo: element offset of this lane's 16 bytes in step 0, or -1 (outside the map / padding rows: zero page)
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int ii = wave + 8 * i;
+    h_goff[i] = -1;
+    if (ii < 2 * NHI) {
+      const int g = ii % NHI, R = 32 * g + (lane >> 1), lslot = (lane & 1) ^ ((R >> 3) & 1);
+      const int hy = R / HW, hx = R - hy * HW;
+      const int gy = ry0 - 1 + hy, gx = rx0 - 1 + hx;
+      if (R < HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) h_goff[i] = (gy * p.W + gx) * p.Cin + lslot * 8;
+    }
+  }
+  const size_t w_tile0 = ((size_t)tile_co * KS_all + s_first) * (W_PLANE / 2);  // elements: this channel tile's block of step s_first
+#define VP_MAP_DMA(BUF, STEP)                                                                                         \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < IPW; ++i) {                                                                 \
+      const int ii_ = wave + 8 * i;                                                                                   \
+      if (ii_ < 2 * NHI) {                                                                                            \
+        const int pl_ = ii_ >= NHI ? 1 : 0;                                                                           \
+        const half_t* base_ = pl_ ? p.in_lo : p.in_hi;                                                                \
+        const half_t* src_ = h_goff[i] >= 0 ? base_ + h_goff[i] + (s_first + (STEP)) * 16 : p.zeros;                  \
+        VP_GLOBAL_LOAD_LDS16(src_, halo0 + (BUF) * H_BUF + pl_ * H_PLANE + (ii_ - pl_ * NHI) * 1024);                 \
+      } else if (ii_ < NINSTR) {                                                                                      \
+        const int wi_ = ii_ - 2 * NHI, pl_ = wi_ >= NWI ? 1 : 0, pc_ = wi_ - pl_ * NWI;                               \
+        const half_t* base_ = pl_ ? p.w_lo : p.w_hi;                                                                  \
+        VP_GLOBAL_LOAD_LDS16(base_ + w_tile0 + (size_t)(STEP) * (W_PLANE / 2) + pc_ * 512 + lane * 8,                 \
+                             wgt0 + (BUF) * W_BUF + pl_ * W_PLANE + pc_ * 1024);                                      \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+
+  // ---- fragment addressing.  Pixel tile f = wave + 8 j holds region pixels 32 f .. 32 f + 31; lane's pixel -> halo row of tap (0, 0)
+  constexpr int NFW = (NF + 7) / 8;  // 4 (wave 0) or 3
+  int b_row[NFW];
+#pragma unroll
+  for (int j = 0; j < NFW; ++j) {
+    const int pix = (wave + 8 * j) * 32 + (lane & 31);
+    const int y = pix / RW, x = pix - y * RW;
+    b_row[j] = y * HW + x;
+  }
+  const int ks = lane >> 5;                                                          // which 8 of the step's 16 channels this lane feeds
+  const int a_ofs = (lane & 31) * 32 + ((ks ^ (((lane & 31) >> 3) & 1)) << 4);      // weight row tap * 32 + (lane & 31): bit 3 of the row = bit 3 of the lane's channel
+
+  f32x16_t acc[NFW];
+#pragma unroll
+  for (int j = 0; j < NFW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+  VP_MAP_DMA(0, 0)
+  for (int s = 0; s < KS; ++s) {
+    const int buf = s & 1;
+    VP_WAIT_VMCNT(0);   // this wave's pieces of step s have landed ...
+    VP_LDS_BARRIER();   // ... everybody's have, and everybody is done reading the other buffer (step s - 1)
+    if (s + 1 < KS) VP_MAP_DMA(buf ^ 1, s + 1)
+    const char* hb = halo0 + buf * H_BUF;
+    const char* wb = wgt0 + buf * W_BUF;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int tofs = (t / 3) * HW + (t % 3);
+      const h8_t a_hi = *reinterpret_cast<const h8_t*>(wb + t * 1024 + a_ofs), a_lo = *reinterpret_cast<const h8_t*>(wb + W_PLANE + t * 1024 + a_ofs);
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) {
+        if (wave + 8 * j < NF) {
+          const int R = b_row[j] + tofs;
+          const int o = R * 32 + ((ks ^ ((R >> 3) & 1)) << 4);
+          const h8_t b_hi = *reinterpret_cast<const h8_t*>(hb + o), b_lo = *reinterpret_cast<const h8_t*>(hb + H_PLANE + o);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#undef VP_MAP_DMA
+
+  // ---- fp32 partial sums straight from the accumulators: lane holds channels 8 g + 4 (lane >> 5) + r of its pixel
+  const int M = p.H * p.W, co0 = tile_co * 32;
+#pragma unroll
+  for (int j = 0; j < NFW; ++j) {
+    if (wave + 8 * j < NF) {
+      const int pix = (wave + 8 * j) * 32 + (lane & 31);
+      const int y = pix / RW, x = pix - y * RW;
+      const int m = (ry0 + y) * p.W + rx0 + x;
+      float* row = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co0 + 4 * (lane >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t v = {acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+        *reinterpret_cast<f32x4_t*>(row + 8 * g) = v;
+      }
+    }
+  }
+}
+
+// weight element (output channel co, input channel ci, tap t) -> index into the packed tensor: [co / 32][ci / 16][plane block of 9 x 32 rows x
+// 32 B in LDS image order]; cin_pad = padded input channels
+size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad) {
+  const int col = co & 31, k16 = ci & 15;
+  const int slot = (k16 >> 3) ^ ((col >> 3) & 1);
+  return (((size_t)(co >> 5) * (cin_pad >> 4) + (ci >> 4)) * (9 * 32) + (size_t)t * 32 + col) * 16 + slot * 8 + (k16 & 7);
+}
+
+bool conv3x3_map_shape_ok(int H, int W, int cin_pad, int coutw) {
+  return H >= mapk::RH && W >= mapk::RW && H % mapk::RH == 0 && W % mapk::RW == 0 && cin_pad % 16 == 0 && cin_pad >= 32 && coutw % 32 == 0;
+}
+
+bool conv3x3_map_supported(const ConvGemmParams& p) {
+  return p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.Cin2 == 0 && p.partial != nullptr && p.zeros != nullptr && p.nsplit >= 1 &&
+         p.nsplit <= (p.Cin >> 4) && conv3x3_map_shape_ok(p.H, p.W, p.Cin, p.CoutW);
+}
+
+hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st) {
+  if (!conv3x3_map_supported(p)) return hipErrorInvalidValue;
+  static LdsAttrOnce once;
+  if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel), mapk::LDS); e != hipSuccess) return e;
+  const int n_regions = (p.H / mapk::RH) * (p.W / mapk::RW);
+  hipLaunchKernelGGL(conv3x3_map_kernel, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(512), mapk::LDS, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return launch_splitk_finish(p, st);  // also for nsplit == 1: bias / activation / (hi, lo) split live there
+}
+
+}  // namespace vp

@@ -204,3 +204,16 @@ def test_gemm_dma_kernel(emu_lib, precision, monkeypatch):
     monkeypatch.setenv("VP_GEMM_DMA", "1")
     with pytest.raises(emu_lib.VpError):
         _case(emu_lib, 256, 96, 9, 15, 2, 1, 0, 0, precision, [(6, -1, 1)], seed=55)                # 4 * 96 rows: not a multiple of 256
+
+
+def test_map_kernel(emu_lib):
+    """kernels_conv3x3_map.hip (halo tile 11): a workgroup holds a 32-channel weight slab x a K slice against ALL 800 pixels of a 20x40
+    region; 16-channel K steps double-buffered by LDS-DMA with the slot swizzle on the global side, zero page at the map border, host
+    packing in LDS image order, fp32 slabs -> finish kernel.  One region and four, one K slice and several (incl. slices of unequal
+    length), ragged channel counts, GELU / none / the context's mul-add residual."""
+    _case(emu_lib, 48, 40, 20, 40, 3, 0, 1, 0, 1, [(111, -1, 1), (111, -1, 2)], seed=71)        # 64 padded input channels = 4 steps; 2 channel tiles
+    _case(emu_lib, 96, 72, 40, 80, 3, 0, 0, 0, 1, [(111, -1, 3)], seed=72)                      # four regions, 6 steps in 3 slices, ragged channel tile
+    _case(emu_lib, 80, 32, 20, 40, 3, 0, 1, 2, 1, [(111, -1, 5)], seed=73)                      # 96 padded channels = 6 steps in 5 slices (1, 1, 1, 1, 2)
+    with pytest.raises(emu_lib.VpError):
+        x = np.zeros((32, 16, 40), np.float32)
+        emu_lib.op_conv2d(x, np.zeros((32, 32, 3, 3), np.float32), np.zeros(32, np.float32), ks=3, precision=1, tile=111, nsplit=1)   # 16 rows: not a region multiple

@@ -220,3 +220,25 @@ def test_gemm_dma_kernel(precision, monkeypatch):
             monkeypatch.setenv("VP_GEMM_DMA", "0")
             assert (np.abs(run() - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
             monkeypatch.setenv("VP_GEMM_DMA", "1")
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,res_mode,nsplit", [(1280, 768, 20, 40, 1, 0, -1), (512, 512, 40, 80, 1, 0, -1), (96, 40, 40, 80, 0, 0, 3), (256, 64, 20, 40, 1, 2, 5)])
+def test_map_kernel_matches_torch(cin, cout, h, w, act, res_mode, nsplit):
+    """kernels_conv3x3_map.hip (halo tile 11; the engine's choice for the neck's 20x40 / 40x80 layers in the parity mode): a workgroup holds
+    a 32-channel weight slab x a K slice against all 800 pixels of a 20x40 region (LDS-DMA double buffering, swizzled 32-byte rows, zero
+    page at the border).  decode_layer_0 / 3 at their real sizes with the engine's own split factor, a ragged channel tile on four
+    regions, the context block's mul-add residual; against torch and run to run."""
+    from autoware_vision_pilot_amd import lib
+
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    wt = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+    res = rng.standard_normal((cout, h, w), dtype=np.float32) if res_mode else None
+    ref = _reference(x, wt, b, 3, 0, act, res, res_mode, fp16=False)
+    got = lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1, tile=111, nsplit=nsplit)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= 2e-5, err.max()
+    assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1, tile=111, nsplit=nsplit))
+    auto = lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1)     # the engine's own choice
+    assert (np.abs(auto - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5
