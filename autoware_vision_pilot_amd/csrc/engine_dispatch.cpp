@@ -285,7 +285,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     pc.CoutW = round_up(ncols, halo_tile_co(halo));
     if (halo == 11) {  // map kernel: K slices until ~one workgroup per CU (it is a one-workgroup-per-CU kernel), fp32 slabs <= 24 MB
       const int regions = (in->H / 20) * (in->W / 40), n_co = pc.CoutW / 32, KS = cin_pad / 16;
-      int ns = o.nsplit > 0 ? o.nsplit : std::max(1, (int)std::lround(256.0 / (regions * n_co)));
+      int ns = o.nsplit > 0 ? o.nsplit : std::max(1, 256 / (regions * n_co));  // floor: 155 KB of LDS = one workgroup per CU, a 257th waits a whole round
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
       while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
       pc.bk = 16;

@@ -40,6 +40,9 @@ constexpr int IPW = (NINSTR + 7) / 8;                    // per wave: 10
 static_assert(RPX % 32 == 0 && LDS <= 160 * 1024, "region / LDS plan");
 }  // namespace mapk
 
+// ABL: ablation bits for tools/map_ablate.hip only (1 = no DMA inside the loop, 2 = no MFMA, 4 = tap-invariant fragment addresses, 8 = no barrier / vmcnt
+// wait in the loop); 0 in the library.
+template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParams p) {
   using namespace mapk;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,27 +117,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParam
   VP_MAP_DMA(0, 0)
   for (int s = 0; s < KS; ++s) {
     const int buf = s & 1;
-    VP_WAIT_VMCNT(0);   // this wave's pieces of step s have landed ...
-    VP_LDS_BARRIER();   // ... everybody's have, and everybody is done reading the other buffer (step s - 1)
-    if (s + 1 < KS) VP_MAP_DMA(buf ^ 1, s + 1)
+    if constexpr (!(ABL & 8)) {
+      VP_WAIT_VMCNT(0);   // this wave's pieces of step s have landed ...
+      VP_LDS_BARRIER();   // ... everybody's have, and everybody is done reading the other buffer (step s - 1)
+    }
+    if constexpr (!(ABL & 1)) {
+      if (s + 1 < KS) VP_MAP_DMA(buf ^ 1, s + 1)
+    }
     const char* hb = halo0 + buf * H_BUF;
     const char* wb = wgt0 + buf * W_BUF;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int tofs = (t / 3) * HW + (t % 3);
-      const h8_t a_hi = *reinterpret_cast<const h8_t*>(wb + t * 1024 + a_ofs), a_lo = *reinterpret_cast<const h8_t*>(wb + W_PLANE + t * 1024 + a_ofs);
-#pragma unroll
-      for (int j = 0; j < NFW; ++j) {
-        if (wave + 8 * j < NF) {
-          const int R = b_row[j] + tofs;
-          const int o = R * 32 + ((ks ^ ((R >> 3) & 1)) << 4);
-          const h8_t b_hi = *reinterpret_cast<const h8_t*>(hb + o), b_lo = *reinterpret_cast<const h8_t*>(hb + H_PLANE + o);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[j], 0, 0, 0);
-        }
-      }
-    }
+    // Fragments are read ONE TAP AHEAD into a second register set (issued before the current tap's MFMAs, sched_barrier keeps them
+    // there): with the reads right in front of their MFMAs the two waves of a SIMD ran "read -> wait -> multiply" back to back and LDS
+    // latency added to the matrix time instead of hiding under it (tools/map_ablate.hip: fragment reads alone 26 us of decode_layer_2's
+    // 74, MFMAs alone 32, together 58).
+    h8_t fa_hi[2], fa_lo[2], fb_hi[2][NFW], fb_lo[2][NFW];
+#define VP_MAP_READ(SET, T)                                                                                          \
+  {                                                                                                                  \
+    constexpr int tofs_ = ((T) / 3) * HW + ((T) % 3);                                                                \
+    fa_hi[SET] = *reinterpret_cast<const h8_t*>(wb + (T) * 1024 + a_ofs);                                            \
+    fa_lo[SET] = *reinterpret_cast<const h8_t*>(wb + W_PLANE + (T) * 1024 + a_ofs);                                  \
+    _Pragma("unroll") for (int j = 0; j < NFW; ++j) {                                                                \
+      if (wave + 8 * j < NF) {                                                                                       \
+        const int R_ = (ABL & 4) ? b_row[j] : b_row[j] + tofs_;                                                      \
+        const int o_ = R_ * 32 + ((ks ^ ((R_ >> 3) & 1)) << 4);                                                      \
+        fb_hi[SET][j] = *reinterpret_cast<const h8_t*>(hb + o_);                                                     \
+        fb_lo[SET][j] = *reinterpret_cast<const h8_t*>(hb + H_PLANE + o_);                                           \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+#define VP_MAP_MFMA(SET)                                                                                             \
+  _Pragma("unroll") for (int j = 0; j < NFW; ++j) {                                                                  \
+    if (wave + 8 * j < NF) {                                                                                         \
+      if constexpr ((ABL & 2) != 0) {                                                                                \
+        acc[j][0] += (float)fa_lo[SET][0] + (float)fa_hi[SET][1] + (float)fb_hi[SET][j][2] + (float)fb_lo[SET][j][3]; \
+      } else {                                                                                                       \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                 \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_lo[SET][j], acc[j], 0, 0, 0);                 \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                 \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
+#define VP_MAP_TAP(T)                                                                                                \
+  {                                                                                                                  \
+    if constexpr ((T) < 8) VP_MAP_READ(((T) + 1) & 1, (T) + 1)                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    VP_MAP_MFMA((T) & 1)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+    VP_MAP_READ(0, 0)
+    VP_MAP_TAP(0) VP_MAP_TAP(1) VP_MAP_TAP(2) VP_MAP_TAP(3) VP_MAP_TAP(4) VP_MAP_TAP(5) VP_MAP_TAP(6) VP_MAP_TAP(7) VP_MAP_TAP(8)
+#undef VP_MAP_TAP
+#undef VP_MAP_MFMA
+#undef VP_MAP_READ
   }
 #undef VP_MAP_DMA
 
@@ -176,9 +210,9 @@ bool conv3x3_map_supported(const ConvGemmParams& p) {
 hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st) {
   if (!conv3x3_map_supported(p)) return hipErrorInvalidValue;
   static LdsAttrOnce once;
-  if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel), mapk::LDS); e != hipSuccess) return e;
+  if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel<0>), mapk::LDS); e != hipSuccess) return e;
   const int n_regions = (p.H / mapk::RH) * (p.W / mapk::RW);
-  hipLaunchKernelGGL(conv3x3_map_kernel, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(512), mapk::LDS, st, p);
+  hipLaunchKernelGGL(conv3x3_map_kernel<0>, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(512), mapk::LDS, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_splitk_finish(p, st);  // also for nsplit == 1: bias / activation / (hi, lo) split live there
