@@ -40,16 +40,17 @@ constexpr int IPW = (NINSTR + 7) / 8;                    // per wave: 10
 static_assert(RPX % 32 == 0 && LDS <= 160 * 1024, "region / LDS plan");
 }  // namespace mapk
 
-// ABL: ablation bits for tools/map_ablate.hip only (1 = no DMA inside the loop, 2 = no MFMA, 4 = tap-invariant fragment addresses, 8 = no barrier / vmcnt
-// wait in the loop); 0 in the library.
-template <int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParams p) {
+// NFW = pixel tiles of THIS wave: 4 for wave 0 (tiles 0, 8, 16, 24), 3 for the others.  The body is instantiated per count and the kernel
+// branches ONCE on the (scalar) wave index: with `if (tile < 25)` tests inside the tap loop the compiler guarded every tap with
+// s_waitcnt lgkmcnt(0) at the joins, i.e. the fragments requested one tap ahead were awaited BEFORE the current tap's MFMAs.
+template <int NFW, int ABL>
+__device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const int wave) {
   using namespace mapk;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo0 = smem;                 // [2 buffers][2 planes][H_PLANE]
   char* const wgt0 = smem + 2 * H_BUF;      // [2 buffers][2 planes][W_PLANE]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int regions_x = p.W / RW, n_regions = regions_x * (p.H / RH), n_co = p.CoutW >> 5;
   int vid;  // XCD-aware map: the workgroups that share a weight slab (the regions of one channel tile and K slice) are consecutive
   {
@@ -64,40 +65,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParam
   const int KS = (int)(((long long)KS_all * (zsplit + 1)) / p.nsplit) - s_first;
 
   // ---- DMA plan of this wave: instruction ii = wave + 8 i of a step.  [0, 2 NHI): halo, plane ii / NHI, rows 32 g .. 32 g + 31 (lane l:
-  // row 32 g + (l >> 1), stored slot l & 1 = logical slot (l & 1) ^ bit 3 of the row); [2 NHI, NINSTR): weights, linear (host-packed image)
-  int h_goff[IPW];   // halo: element offset of this lane's 16 bytes in step 0, or -1 (outside the map / padding rows: zero page)
+  // row 32 g + (l >> 1), stored slot l & 1 = logical slot (l & 1) ^ bit 3 of the row); [2 NHI, NINSTR): weights, linear (host-packed image).
+  // Everything that depends on the instruction's kind is resolved HERE, once: per instruction a source pointer and a per-step element stride
+  // for this lane (0 for a lane that reads the zero page), a wave-uniform LDS offset and buffer stride -- the loop then issues IPW
+  // branch-free DMA instructions (the last one under a single scalar test: waves 4..7 have nine).
+  const half_t* d_src[IPW];
+  int d_step[IPW], d_dst[IPW], d_buf[IPW];
+  const int n_dma = (NINSTR - wave + 7) / 8;  // instructions of this wave
 #pragma unroll
   for (int i = 0; i < IPW; ++i) {
     const int ii = wave + 8 * i;
-    h_goff[i] = -1;
     if (ii < 2 * NHI) {
-      const int g = ii % NHI, R = 32 * g + (lane >> 1), lslot = (lane & 1) ^ ((R >> 3) & 1);
+      const int pl = ii >= NHI ? 1 : 0, g = ii - pl * NHI;
+      const int R = 32 * g + (lane >> 1), lslot = (lane & 1) ^ ((R >> 3) & 1);
       const int hy = R / HW, hx = R - hy * HW;
       const int gy = ry0 - 1 + hy, gx = rx0 - 1 + hx;
-      if (R < HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) h_goff[i] = (gy * p.W + gx) * p.Cin + lslot * 8;
+      const bool ok = R < HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      d_src[i] = ok ? (pl ? p.in_lo : p.in_hi) + ((size_t)(gy * p.W + gx) * p.Cin + lslot * 8 + s_first * 16) : p.zeros;
+      d_step[i] = ok ? 16 : 0;
+      d_dst[i] = pl * H_PLANE + g * 1024;
+      d_buf[i] = H_BUF;
+    } else {
+      const int wi = (ii < NINSTR ? ii : NINSTR - 1) - 2 * NHI, pl = wi >= NWI ? 1 : 0, pc = wi - pl * NWI;
+      d_src[i] = (pl ? p.w_lo : p.w_hi) + (((size_t)tile_co * KS_all + s_first) * (W_PLANE / 2) + pc * 512 + lane * 8);
+      d_step[i] = W_PLANE / 2;
+      d_dst[i] = 2 * H_BUF + pl * W_PLANE + pc * 1024;
+      d_buf[i] = W_BUF;
     }
   }
-  const size_t w_tile0 = ((size_t)tile_co * KS_all + s_first) * (W_PLANE / 2);  // elements: this channel tile's block of step s_first
 #define VP_MAP_DMA(BUF, STEP)                                                                                         \
   {                                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < IPW; ++i) {                                                                 \
-      const int ii_ = wave + 8 * i;                                                                                   \
-      if (ii_ < 2 * NHI) {                                                                                            \
-        const int pl_ = ii_ >= NHI ? 1 : 0;                                                                           \
-        const half_t* base_ = pl_ ? p.in_lo : p.in_hi;                                                                \
-        const half_t* src_ = h_goff[i] >= 0 ? base_ + h_goff[i] + (s_first + (STEP)) * 16 : p.zeros;                  \
-        VP_GLOBAL_LOAD_LDS16(src_, halo0 + (BUF) * H_BUF + pl_ * H_PLANE + (ii_ - pl_ * NHI) * 1024);                 \
-      } else if (ii_ < NINSTR) {                                                                                      \
-        const int wi_ = ii_ - 2 * NHI, pl_ = wi_ >= NWI ? 1 : 0, pc_ = wi_ - pl_ * NWI;                               \
-        const half_t* base_ = pl_ ? p.w_lo : p.w_hi;                                                                  \
-        VP_GLOBAL_LOAD_LDS16(base_ + w_tile0 + (size_t)(STEP) * (W_PLANE / 2) + pc_ * 512 + lane * 8,                 \
-                             wgt0 + (BUF) * W_BUF + pl_ * W_PLANE + pc_ * 1024);                                      \
-      }                                                                                                               \
+      if (i < IPW - 1 || n_dma == IPW) VP_GLOBAL_LOAD_LDS16(d_src[i] + (size_t)(STEP) * d_step[i], smem + d_dst[i] + (BUF) * d_buf[i]); \
     }                                                                                                                 \
   }
 
   // ---- fragment addressing.  Pixel tile f = wave + 8 j holds region pixels 32 f .. 32 f + 31; lane's pixel -> halo row of tap (0, 0)
-  constexpr int NFW = (NF + 7) / 8;  // 4 (wave 0) or 3
   int b_row[NFW];
 #pragma unroll
   for (int j = 0; j < NFW; ++j) {
@@ -137,24 +140,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParam
     fa_hi[SET] = *reinterpret_cast<const h8_t*>(wb + (T) * 1024 + a_ofs);                                            \
     fa_lo[SET] = *reinterpret_cast<const h8_t*>(wb + W_PLANE + (T) * 1024 + a_ofs);                                  \
     _Pragma("unroll") for (int j = 0; j < NFW; ++j) {                                                                \
-      if (wave + 8 * j < NF) {                                                                                       \
-        const int R_ = (ABL & 4) ? b_row[j] : b_row[j] + tofs_;                                                      \
-        const int o_ = R_ * 32 + ((ks ^ ((R_ >> 3) & 1)) << 4);                                                      \
-        fb_hi[SET][j] = *reinterpret_cast<const h8_t*>(hb + o_);                                                     \
-        fb_lo[SET][j] = *reinterpret_cast<const h8_t*>(hb + H_PLANE + o_);                                           \
-      }                                                                                                              \
+      const int R_ = (ABL & 4) ? b_row[j] : b_row[j] + tofs_;                                                        \
+      const int o_ = R_ * 32 + ((ks ^ ((R_ >> 3) & 1)) << 4);                                                        \
+      fb_hi[SET][j] = *reinterpret_cast<const h8_t*>(hb + o_);                                                       \
+      fb_lo[SET][j] = *reinterpret_cast<const h8_t*>(hb + H_PLANE + o_);                                             \
     }                                                                                                                \
   }
 #define VP_MAP_MFMA(SET)                                                                                             \
   _Pragma("unroll") for (int j = 0; j < NFW; ++j) {                                                                  \
-    if (wave + 8 * j < NF) {                                                                                         \
-      if constexpr ((ABL & 2) != 0) {                                                                                \
-        acc[j][0] += (float)fa_lo[SET][0] + (float)fa_hi[SET][1] + (float)fb_hi[SET][j][2] + (float)fb_lo[SET][j][3]; \
-      } else {                                                                                                       \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                 \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_lo[SET][j], acc[j], 0, 0, 0);                 \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                 \
-      }                                                                                                              \
+    if constexpr ((ABL & 2) != 0) {                                                                                  \
+      acc[j][0] += (float)fa_lo[SET][0] + (float)fa_hi[SET][1] + (float)fb_hi[SET][j][2] + (float)fb_lo[SET][j][3];  \
+    } else {                                                                                                         \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                   \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_lo[SET][j], acc[j], 0, 0, 0);                   \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                   \
     }                                                                                                                \
   }
 #define VP_MAP_TAP(T)                                                                                                \
@@ -176,18 +175,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParam
   const int M = p.H * p.W, co0 = tile_co * 32;
 #pragma unroll
   for (int j = 0; j < NFW; ++j) {
-    if (wave + 8 * j < NF) {
-      const int pix = (wave + 8 * j) * 32 + (lane & 31);
-      const int y = pix / RW, x = pix - y * RW;
-      const int m = (ry0 + y) * p.W + rx0 + x;
-      float* row = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co0 + 4 * (lane >> 5);
+    const int pix = (wave + 8 * j) * 32 + (lane & 31);
+    const int y = pix / RW, x = pix - y * RW;
+    const int m = (ry0 + y) * p.W + rx0 + x;
+    float* row = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co0 + 4 * (lane >> 5);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4_t v = {acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-        *reinterpret_cast<f32x4_t*>(row + 8 * g) = v;
-      }
+    for (int g = 0; g < 4; ++g) {
+      const f32x4_t v = {acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+      *reinterpret_cast<f32x4_t*>(row + 8 * g) = v;
     }
   }
+}
+
+// ABL: ablation bits for tools/map_ablate.hip only (1 = no DMA inside the loop, 2 = no MFMA, 4 = tap-invariant fragment addresses, 8 = no barrier / vmcnt
+// wait in the loop); 0 in the library.
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParams p) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: keep it scalar
+  static_assert(mapk::NF == 25, "wave 0 carries pixel tiles 0, 8, 16, 24; waves 1..7 three each");
+  if (wave == 0) conv3x3_map_body<4, ABL>(p, wave);
+  else conv3x3_map_body<3, ABL>(p, wave);
 }
 
 // weight element (output channel co, input channel ci, tap t) -> index into the packed tensor: [co / 32][ci / 16][plane block of 9 x 32 rows x

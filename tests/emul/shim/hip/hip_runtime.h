@@ -452,6 +452,7 @@ F4 mfma_16x16x32_f16(H8 a, H8 b, F4 c) {
 #define __builtin_amdgcn_wave_barrier() emu::sync_wave()  // lanes of a wave run in lockstep on the device; here they must meet
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0u
+#define __builtin_amdgcn_readfirstlane(x) (x)   // used on wave-uniform values only
 
 #define threadIdx (emu::cur->tid)
 #define blockIdx (emu::cur->bid)
