@@ -422,8 +422,13 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         }
       }
       // squeeze-excite -> per-frame scaled projection weights
+      // parity mode, one frame per pass: squeeze-excite tail + projection (+ residual) as ONE launch (kernels_mbconv.hip, back half).
+      // VP_MBCONV_BACK=0 (developer knob, A/B timing): se_gate_scale + the projection GEMM (+ its split-K finish).
+      static const char* env_mbb = std::getenv("VP_MBCONV_BACK");
+      const bool fuse_back = split() && N == 1 && !(env_mbb && env_mbb[0] == '0');
       SeParams se{};
       const float *se_w2 = nullptr, *se_b2 = nullptr;
+      std::vector<float> se_w2_host;  // [C][sq]
       std::string se_name;
       {
         const std::string sp = bp + std::to_string(j);
@@ -447,14 +452,52 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         se.inv_hw = 1.0f / (float)HWz;
         se.w1 = dupload(w1p);
         se.b1 = dupload(b1.data);
-        se_w2 = dupload(w2p);
+        if (fuse_back) se_w2_host = w2p;
+        else se_w2 = dupload(w2p);
         se_b2 = dupload(b2p);
         se.frames = N;
         se_name = sp;
         ++j;
       }
       // project 1x1 (+BN folded) with SE scale folded into K, optional residual
-      {
+      if (fuse_back) {
+        Folded f = fold_conv_bn(blob, bp + std::to_string(j));
+        if (f.cout != S.cout || f.cin != cexp || f.k != 1) throw std::runtime_error("projection conv shape mismatch: " + bp);
+        const bool residual = (stride == 1 && cin == S.cout);
+        Act* out = new_act(bp + std::to_string(j), S.cout, z->H, z->W);
+        out->frames = N;
+        std::vector<float> wf((size_t)out->C * z->C, 0.0f), bias(out->C, 0.0f);
+        for (int co = 0; co < S.cout; ++co) {
+          for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c];
+          bias[co] = f.b[co];
+        }
+        for (float v : wf)
+          if (!(std::fabs(v) <= 65504.0f)) throw RangeError("projection weight " + std::to_string(v) + " of " + bp + " is outside the fp16 range the matrix pipe carries (|w| <= 65504): re-scale the checkpoint");
+        const int sqp = round_up(sq, 4);
+        std::vector<float> w2q((size_t)sqp * z->C, 0.0f);
+        for (int c = 0; c < z->C; ++c)
+          for (int q = 0; q < sq; ++q) w2q[((size_t)(q >> 2) * z->C + c) * 4 + (q & 3)] = se_w2_host[(size_t)c * sq + q];
+        MbBackParams mb{};
+        mb.in = z->view();
+        mb.se = se;
+        mb.se.frames = 1;
+        mb.w2q = dupload(w2q);
+        mb.b2 = se_b2;
+        mb.sqp = sqp;
+        mb.w = dupload(wf);
+        mb.bias = dupload(bias);
+        if (residual) mb.res = x->view();
+        mb.out = out->view();
+        if (!mbconv_back_supported(mb)) throw std::runtime_error("fused MBConv back: unsupported shape: " + bp);
+        Op op;
+        op.name = bp + std::to_string(j - 1) + "+" + std::to_string(j);   // squeeze-excite + projection
+        op.flops = 2.0 * cexp * S.cout * z->H * z->W + 4.0 * sq * cexp;
+        op.bytes = 4.0 * (z->elems() + out->elems() + (residual ? x->elems() : 0)) + 4.0 * wf.size();
+        op.kernel = std::string("mbconv_back<wm") + (z->H * z->W >= 12800 ? "4" : "1") + ">";
+        op.run = [mb](hipStream_t st) { return launch_mbconv_back(mb, st); };
+        ops_.push_back(std::move(op));
+        x = out;
+      } else {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         const int ncols = round_up(S.cout, 32);
         ConvOpts o;

@@ -97,6 +97,20 @@ struct ScaleWParams {
   int frames;       // batched encoder: grid.y = frame; out_hi / out_lo [frames][rows][C]
 };
 
+// MBConv back half in one launch (kernels_mbconv.hip): squeeze-excite gate -> projection 1x1 (+BN) with the gate folded into its K axis
+// (+ residual).  One frame per pass, (hi, lo) activations.
+struct MbBackParams {
+  ActView in;          // depthwise output, H x W x C (hi, lo)
+  SeParams se;         // pool sums of that tensor, squeeze FC (frames == 1, se.C == in.C)
+  const float* w2q;    // excite FC as [sqp / 4][C][4]: w2q[(q * C + c) * 4 + i] = fc2.weight[c][4 q + i], zero beyond sq
+  const float* b2;     // [C]
+  int sqp;             // sq rounded up to a multiple of 4
+  const float* w;      // [out.C][C] fp32 projection weights (BN folded), zero rows / columns in the padding
+  const float* bias;   // [out.C]
+  ActView res;         // residual (the block's input, same geometry as out) or hi == nullptr
+  ActView out;         // H x W x Cout_pad (hi, lo)
+};
+
 struct FcParams {
   const float* x;
   const float* w;  // [N][K]
@@ -164,6 +178,8 @@ hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 bool mbconv_front_supported(const MbFrontParams& p);
 hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st);
+bool mbconv_back_supported(const MbBackParams& p);
+hipError_t launch_mbconv_back(const MbBackParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);
 hipError_t launch_zero_u64(unsigned long long* p, size_t n, hipStream_t st);
 // The fused average pool spreads its atomics over `replicas` rows: same-address atomics serialise in L2 (measured:

@@ -18,6 +18,7 @@
 // two-launch path.  fp16x3 engines, one frame per pass (the batched encoder and the fp16 engines keep the two launches).
 #include "act_io.hpp"
 #include "conv_epilogue.hpp"
+#include "se_phases.hpp"
 
 namespace vp {
 
@@ -233,6 +234,183 @@ hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st) {
   if (p.k == 5 && p.stride == 1) return launch_mb<5, 1>(p, st);
   if (p.k == 3 && p.stride == 2) return launch_mb<3, 2>(p, st);
   return launch_mb<5, 2>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------- back half
+// MBConv back half in ONE launch: squeeze-excite tail (means -> squeeze FC + SiLU -> excite FC + sigmoid) -> projection 1x1 (+BN)
+// with the gate folded into its K axis (+ residual) -- torchvision MBConv.block[2..3] + the stochastic-depth-free skip
+// (Models/model_components/backbone.py:9-22).  It replaces se_gate_scale + the projection GEMM + (on the <= 20x40 maps) its
+// split-K finish: three dependent launches of 7-18 + 6-13 + 5-6 us in the replayed graph for a few hundred MFLOP.
+//   * workgroup = 32 WM pixels x 32 output channels, ALL of K.  WM = 1 (maps up to 40x80: 42 ... 200 workgroups): the four waves take
+//     a quarter of the K steps each and meet in LDS (fixed order: bit-deterministic).  WM = 4 (80x160, 160x320, K = 32 ... 160): a
+//     wave owns 32 pixels and all of K, so the gate is rebuilt by 100 / 400 workgroups instead of 400 / 1600.
+//   * every workgroup REBUILDS the gate itself (the two FC matrices are <= 2 x 221 KB, L2-resident): no launch boundary, no
+//     device-wide hand-off (a buffer_wbl2 per workgroup costs more than the FCs: profiles/r03_splitk_fold_ab.tsv).
+//   * the operands do not pass through LDS: a lane's MFMA fragments ARE 16 / 32 contiguous bytes of a pixel row / weight row, loaded
+//     straight from global (L2) memory, three K steps in flight; the first batch and the residual are requested BEFORE the gate
+//     phases, so the FC round trips and the operand round trip overlap.
+//   * W'[n][k] = W[n][k] * gate[k], (hi, lo) split, per fragment in registers -- the arithmetic of se_gate_scale's phase 4.
+struct MbBackFrag {
+  f32x4_t w0, w1;  // 8 fp32 projection weights of this lane's row
+  h8_t xh, xl;     // 8 channels of this lane's pixel, (hi, lo)
+};
+
+template <int WM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void mbconv_back_kernel(const MbBackParams p) {
+  constexpr int U = 3;                  // K steps per batch in flight
+  constexpr int NSH = 4 / WM;           // K shares (waves per pixel tile)
+  constexpr int RP = 32 * 4 + 16;       // bytes per pixel row of a wave's partial tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char bk_smem[];
+  const int C = p.se.C;
+  const int acc_rows = se_acc_rows(C);
+  unsigned long long* const accs = reinterpret_cast<unsigned long long*>(bk_smem);             // [acc_rows][C]
+  float* const mean = reinterpret_cast<float*>(bk_smem + (size_t)acc_rows * C * 8);            // [C]
+  float* const gate = mean + C;                                                                 // [C]
+  unsigned char* const rb = reinterpret_cast<unsigned char*>(gate + C);                         // [4 waves][32 pixels][RP]
+  __shared__ float red[256];
+  __shared__ __attribute__((aligned(16))) float s1[64];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int M = p.in.H * p.in.W, Cout = p.out.C;
+  const int pxw = blockIdx.x * 32 * WM, co0 = blockIdx.y * 32;   // first pixel of the workgroup
+  const int px0 = pxw + (wave % WM) * 32;                        // ... and of this wave's tile
+  // this wave's K steps (16 channels each)
+  const int KS = C >> 4, sh = wave / WM;
+  const int ks0 = sh * KS / NSH, nst = (sh + 1) * KS / NSH - ks0;
+  const int pxl = min(px0 + (lane & 31), M - 1);        // rows past the map repeat its last pixel (never stored)
+  const float* const wrow = p.w + (size_t)(co0 + (lane & 31)) * C + 8 * (lane >> 5);
+  const size_t xoff = (size_t)pxl * C + 8 * (lane >> 5);
+  MbBackFrag nxt[U];
+#define VP_MBB_LOAD(S0)                                                               \
+  {                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                   \
+      const int k_ = min(ks0 + (S0) + u, KS - 1) * 16;                                \
+      nxt[u].w0 = *reinterpret_cast<const f32x4_t*>(wrow + k_);                       \
+      nxt[u].w1 = *reinterpret_cast<const f32x4_t*>(wrow + k_ + 4);                   \
+      nxt[u].xh = *reinterpret_cast<const h8_t*>(p.in.hi + xoff + k_);                \
+      nxt[u].xl = *reinterpret_cast<const h8_t*>(p.in.lo + xoff + k_);                \
+    }                                                                                 \
+  }
+  VP_MBB_LOAD(0)
+  // epilogue items of this thread: pixel 32 t + (tid >> 3) of the workgroup (t < WM), channels 4 (tid & 7) .. + 4; the residual and the
+  // bias travel under the gate phases
+  const int epx = pxw + (tid >> 3), ec = co0 + 4 * (tid & 7);
+  typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+  h4_t r_hi[WM], r_lo[WM];
+#pragma unroll
+  for (int t = 0; t < WM; ++t) {
+    r_hi[t] = r_lo[t] = h4_t{0, 0, 0, 0};
+    if (p.res.hi && epx + 32 * t < M) {
+      r_hi[t] = *reinterpret_cast<const h4_t*>(p.res.hi + (size_t)(epx + 32 * t) * Cout + ec);
+      r_lo[t] = *reinterpret_cast<const h4_t*>(p.res.lo + (size_t)(epx + 32 * t) * Cout + ec);
+    }
+  }
+  const f32x4_t bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + ec);
+
+  // ---- gate: means, squeeze FC (shared with se_gate_scale_kernel), excite FC + sigmoid for ALL channels
+  se_means_squeeze<(WM == 4 ? 4 : 16)>(p.se, accs, mean, red, s1);  // WM = 4: C <= 160, a thread of the squeeze FC has one or two loads
+  {
+    const int nq = p.sqp >> 2;
+    const f32x4_t* s4 = reinterpret_cast<const f32x4_t*>(s1);
+    for (int c = tid; c < C; c += 256) {
+      const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w2q) + c;
+      float s = 0.f;
+#pragma unroll 4
+      for (int q = 0; q < nq; ++q) {
+        const f32x4_t a = wr[(size_t)q * C], m = s4[q];
+        s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+      }
+      gate[c] = c < p.se.Creal ? sigmoid_f(s + p.b2[c]) : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  // ---- projection: A = scaled weights (32 output channels x 16 k), B = pixels (32 x 16 k); a lane's 16 accumulators are channels
+  // 8 g + 4 (lane >> 5) + r (g, r = 0..3) of pixel lane & 31
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int s = 0; s < nst; s += U) {
+    MbBackFrag cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    if (s + U < nst) VP_MBB_LOAD(s + U)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u < nst) {
+        const float* gk = gate + (ks0 + s + u) * 16 + 8 * (lane >> 5);
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gk), g1 = *reinterpret_cast<const f32x4_t*>(gk + 4);
+        h8_t a_hi, a_lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = (i < 4 ? cur[u].w0[i] * g0[i] : cur[u].w1[i - 4] * g1[i - 4]);
+          a_hi[i] = (half_t)v;
+          a_lo[i] = (half_t)(v - (float)a_hi[i]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, cur[u].xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, cur[u].xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, cur[u].xh, acc, 0, 0, 0);
+      }
+    }
+  }
+#undef VP_MBB_LOAD
+  // ---- the K shares of a pixel tile meet in LDS (fixed order), bias, residual, (hi, lo) store
+  {
+    unsigned char* const mine = rb + wave * 32 * RP + (lane & 31) * RP + 16 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4_t v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[4 * g + r];
+      *reinterpret_cast<f32x4_t*>(mine + 32 * g) = v;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < WM; ++t) {
+    const int px = epx + 32 * t;
+    if (px >= M) continue;
+    const unsigned char* src = rb + t * 32 * RP + (tid >> 3) * RP + 16 * (tid & 7);   // wave t = share 0 of tile t
+    f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
+#pragma unroll
+    for (int j = 1; j < NSH; ++j) {
+      const f32x4_t q = *reinterpret_cast<const f32x4_t*>(src + j * WM * 32 * RP);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += q[r];
+    }
+    h4_t o_hi, o_lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y = v[r] + bias4[r];
+      if (p.res.hi) y += (float)r_hi[t][r] + (float)r_lo[t][r];
+      o_hi[r] = (half_t)y;
+      o_lo[r] = (half_t)(y - (float)o_hi[r]);
+    }
+    *reinterpret_cast<h4_t*>(p.out.hi + (size_t)px * Cout + ec) = o_hi;
+    *reinterpret_cast<h4_t*>(p.out.lo + (size_t)px * Cout + ec) = o_lo;
+  }
+}
+
+bool mbconv_back_supported(const MbBackParams& p) {
+  const SeParams& se = p.se;
+  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && se.sums && se.w1 && se.b1 && p.w2q && p.b2 && p.w && p.bias && se.frames <= 1 &&
+         se.C == p.in.C && (se.C & 31) == 0 && se.C >= 32 && (p.out.C & 31) == 0 && se.sq >= 1 && se.sq <= 64 && p.sqp >= se.sq && (p.sqp & 3) == 0 && p.sqp <= 64 &&
+         se.replicas >= 1 && p.out.H == p.in.H && p.out.W == p.in.W && p.in.H * p.in.W >= 1 &&
+         (!p.res.hi || (p.res.lo && p.res.C == p.out.C && p.res.H == p.out.H && p.res.W == p.out.W));
+}
+
+hipError_t launch_mbconv_back(const MbBackParams& p, hipStream_t st) {
+  if (!mbconv_back_supported(p)) return hipErrorInvalidValue;
+  const int C = p.se.C;
+  const size_t lds = (size_t)C * (8 * se_acc_rows(C) + 8) + 4 * 32 * (32 * 4 + 16);
+  const int M = p.in.H * p.in.W;
+  if (M >= 12800) {  // 80x160 and 160x320: K is 2 ... 10 steps, a wave per pixel tile
+    hipLaunchKernelGGL(mbconv_back_kernel<4>, dim3((M + 127) / 128, p.out.C / 32), dim3(256), lds, st, p);
+  } else {
+    hipLaunchKernelGGL(mbconv_back_kernel<1>, dim3((M + 31) / 32, p.out.C / 32), dim3(256), lds, st, p);
+  }
+  return hipGetLastError();
 }
 
 }  // namespace vp

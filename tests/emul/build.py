@@ -2,7 +2,8 @@
 HOST on top of the HIP-on-CPU shim (shim/hip/hip_runtime.h), so the CPU suite can execute the real kernel and engine code
 against the oracle.  Source rewrites (listed here, nothing else differs from what hipcc compiles):
   * `extern __shared__`  ->  `extern VP_EMU_LDS`           (dynamic LDS is per-worker storage in harness.cpp)
-  * the two inline-asm statements (an AGPR read, an ablation-only register pin) -> their plain C++ equivalents.
+  * the two inline-asm statements (an AGPR read, an ablation-only register pin) -> their plain C++ equivalents;
+  * the register-budget attribute of one kernel (`amdgpu_waves_per_eu`) is dropped.
 Linked with -Bsymbolic and meant to be dlopen-ed RTLD_LOCAL: it exports the same symbols as libvp_hip.so and must neither
 capture nor be captured by that library when both live in one test process."""
 import os
@@ -16,12 +17,13 @@ OUT = os.path.join(HERE, "_build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 UNITS = ("kernels_conv.hip", "kernels_convt_rs.hip", "kernels_head.hip", "kernels_gemm_dma.hip", "kernels_conv3x3.hip", "kernels_conv3x3_x3.hip", "kernels_conv3x3_map.hip", "kernels_backbone.hip", "kernels_mbconv.hip",
          "kernels_misc.hip", "kernels_autodrive.hip", "engine.cpp", "engine_dispatch.cpp", "engine_io.cpp", "onnx_reader.cpp", "vp_api.cpp")
-HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp", "conv_epilogue.hpp", "lds_dma.hpp", "engine.hpp", "engine_internal.hpp", "vp_handle.hpp", "viridis_lut.inc")
+HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp", "se_phases.hpp", "conv_epilogue.hpp", "lds_dma.hpp", "engine.hpp", "engine_internal.hpp", "vp_handle.hpp", "viridis_lut.inc")
 REWRITES = (
     ('asm volatile("" : "+v"(lane_o_));', "(void)0;"),
     ("extern __shared__", "extern VP_EMU_LDS"),
     ('asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));', "v = acc[i][j][4 * g + r];"),
     ('asm volatile("" ::"v"(a_[i]), "v"(b_[j]));', "(void)0;"),
+    ("__attribute__((amdgpu_waves_per_eu(3))) ", ""),
 )
 
 

@@ -7,6 +7,7 @@ namespace vp {  // dynamic-LDS arrays of the kernels (per worker thread = per ru
 alignas(16) VP_EMU_LDS char smem[160 << 10];
 alignas(16) VP_EMU_LDS unsigned char dw_smem[160 << 10];
 alignas(16) VP_EMU_LDS unsigned char se_smem[64 << 10];
+alignas(16) VP_EMU_LDS unsigned char bk_smem[64 << 10];
 alignas(16) VP_EMU_LDS float xs[40 << 10];
 alignas(16) VP_EMU_LDS float sh[40 << 10];
 }  // namespace vp
@@ -97,6 +98,18 @@ int emu_mbconv_front(void* in_hi, void* in_lo, int H, int W, int Cin, const void
   p.out = view(out_hi, out_lo, H / stride, W / stride, Cexp);
   p.k = k; p.stride = stride; p.sums = sums; p.replicas = replicas;
   return launch_mbconv_front(p, nullptr);
+}
+int emu_mbconv_back(void* in_hi, void* in_lo, int H, int W, int C, int Creal, const unsigned long long* sums, int replicas, int sq, const float* w1,
+                    const float* b1, const float* w2q, const float* b2, int sqp, const float* w, const float* bias, void* res_hi, void* res_lo,
+                    void* out_hi, void* out_lo, int Cout) {
+  MbBackParams p{};
+  p.in = view(in_hi, in_lo, H, W, C);
+  p.se.sums = sums; p.se.replicas = replicas; p.se.C = C; p.se.Creal = Creal; p.se.sq = sq; p.se.inv_hw = 1.0f / (float)(H * W); p.se.w1 = w1; p.se.b1 = b1;
+  p.se.frames = 1;
+  p.w2q = w2q; p.b2 = b2; p.sqp = sqp; p.w = w; p.bias = bias;
+  if (res_hi) p.res = view(res_hi, res_lo, H, W, Cout);
+  p.out = view(out_hi, out_lo, H, W, Cout);
+  return launch_mbconv_back(p, nullptr);
 }
 int emu_se_gate_scale(const unsigned long long* sums, int replicas, int C, int Creal, int sq, float inv_hw, const float* w1, const float* b1,
                       const float* w, void* out_hi, void* out_lo, int rows, const float* w2, const float* b2, int frames) {

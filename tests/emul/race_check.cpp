@@ -22,6 +22,8 @@ int emu_stem(const float*, int, int, const float*, const float*, void*, void*);
 int emu_dwconv(void*, void*, int, int, int, void*, void*, int, int, const float*, const float*, int, int, unsigned long long*, int);
 int emu_se_gate_scale(const unsigned long long*, int, int, int, int, float, const float*, const float*, const float*, void*, void*, int, const float*, const float*, int);
 int emu_mbconv_front(void*, void*, int, int, int, const void*, const void*, const float*, const float*, const float*, void*, void*, int, int, int, unsigned long long*, int);
+int emu_mbconv_back(void*, void*, int, int, int, int, const unsigned long long*, int, int, const float*, const float*, const float*, const float*, int, const float*, const float*,
+                    void*, void*, void*, void*, int);
 int emu_fc(const float*, const float*, const float*, float*, int, int, int);
 int emu_pool_partial(void*, void*, int, int, int, float*, int);
 int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
@@ -147,6 +149,15 @@ int main(int argc, char** argv) {
       std::vector<float> be = rnd(cexp, 0.1f), wk = rnd((size_t)k * k * cexp, 0.3f), bb = rnd(cexp, 0.1f);
       std::vector<unsigned long long> sums(4 * cexp, 0ull);
       bad |= emu_mbconv_front(ih.data(), il.data(), h, ww, cin, wh.data(), wl.data(), be.data(), wk.data(), bb.data(), oh_.data(), ol_.data(), cexp, k, stride, sums.data(), 4);
+    }
+    // fused MBConv back: the gate phases' LDS hand-offs, the waves' partial tiles meeting in LDS (a wave per K quarter / per pixel tile)
+    for (int cfg = 0; cfg < (quick ? 1 : 2); ++cfg) {
+      const int C = 96, cout = 64, sq = 6, sqp = 8, h = cfg ? 100 : 5, ww = cfg ? 128 : 9, m = h * ww;   // 12800 pixels: the wide instantiation
+      std::vector<half_t> ih = rnd16((size_t)m * C), il = rnd16(ih.size()), rh = rnd16((size_t)m * cout), rl = rnd16(rh.size()), oh_((size_t)m * cout), ol_(oh_.size());
+      std::vector<unsigned long long> sums(8 * C, 1ull << 20);
+      std::vector<float> w1 = rnd(sq * C, 0.2f), b1 = rnd(sq, 0.1f), w2q = rnd((size_t)sqp * C, 0.5f), b2 = rnd(C, 0.1f), pw = rnd((size_t)cout * C), pb = rnd(cout);
+      bad |= emu_mbconv_back(ih.data(), il.data(), h, ww, C, C, sums.data(), 8, sq, w1.data(), b1.data(), w2q.data(), b2.data(), sqp, pw.data(), pb.data(), rh.data(), rl.data(),
+                             oh_.data(), ol_.data(), cout);
     }
     std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
     bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);

@@ -249,6 +249,60 @@ def test_mbconv_front_kernel(emu, cin, cexp, k, stride, H, W):
     assert np.abs(pooled - got.astype(np.float64).sum(axis=(1, 2))).max() <= 1e-4
 
 
+@pytest.mark.parametrize("cexp,cout,sq,H,W,residual", [(1152, 192, 48, 10, 20, True), (144, 40, 6, 9, 13, False), (240, 40, 10, 40, 80, True),
+                                                      (96, 24, 4, 80, 160, False), (32, 16, 8, 81, 160, False)])
+def test_mbconv_back_kernel(emu, cexp, cout, sq, H, W, residual):
+    """kernels_mbconv.hip, back half: squeeze-excite tail (means from the replica rows -> squeeze FC + SiLU -> excite FC + sigmoid) -> projection
+    1x1 with the gate folded into its K axis (+ bias, + residual) in ONE launch, against float64 numpy: both instantiations (a wave per K
+    quarter on the <= 40x80 maps, a wave per pixel tile on the big ones), K steps that do not divide by four, a last pixel tile of 8 / 21
+    rows, channel counts padded to 32 (pad input channels gated to 0, pad output channels exactly 0), sq not a multiple of 4."""
+    rng = np.random.default_rng(cexp + cout)
+    C, Cout = (cexp + 31) // 32 * 32, (cout + 31) // 32 * 32
+    M, replicas = H * W, 8
+    x = np.zeros((M, C), np.float32)
+    x[:, :cexp] = (rng.standard_normal((M, cexp)) * (1.0 + rng.random(cexp))).astype(np.float32)
+    xh, xl = split16(x)
+    xv = xh.astype(np.float64) + xl.astype(np.float64)
+    fixed = np.rint(xv * 2.0 ** 24).astype(np.int64)
+    sums = np.zeros((replicas, C), dtype=np.int64)
+    for r in range(replicas):
+        sums[r] = fixed[r::replicas].sum(axis=0)
+    w1 = np.zeros((sq, C), np.float32)
+    w1[:, :cexp] = rng.standard_normal((sq, cexp)).astype(np.float32) * 0.2
+    b1 = (rng.standard_normal(sq) * 0.1).astype(np.float32)
+    w2 = np.zeros((C, sq), np.float32)
+    w2[:cexp] = rng.standard_normal((cexp, sq)).astype(np.float32) * 0.5
+    b2 = np.zeros(C, np.float32)
+    b2[:cexp] = rng.standard_normal(cexp).astype(np.float32) * 0.2
+    sqp = (sq + 3) // 4 * 4
+    w2q = np.zeros((sqp // 4, C, 4), np.float32)
+    for q in range(sq):
+        w2q[q // 4, :, q % 4] = w2[:, q]
+    w = np.zeros((Cout, C), np.float32)
+    w[:cout, :cexp] = (rng.standard_normal((cout, cexp)) * np.sqrt(1.0 / cexp)).astype(np.float32)
+    bias = np.zeros(Cout, np.float32)
+    bias[:cout] = (rng.standard_normal(cout) * 0.2).astype(np.float32)
+    res = np.zeros((M, Cout), np.float32)
+    res[:, :cout] = rng.standard_normal((M, cout)).astype(np.float32)
+    rh, rl = split16(res)
+    oh, ol = np.full((M, Cout), 7, np.float16), np.full((M, Cout), 7, np.float16)
+    emu.emu_mbconv_back.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int] + [ct.c_void_p] * 4 + \
+        [ct.c_int] + [ct.c_void_p] * 6 + [ct.c_int]
+    assert emu.emu_mbconv_back(ptr(xh), ptr(xl), H, W, C, cexp, ptr(sums.view(np.uint64)), replicas, sq, ptr(w1), ptr(b1), ptr(w2q), ptr(b2), sqp, ptr(w),
+                               ptr(bias), ptr(rh) if residual else None, ptr(rl) if residual else None, ptr(oh), ptr(ol), Cout) == 0
+    mean = fixed.sum(axis=0).astype(np.float64) / 2.0 ** 24 / M
+    z = w1.astype(np.float64) @ mean + b1
+    s1 = z / (1.0 + np.exp(-z))
+    gate = 1.0 / (1.0 + np.exp(-(w2.astype(np.float64) @ s1 + b2)))
+    gate[cexp:] = 0.0
+    want = (xv * gate[None, :]) @ w.astype(np.float64).T + bias
+    if residual:
+        want = want + rh.astype(np.float64) + rl.astype(np.float64)
+    got = oh.astype(np.float64) + ol.astype(np.float64)
+    assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
+    assert not got[:, cout:].any()
+
+
 def test_squeeze_excite_kernel(emu):
     """se_gate_scale: means from the replica rows -> squeeze FC -> SiLU -> excite FC -> sigmoid gate folded into the projection
     weights' K axis (pad channels gated to 0), one launch; wide (sq = 48, C = 1152: 5 K segments per unit) and narrow (sq = 4:
