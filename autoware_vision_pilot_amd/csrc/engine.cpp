@@ -288,7 +288,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
   // ---- squeeze-excite pool accumulators of all 16 MBConv blocks: one arena, one memset node per frame
   constexpr int kSeBlocks = 16;
   const int N = frames_;  // batched encoder: activations are N frames stacked along H, one launch covers all of them where it can
-  const size_t se_words = (size_t)N * ((size_t)kSeBlocks * 1536 * 8 + (size_t)6 * 256 * kSeMaxReplicas);  // >= sum of N*replicas*C below (checked)
+  const size_t se_words = (size_t)N * ((size_t)kSeBlocks * 1536 * 8 + (size_t)6 * 256 * kSeMaxReplicas) + (size_t)kSeBlocks * 64 * kSeMaxReplicas;  // >= sum of N*replicas*C (+ replicas*64 squeeze sums) below (checked)
   unsigned long long* se_arena = static_cast<unsigned long long*>(dalloc(se_words * sizeof(unsigned long long)));
   int se_block = 0;
   size_t se_used = 0;
@@ -362,6 +362,24 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       unsigned long long* sums = se_arena + se_used;  // [N][se_rep][C]
       se_used += (size_t)N * se_rep * z->C;
       ++se_block;
+      // fused front + fused back: the squeeze FC travels with the pool sums ([se_rep][64] fixed-point numbers, same arena: zeroed per frame)
+      static const char* env_mbb0 = std::getenv("VP_MBCONV_BACK");
+      unsigned long long* zsums = nullptr;
+      if (fuse_front && !(env_mbb0 && env_mbb0[0] == '0')) {
+        if (se_used + (size_t)se_rep * 64 > se_words) throw std::runtime_error("SE arena too small");
+        zsums = se_arena + se_used;
+        se_used += (size_t)se_rep * 64;
+      }
+      const float* d_se_w1 = nullptr;   // squeeze FC matrix, uploaded once (shared by the front and back halves)
+      if (zsums) {
+        const std::string sp = bp + std::to_string(j + 1);
+        const HostTensor& w1 = blob.get(sp + ".fc1.weight");
+        if (w1.shape[0] != sq || w1.shape[1] != cexp) throw std::runtime_error("SE fc1 shape mismatch: " + sp);
+        std::vector<float> w1p((size_t)sq * z->C, 0.0f);
+        for (int q = 0; q < sq; ++q)
+          for (int c = 0; c < cexp; ++c) w1p[(size_t)q * z->C + c] = w1.data[(size_t)q * cexp + c];
+        d_se_w1 = dupload(w1p);
+      }
       {
         Folded f = fold_conv_bn(blob, bp + std::to_string(j));
         const int kk = S.k * S.k;
@@ -390,6 +408,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           mp.stride = stride;
           mp.sums = sums;
           mp.replicas = se_rep;
+          mp.w1 = d_se_w1;
+          mp.sq = sq;
+          mp.zsums = zsums;
           if (!mbconv_front_supported(mp)) throw std::runtime_error("fused MBConv front: unsupported shape: " + bp);
           Op op;
           op.name = bp + "0+" + std::to_string(j);   // expand + depthwise
@@ -450,7 +471,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         se.Creal = cexp;
         se.sq = sq;
         se.inv_hw = 1.0f / (float)HWz;
-        se.w1 = dupload(w1p);
+        se.w1 = d_se_w1 ? d_se_w1 : dupload(w1p);
         se.b1 = dupload(b1.data);
         if (fuse_back) se_w2_host = w2p;
         else se_w2 = dupload(w2p);
@@ -481,6 +502,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         mb.in = z->view();
         mb.se = se;
         mb.se.frames = 1;
+        mb.zsums = zsums;
         mb.w2q = dupload(w2q);
         mb.b2 = se_b2;
         mb.sqp = sqp;

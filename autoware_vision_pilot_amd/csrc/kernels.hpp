@@ -68,6 +68,11 @@ struct MbFrontParams {
   int k, stride;
   unsigned long long* sums;  // [replicas][Cexp_pad] fixed-point channel sums (as DwParams)
   int replicas;
+  // optional: the squeeze FC of the block's squeeze-excite, taken here from the workgroup's own channel sums (it is linear in them):
+  // zsums[replica][j] += fixed(sum_c w1[j][c] * patch_sum[c]) -- the back half (mbconv_back) then starts from sq numbers, not from the means
+  const float* w1;            // [sq][Cexp_pad] or null
+  int sq;
+  unsigned long long* zsums;  // [replicas][64] 2^24 fixed point
 };
 
 struct PoolParams {
@@ -102,6 +107,7 @@ struct ScaleWParams {
 struct MbBackParams {
   ActView in;          // depthwise output, H x W x C (hi, lo)
   SeParams se;         // pool sums of that tensor, squeeze FC (frames == 1, se.C == in.C)
+  const unsigned long long* zsums;  // [se.replicas][64] pre-activation squeeze sums from mbconv_front (MbFrontParams::zsums), or null: means + FC here
   const float* w2q;    // excite FC as [sqp / 4][C][4]: w2q[(q * C + c) * 4 + i] = fc2.weight[c][4 q + i], zero beyond sq
   const float* b2;     // [C]
   int sqp;             // sq rounded up to a multiple of 4

@@ -208,11 +208,25 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     const unsigned long long v = red64[tid];
     if (v != 0ull) atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * Cexp + c0 + tid, v);
   }
+  // squeeze FC of the squeeze-excite, this workgroup's share (32 channels x its patch): linear in the sums, so it can be taken here and
+  // added up as integers like them -- mbconv_back then reads sq numbers instead of streaming the FC matrix through every workgroup
+  if (p.w1 && tid >= 64 && tid < 64 + p.sq) {
+    const int j = tid - 64;
+    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)j * Cexp + c0);
+    float z = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4_t w4 = wr[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z = fmaf(w4[i], (float)((double)(long long)red64[4 * q + i] * (1.0 / 16777216.0)), z);
+    }
+    atomicAdd(p.zsums + (size_t)(blockIdx.x & (p.replicas - 1)) * 64 + j, (unsigned long long)(long long)__float2ll_rn(z * 16777216.0f));
+  }
 }
 
 bool mbconv_front_supported(const MbFrontParams& p) {
   return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.w_dw && p.b_dw && p.sums && (p.k == 3 || p.k == 5) &&
-         (p.stride == 1 || p.stride == 2) && (p.in.C & 31) == 0 && (p.out.C & 31) == 0 && p.replicas >= 1 && (p.replicas & (p.replicas - 1)) == 0 &&
+         (p.stride == 1 || p.stride == 2) && (!p.w1 || (p.zsums && p.sq >= 1 && p.sq <= 64)) && (p.in.C & 31) == 0 && (p.out.C & 31) == 0 && p.replicas >= 1 && (p.replicas & (p.replicas - 1)) == 0 &&
          p.out.H == p.in.H / p.stride && p.out.W == p.in.W / p.stride && p.in.H % p.stride == 0 && p.in.W % p.stride == 0;
 }
 
@@ -241,9 +255,10 @@ hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st) {
 // with the gate folded into its K axis (+ residual) -- torchvision MBConv.block[2..3] + the stochastic-depth-free skip
 // (Models/model_components/backbone.py:9-22).  It replaces se_gate_scale + the projection GEMM + (on the <= 20x40 maps) its
 // split-K finish: three dependent launches of 7-18 + 6-13 + 5-6 us in the replayed graph for a few hundred MFLOP.
-//   * workgroup = 32 WM pixels x 32 output channels, ALL of K.  WM = 1 (maps up to 40x80: 42 ... 200 workgroups): the four waves take
-//     a quarter of the K steps each and meet in LDS (fixed order: bit-deterministic).  WM = 4 (80x160, 160x320, K = 32 ... 160): a
-//     wave owns 32 pixels and all of K, so the gate is rebuilt by 100 / 400 workgroups instead of 400 / 1600.
+//   * workgroup = 32 WM pixels x 32 output channels, ALL of K.  WM = 1 (maps up to 40x80: 42 ... 200 workgroups): EIGHT waves take
+//     an eighth of the K steps each and meet in LDS (fixed order: bit-deterministic); 512 threads also halve the round trips of the
+//     two FC phases.  WM = 4 (80x160, 160x320, K = 32 ... 160): four waves, each owns 32 pixels and all of K, so the gate is rebuilt
+//     by 100 / 400 workgroups instead of 400 / 1600.
 //   * every workgroup REBUILDS the gate itself (the two FC matrices are <= 2 x 221 KB, L2-resident): no launch boundary, no
 //     device-wide hand-off (a buffer_wbl2 per workgroup costs more than the FCs: profiles/r03_splitk_fold_ab.tsv).
 //   * the operands do not pass through LDS: a lane's MFMA fragments ARE 16 / 32 contiguous bytes of a pixel row / weight row, loaded
@@ -255,19 +270,29 @@ struct MbBackFrag {
   h8_t xh, xl;     // 8 channels of this lane's pixel, (hi, lo)
 };
 
-template <int WM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void mbconv_back_kernel(const MbBackParams p) {
+template <int WM, int NW>
+struct MbBack {
+  static constexpr int NT = 64 * NW;           // threads
+  static constexpr int NSH = NW / WM;          // K shares (waves per pixel tile)
+  static constexpr int RP = 32 * 4 + 16;       // bytes per pixel row of a wave's partial tile
+  static constexpr int ITEMS = WM * 256;       // epilogue items (pixel, 4 channels) of the workgroup
+  static constexpr int IPT = (ITEMS + NT - 1) / NT;
+  static size_t lds(int C) { return (size_t)C * (8 * se_acc_rows(C, NT) + 8) + (size_t)NW * 32 * RP; }
+};
+
+// ABL (tools/mbb_check.hip only): 1 = no gate phases (gate = 0.5), 2 = no projection loop, 4 = no means, 8 = no squeeze FC, 16 = no excite FC
+template <int WM, int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4 ? 3 : 2))) void mbconv_back_kernel(const MbBackParams p) {
+  using T = MbBack<WM, NW>;
   constexpr int U = 3;                  // K steps per batch in flight
-  constexpr int NSH = 4 / WM;           // K shares (waves per pixel tile)
-  constexpr int RP = 32 * 4 + 16;       // bytes per pixel row of a wave's partial tile
+  constexpr int NT = T::NT, NSH = T::NSH, RP = T::RP, IPT = T::IPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char bk_smem[];
   const int C = p.se.C;
-  const int acc_rows = se_acc_rows(C);
+  const int acc_rows = se_acc_rows(C, NT);
   unsigned long long* const accs = reinterpret_cast<unsigned long long*>(bk_smem);             // [acc_rows][C]
   float* const mean = reinterpret_cast<float*>(bk_smem + (size_t)acc_rows * C * 8);            // [C]
   float* const gate = mean + C;                                                                 // [C]
-  unsigned char* const rb = reinterpret_cast<unsigned char*>(gate + C);                         // [4 waves][32 pixels][RP]
-  __shared__ float red[256];
+  unsigned char* const rb = reinterpret_cast<unsigned char*>(gate + C);                         // [NW waves][32 pixels][RP]
   __shared__ __attribute__((aligned(16))) float s1[64];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -293,35 +318,122 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void m
     }                                                                                 \
   }
   VP_MBB_LOAD(0)
-  // epilogue items of this thread: pixel 32 t + (tid >> 3) of the workgroup (t < WM), channels 4 (tid & 7) .. + 4; the residual and the
-  // bias travel under the gate phases
-  const int epx = pxw + (tid >> 3), ec = co0 + 4 * (tid & 7);
+  // epilogue items of this thread: item tid + NT t = (pixel tile it >> 8, pixel (it & 255) >> 3 of the tile, channels 4 (it & 7) .. + 4);
+  // the residual and the bias travel under the gate phases
   typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-  h4_t r_hi[WM], r_lo[WM];
+  h4_t r_hi[IPT], r_lo[IPT];
+  const int ec = co0 + 4 * (tid & 7);
 #pragma unroll
-  for (int t = 0; t < WM; ++t) {
+  for (int t = 0; t < IPT; ++t) {
+    const int it = tid + NT * t, px = pxw + 32 * (it >> 8) + ((it & 255) >> 3);
     r_hi[t] = r_lo[t] = h4_t{0, 0, 0, 0};
-    if (p.res.hi && epx + 32 * t < M) {
-      r_hi[t] = *reinterpret_cast<const h4_t*>(p.res.hi + (size_t)(epx + 32 * t) * Cout + ec);
-      r_lo[t] = *reinterpret_cast<const h4_t*>(p.res.lo + (size_t)(epx + 32 * t) * Cout + ec);
+    if (p.res.hi && it < T::ITEMS && px < M) {
+      r_hi[t] = *reinterpret_cast<const h4_t*>(p.res.hi + (size_t)px * Cout + ec);
+      r_lo[t] = *reinterpret_cast<const h4_t*>(p.res.lo + (size_t)px * Cout + ec);
     }
   }
   const f32x4_t bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + ec);
 
   // ---- gate: means, squeeze FC (shared with se_gate_scale_kernel), excite FC + sigmoid for ALL channels
-  se_means_squeeze<(WM == 4 ? 4 : 16)>(p.se, accs, mean, red, s1);  // WM = 4: C <= 160, a thread of the squeeze FC has one or two loads
-  {
+  if constexpr (ABL & 1) {
+    for (int c = tid; c < C; c += NT) gate[c] = 0.5f;
+  } else {
+    // WM = 4: C <= 160 and the register budget is 168 (three workgroups per CU).  WM = 1: one workgroup per CU, 256 registers: ALL of a
+    // thread's FC weights are requested at once.
+    if (p.zsums) {
+      // the squeeze FC arrived with the pool (mbconv_front): replica rows -> sq numbers, SiLU
+      if (tid < 64) {
+        float v = 0.0f;
+        if (tid < p.se.sq) {
+          long long t = 0;
+#pragma unroll 8
+          for (int r = 0; r < p.se.replicas; ++r) t += (long long)p.zsums[(size_t)r * 64 + tid];
+          v = silu_f((float)((double)t * (1.0 / 16777216.0)) * p.se.inv_hw + p.se.b1[tid]);
+        }
+        s1[tid] = v;
+      }
+    } else {
+    if constexpr (ABL & 4) {
+      for (int c = tid; c < C; c += NT) mean[c] = 0.25f;
+      __syncthreads();
+    } else {
+      se_means<NT>(p.se, accs, mean);
+    }
+    if constexpr (ABL & 8) {
+      if (tid < 64) s1[tid] = tid < p.se.sq ? 0.3f : 0.0f;
+    } else {
+      // squeeze FC, COALESCED: a wave owns units wave, wave + NW, ...; its lanes walk a unit's row 16 bytes apiece (1 KB per load
+      // instruction: 8 full lines -- a thread walking its own segment of a row touches 64 lines per instruction, one line a cycle:
+      // 6.6 us of a 1152-channel block, tools/mbb_check.hip), butterfly sum over the lanes (fixed order)
+      constexpr int MU = WM == 4 ? 4 : 6, MQ = WM == 4 ? 1 : 5;   // units per wave, 64-lane passes over a row, per batch
+      const int C4 = C >> 2;
+      const f32x4_t* m4 = reinterpret_cast<const f32x4_t*>(mean);
+      for (int j0 = wave; j0 < p.se.sq; j0 += NW * MU) {
+        float sj[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) sj[u] = 0.f;
+        for (int q0 = lane; q0 < C4; q0 += 64 * MQ) {
+          f32x4_t a[MU][MQ];
+#pragma unroll
+          for (int u = 0; u < MU; ++u)
+#pragma unroll
+            for (int i = 0; i < MQ; ++i)
+              if (j0 + NW * u < p.se.sq && q0 + 64 * i < C4) a[u][i] = reinterpret_cast<const f32x4_t*>(p.se.w1 + (size_t)(j0 + NW * u) * C)[q0 + 64 * i];
+#pragma unroll
+          for (int u = 0; u < MU; ++u)
+#pragma unroll
+            for (int i = 0; i < MQ; ++i)
+              if (j0 + NW * u < p.se.sq && q0 + 64 * i < C4) {
+                const f32x4_t m = m4[q0 + 64 * i];
+                sj[u] += (a[u][i][0] * m[0] + a[u][i][1] * m[1]) + (a[u][i][2] * m[2] + a[u][i][3] * m[3]);
+              }
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+          float t = sj[u];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+          if (lane == 0 && j0 + NW * u < p.se.sq) s1[j0 + NW * u] = silu_f(t + p.se.b1[j0 + NW * u]);
+        }
+      }
+      if (tid >= p.se.sq && tid < 64) s1[tid] = 0.0f;
+    }
+    }
+    __syncthreads();
     const int nq = p.sqp >> 2;
     const f32x4_t* s4 = reinterpret_cast<const f32x4_t*>(s1);
-    for (int c = tid; c < C; c += 256) {
-      const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w2q) + c;
-      float s = 0.f;
-#pragma unroll 4
-      for (int q = 0; q < nq; ++q) {
-        const f32x4_t a = wr[(size_t)q * C], m = s4[q];
-        s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+    constexpr int EQ = WM == 4 ? 4 : 12;   // weights (x 16 bytes) per channel and batch: sq <= 16 on the big maps, <= 48 anywhere in the encoder
+    constexpr int CI = WM == 4 ? 1 : 3;    // channels per thread and batch (C <= 3 x 512 in one batch)
+    for (int cb = tid; cb < C; cb += NT * CI) {
+      if constexpr (ABL & 16) {
+        gate[cb] = 0.5f * s1[cb & 7];
+        if (CI > 1) break;
+        continue;
       }
-      gate[c] = c < p.se.Creal ? sigmoid_f(s + p.b2[c]) : 0.0f;
+      float s[CI];
+#pragma unroll
+      for (int i = 0; i < CI; ++i) s[i] = 0.f;
+      for (int q0 = 0; q0 < nq; q0 += EQ) {
+        f32x4_t a[CI][EQ];
+#pragma unroll
+        for (int i = 0; i < CI; ++i)
+#pragma unroll
+          for (int q = 0; q < EQ; ++q)
+            if (q0 + q < nq && cb + NT * i < C) a[i][q] = reinterpret_cast<const f32x4_t*>(p.w2q)[(size_t)(q0 + q) * C + cb + NT * i];
+#pragma unroll
+        for (int i = 0; i < CI; ++i)
+#pragma unroll
+          for (int q = 0; q < EQ; ++q)
+            if (q0 + q < nq && cb + NT * i < C) {
+              const f32x4_t m = s4[q0 + q];
+              s[i] += (a[i][q][0] * m[0] + a[i][q][1] * m[1]) + (a[i][q][2] * m[2] + a[i][q][3] * m[3]);
+            }
+      }
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        const int c = cb + NT * i;
+        if (c < C) gate[c] = c < p.se.Creal ? sigmoid_f(s[i] + p.b2[c]) : 0.0f;
+      }
     }
   }
   __syncthreads();
@@ -331,7 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void m
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  for (int s = 0; s < nst; s += U) {
+  for (int s = 0; s < ((ABL & 2) ? 0 : nst); s += U) {
     MbBackFrag cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = nxt[u];
@@ -344,7 +456,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void m
         h8_t a_hi, a_lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = (i < 4 ? cur[u].w0[i] * g0[i] : cur[u].w1[i - 4] * g1[i - 4]);
+          float v = (i < 4 ? cur[u].w0[i] * g0[i] : cur[u].w1[i - 4] * g1[i - 4]);
+          // v must be ONE fp32 value for both planes: left to itself the backend folds the product into the hi conversion
+          // (v_fma_mixlo_f16: the exact product rounded once) but takes lo against the fp32 product, and the planes of a few elements in
+          // 2^12 disagree by one fp16 ulp (1e-4 of a layer's output, tools/mbb_check.hip).  The empty asm pins v in a register.
+          asm volatile("" : "+v"(v));
           a_hi[i] = (half_t)v;
           a_lo[i] = (half_t)(v - (float)a_hi[i]);
         }
@@ -368,10 +484,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void m
   }
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < WM; ++t) {
-    const int px = epx + 32 * t;
-    if (px >= M) continue;
-    const unsigned char* src = rb + t * 32 * RP + (tid >> 3) * RP + 16 * (tid & 7);   // wave t = share 0 of tile t
+  for (int t = 0; t < IPT; ++t) {
+    const int it = tid + NT * t, tile = it >> 8, px = pxw + 32 * tile + ((it & 255) >> 3);
+    if (it >= T::ITEMS || px >= M) continue;
+    const unsigned char* src = rb + tile * 32 * RP + ((it & 255) >> 3) * RP + 16 * (it & 7);   // wave `tile` = share 0 of that tile
     f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
 #pragma unroll
     for (int j = 1; j < NSH; ++j) {
@@ -400,17 +516,18 @@ bool mbconv_back_supported(const MbBackParams& p) {
          (!p.res.hi || (p.res.lo && p.res.C == p.out.C && p.res.H == p.out.H && p.res.W == p.out.W));
 }
 
+template <int WM, int NW, int ABL = 0>
+static hipError_t launch_mbb(const MbBackParams& p, hipStream_t st) {
+  using T = MbBack<WM, NW>;
+  const int M = p.in.H * p.in.W;
+  hipLaunchKernelGGL((mbconv_back_kernel<WM, NW, ABL>), dim3((M + 32 * WM - 1) / (32 * WM), p.out.C / 32), dim3(T::NT), T::lds(p.se.C), st, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_mbconv_back(const MbBackParams& p, hipStream_t st) {
   if (!mbconv_back_supported(p)) return hipErrorInvalidValue;
-  const int C = p.se.C;
-  const size_t lds = (size_t)C * (8 * se_acc_rows(C) + 8) + 4 * 32 * (32 * 4 + 16);
-  const int M = p.in.H * p.in.W;
-  if (M >= 12800) {  // 80x160 and 160x320: K is 2 ... 10 steps, a wave per pixel tile
-    hipLaunchKernelGGL(mbconv_back_kernel<4>, dim3((M + 127) / 128, p.out.C / 32), dim3(256), lds, st, p);
-  } else {
-    hipLaunchKernelGGL(mbconv_back_kernel<1>, dim3((M + 31) / 32, p.out.C / 32), dim3(256), lds, st, p);
-  }
-  return hipGetLastError();
+  // 80x160 and 160x320 (K = 2 ... 10 steps): a wave per pixel tile, four waves; the smaller maps: eight waves, an eighth of K each
+  return p.in.H * p.in.W >= 12800 ? launch_mbb<4, 4>(p, st) : launch_mbb<1, 8>(p, st);
 }
 
 }  // namespace vp

@@ -1,17 +1,17 @@
 // Squeeze-excite, phases 1 and 2, shared by se_gate_scale_kernel (kernels_backbone.hip) and mbconv_back_kernel (kernels_mbconv.hip): a
-// workgroup of 256 threads rebuilds the channel means from the replica rows of the fused pool and ALL squeeze units itself
+// workgroup of NT (256 or 512) threads rebuilds the channel means from the replica rows of the fused pool and ALL squeeze units itself
 // (torchvision SqueezeExcitation: avgpool -> fc1 -> SiLU; Models/model_components/backbone.py:9-22).
 #pragma once
 #include "kernels.hpp"
 
 namespace vp {
 
-// acc: [acc_rows][C] u64 (acc_rows = se_acc_rows(C)), mean: [C] floats (16-byte aligned), red: [256] floats, s1: [64] floats.
+// acc: [acc_rows][C] u64 (acc_rows = se_acc_rows(C, NT)), mean: [C] floats (16-byte aligned), red: [NT] floats, s1: [64] floats.
 // On return (after the trailing barrier) mean[] and s1[0 .. sq) are valid for every thread; s1[sq .. 64) is zero.
-__host__ __device__ static inline int se_acc_rows(int C) { return (C >> 1) >= 256 ? 1 : 256 / (C >> 1); }
+__host__ __device__ static inline int se_acc_rows(int C, int NT = 256) { return (C >> 1) >= NT ? 1 : NT / (C >> 1); }
 
-template <int NB = 16>  // 16-byte loads of the squeeze FC in flight per thread
-__device__ __forceinline__ void se_means_squeeze(const SeParams& se, unsigned long long* acc, float* mean, float* red, float* s1) {
+template <int NT = 256>
+__device__ __forceinline__ void se_means(const SeParams& se, unsigned long long* acc, float* mean) {
   const int tid = threadIdx.x, C = se.C;
   // ---- 1: means.  Thread = (channel pair, slice of the replica rows): every load of a thread is independent (one or two round
   // trips), the slices of a pair meet in LDS; integer sums, so any grouping gives the same bits.  (LDS atomics per loaded pair
@@ -19,10 +19,10 @@ __device__ __forceinline__ void se_means_squeeze(const SeParams& se, unsigned lo
   {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const int CP = C >> 1;                                  // 16-byte pairs per row
-    const int TPC = CP >= 256 ? 1 : 256 / CP;               // threads per pair
+    const int TPC = CP >= NT ? 1 : NT / CP;               // threads per pair
     const int rows_per = (se.replicas + TPC - 1) / TPC;
     const u64x2* src = reinterpret_cast<const u64x2*>(se.sums);
-    for (int cp = tid % (TPC == 1 ? 256 : CP); cp < CP; cp += 256) {
+    for (int cp = tid % (TPC == 1 ? NT : CP); cp < CP; cp += NT) {
       const int g = TPC == 1 ? 0 : tid / CP;
       if (g >= TPC) break;
       const int r_begin = g * rows_per, r_end = min(se.replicas, r_begin + rows_per);
@@ -45,16 +45,22 @@ __device__ __forceinline__ void se_means_squeeze(const SeParams& se, unsigned lo
       if (TPC > 1) break;  // one pair per thread in the sliced form
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
       unsigned long long t = acc[c];
       for (int g = 1; g < TPC; ++g) t += acc[(size_t)g * C + c];
       mean[c] = (float)((double)(long long)t * (1.0 / 16777216.0)) * se.inv_hw;
     }
   }
   __syncthreads();
+}
+
+template <int NB = 16, int NT = 256>  // NB: 16-byte loads of the squeeze FC in flight per thread; NT: threads of the workgroup
+__device__ __forceinline__ void se_means_squeeze(const SeParams& se, unsigned long long* acc, float* mean, float* red, float* s1) {
+  const int tid = threadIdx.x, C = se.C;
+  se_means<NT>(se, acc, mean);
   // ---- 2: squeeze FC
   {
-    const int nseg = 256 / se.sq;                      // >= 4 (sq <= 64)
+    const int nseg = NT / se.sq;                       // >= 4 (sq <= 64)
     const int j = tid / nseg, sg = tid - j * nseg;
     const int C4 = C >> 2, per = (C4 + nseg - 1) / nseg;
     float s = 0.f;

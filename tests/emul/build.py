@@ -2,7 +2,7 @@
 HOST on top of the HIP-on-CPU shim (shim/hip/hip_runtime.h), so the CPU suite can execute the real kernel and engine code
 against the oracle.  Source rewrites (listed here, nothing else differs from what hipcc compiles):
   * `extern __shared__`  ->  `extern VP_EMU_LDS`           (dynamic LDS is per-worker storage in harness.cpp)
-  * the two inline-asm statements (an AGPR read, an ablation-only register pin) -> their plain C++ equivalents;
+  * the inline-asm statements (an AGPR read, two register pins) -> their plain C++ equivalents;
   * the register-budget attribute of one kernel (`amdgpu_waves_per_eu`) is dropped.
 Linked with -Bsymbolic and meant to be dlopen-ed RTLD_LOCAL: it exports the same symbols as libvp_hip.so and must neither
 capture nor be captured by that library when both live in one test process."""
@@ -23,7 +23,8 @@ REWRITES = (
     ("extern __shared__", "extern VP_EMU_LDS"),
     ('asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][4 * g + r]));', "v = acc[i][j][4 * g + r];"),
     ('asm volatile("" ::"v"(a_[i]), "v"(b_[j]));', "(void)0;"),
-    ("__attribute__((amdgpu_waves_per_eu(3))) ", ""),
+    ("__attribute__((amdgpu_waves_per_eu(WM == 4 ? 3 : 2))) ", ""),
+    ('asm volatile("" : "+v"(v));', "(void)0;"),
 )
 
 

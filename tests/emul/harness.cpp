@@ -91,8 +91,10 @@ int emu_dwconv_batched(void* in_hi, void* in_lo, int H, int W, int C, void* out_
   return launch_dwconv(p, nullptr);
 }
 int emu_mbconv_front(void* in_hi, void* in_lo, int H, int W, int Cin, const void* w_hi, const void* w_lo, const float* b_exp, const float* w_dw,
-                     const float* b_dw, void* out_hi, void* out_lo, int Cexp, int k, int stride, unsigned long long* sums, int replicas) {
+                     const float* b_dw, void* out_hi, void* out_lo, int Cexp, int k, int stride, unsigned long long* sums, int replicas, const float* w1, int sq,
+                     unsigned long long* zsums) {
   MbFrontParams p{};
+  p.w1 = w1; p.sq = sq; p.zsums = zsums;
   p.in = view(in_hi, in_lo, H, W, Cin);
   p.w_hi = static_cast<const half_t*>(w_hi); p.w_lo = static_cast<const half_t*>(w_lo); p.b_exp = b_exp; p.w_dw = w_dw; p.b_dw = b_dw;
   p.out = view(out_hi, out_lo, H / stride, W / stride, Cexp);
@@ -101,8 +103,9 @@ int emu_mbconv_front(void* in_hi, void* in_lo, int H, int W, int Cin, const void
 }
 int emu_mbconv_back(void* in_hi, void* in_lo, int H, int W, int C, int Creal, const unsigned long long* sums, int replicas, int sq, const float* w1,
                     const float* b1, const float* w2q, const float* b2, int sqp, const float* w, const float* bias, void* res_hi, void* res_lo,
-                    void* out_hi, void* out_lo, int Cout) {
+                    void* out_hi, void* out_lo, int Cout, const unsigned long long* zsums) {
   MbBackParams p{};
+  p.zsums = zsums;
   p.in = view(in_hi, in_lo, H, W, C);
   p.se.sums = sums; p.se.replicas = replicas; p.se.C = C; p.se.Creal = Creal; p.se.sq = sq; p.se.inv_hw = 1.0f / (float)(H * W); p.se.w1 = w1; p.se.b1 = b1;
   p.se.frames = 1;

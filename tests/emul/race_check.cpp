@@ -21,9 +21,10 @@ extern "C" {
 int emu_stem(const float*, int, int, const float*, const float*, void*, void*);
 int emu_dwconv(void*, void*, int, int, int, void*, void*, int, int, const float*, const float*, int, int, unsigned long long*, int);
 int emu_se_gate_scale(const unsigned long long*, int, int, int, int, float, const float*, const float*, const float*, void*, void*, int, const float*, const float*, int);
-int emu_mbconv_front(void*, void*, int, int, int, const void*, const void*, const float*, const float*, const float*, void*, void*, int, int, int, unsigned long long*, int);
+int emu_mbconv_front(void*, void*, int, int, int, const void*, const void*, const float*, const float*, const float*, void*, void*, int, int, int, unsigned long long*, int, const float*, int,
+                     unsigned long long*);
 int emu_mbconv_back(void*, void*, int, int, int, int, const unsigned long long*, int, int, const float*, const float*, const float*, const float*, int, const float*, const float*,
-                    void*, void*, void*, void*, int);
+                    void*, void*, void*, void*, int, const unsigned long long*);
 int emu_fc(const float*, const float*, const float*, float*, int, int, int);
 int emu_pool_partial(void*, void*, int, int, int, float*, int);
 int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
@@ -147,8 +148,10 @@ int main(int argc, char** argv) {
       const int k = cfg ? 5 : 3, stride = cfg ? 2 : 1, cin = 64, cexp = 96, h = 10, ww = 18, oh = h / stride, ow = ww / stride;
       std::vector<half_t> ih = rnd16((size_t)h * ww * cin), il = rnd16(ih.size()), wh = rnd16((size_t)cexp * cin), wl = rnd16(wh.size()), oh_((size_t)oh * ow * cexp), ol_(oh_.size());
       std::vector<float> be = rnd(cexp, 0.1f), wk = rnd((size_t)k * k * cexp, 0.3f), bb = rnd(cexp, 0.1f);
-      std::vector<unsigned long long> sums(4 * cexp, 0ull);
-      bad |= emu_mbconv_front(ih.data(), il.data(), h, ww, cin, wh.data(), wl.data(), be.data(), wk.data(), bb.data(), oh_.data(), ol_.data(), cexp, k, stride, sums.data(), 4);
+      std::vector<unsigned long long> sums(4 * cexp, 0ull), zs(4 * 64, 0ull);
+      std::vector<float> w1 = rnd((size_t)6 * cexp, 0.2f);
+      bad |= emu_mbconv_front(ih.data(), il.data(), h, ww, cin, wh.data(), wl.data(), be.data(), wk.data(), bb.data(), oh_.data(), ol_.data(), cexp, k, stride, sums.data(), 4, w1.data(), 6,
+                              zs.data());
     }
     // fused MBConv back: the gate phases' LDS hand-offs, the waves' partial tiles meeting in LDS (a wave per K quarter / per pixel tile)
     for (int cfg = 0; cfg < (quick ? 1 : 2); ++cfg) {
@@ -157,7 +160,7 @@ int main(int argc, char** argv) {
       std::vector<unsigned long long> sums(8 * C, 1ull << 20);
       std::vector<float> w1 = rnd(sq * C, 0.2f), b1 = rnd(sq, 0.1f), w2q = rnd((size_t)sqp * C, 0.5f), b2 = rnd(C, 0.1f), pw = rnd((size_t)cout * C), pb = rnd(cout);
       bad |= emu_mbconv_back(ih.data(), il.data(), h, ww, C, C, sums.data(), 8, sq, w1.data(), b1.data(), w2q.data(), b2.data(), sqp, pw.data(), pb.data(), rh.data(), rl.data(),
-                             oh_.data(), ol_.data(), cout);
+                             oh_.data(), ol_.data(), cout, cfg ? sums.data() : nullptr);
     }
     std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
     bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);

@@ -201,6 +201,11 @@ def test_depthwise_pool_kernel(emu, C, k, stride, H, W):
     assert _rel(got, want) <= 2e-6
     pooled = sums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
     assert np.abs(pooled - got.astype(np.float64).sum(axis=(1, 2))).max() <= 1e-4
+    # the squeeze FC taken from the workgroups' own sums (linear in them): sq numbers, the rest of the 64-wide rows untouched
+    z = zsums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
+    want_z = w1.astype(np.float64) @ pooled
+    assert np.abs(z[:sq] - want_z).max() <= 3e-6 * max(1.0, np.abs(want_z).max())
+    assert not z[sq:].any()
     # fp16 engine: single plane, SiLU variant rounded to fp16
     o16 = np.zeros((OH, OW, C), np.float16)
     sums2 = np.zeros((replicas, C), dtype=np.uint64)
@@ -240,13 +245,23 @@ def test_mbconv_front_kernel(emu, cin, cexp, k, stride, H, W):
     oh, ol = np.full((OH, OW, cexpp), 7, np.float16), np.full((OH, OW, cexpp), 7, np.float16)
     replicas = 4
     sums = np.zeros((replicas, cexpp), dtype=np.uint64)
+    sq = max(1, cin // 4)
+    w1 = np.zeros((sq, cexpp), np.float32)
+    w1[:, :cexp] = rng.standard_normal((sq, cexp)).astype(np.float32) * 0.2
+    zsums = np.zeros((replicas, 64), dtype=np.uint64)
+    emu.emu_mbconv_front.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int] + [ct.c_void_p] * 7 + [ct.c_int] * 3 + [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]
     assert emu.emu_mbconv_front(ptr(xh), ptr(xl), H, W, cinp, ptr(wh), ptr(wlo), ptr(bep), ptr(wk), ptr(bdp), ptr(oh), ptr(ol), cexpp, k, stride,
-                                ptr(sums), replicas) == 0
+                                ptr(sums), replicas, ptr(w1), sq, ptr(zsums)) == 0
     got = (oh.astype(np.float32) + ol.astype(np.float32)).transpose(2, 0, 1)
     assert _rel(got[:cexp], want) <= 3e-6
     assert not got[cexp:].any()                                   # pad channels stay exactly zero
     pooled = sums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
     assert np.abs(pooled - got.astype(np.float64).sum(axis=(1, 2))).max() <= 1e-4
+    # the squeeze FC taken from the workgroups' own sums (linear in them): sq numbers, the rest of the 64-wide rows untouched
+    z = zsums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
+    want_z = w1.astype(np.float64) @ pooled
+    assert np.abs(z[:sq] - want_z).max() <= 3e-6 * max(1.0, np.abs(want_z).max())
+    assert not z[sq:].any()
 
 
 @pytest.mark.parametrize("cexp,cout,sq,H,W,residual", [(1152, 192, 48, 10, 20, True), (144, 40, 6, 9, 13, False), (240, 40, 10, 40, 80, True),
@@ -287,9 +302,9 @@ def test_mbconv_back_kernel(emu, cexp, cout, sq, H, W, residual):
     rh, rl = split16(res)
     oh, ol = np.full((M, Cout), 7, np.float16), np.full((M, Cout), 7, np.float16)
     emu.emu_mbconv_back.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int] + [ct.c_void_p] * 4 + \
-        [ct.c_int] + [ct.c_void_p] * 6 + [ct.c_int]
+        [ct.c_int] + [ct.c_void_p] * 6 + [ct.c_int, ct.c_void_p]
     assert emu.emu_mbconv_back(ptr(xh), ptr(xl), H, W, C, cexp, ptr(sums.view(np.uint64)), replicas, sq, ptr(w1), ptr(b1), ptr(w2q), ptr(b2), sqp, ptr(w),
-                               ptr(bias), ptr(rh) if residual else None, ptr(rl) if residual else None, ptr(oh), ptr(ol), Cout) == 0
+                               ptr(bias), ptr(rh) if residual else None, ptr(rl) if residual else None, ptr(oh), ptr(ol), Cout, None) == 0
     mean = fixed.sum(axis=0).astype(np.float64) / 2.0 ** 24 / M
     z = w1.astype(np.float64) @ mean + b1
     s1 = z / (1.0 + np.exp(-z))
@@ -301,6 +316,16 @@ def test_mbconv_back_kernel(emu, cexp, cout, sq, H, W, residual):
     got = oh.astype(np.float64) + ol.astype(np.float64)
     assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
     assert not got[:, cout:].any()
+    # the squeeze sums handed over by the front half (mbconv_front's zsums) instead of means + FC here: same result to rounding
+    zs = np.zeros((replicas, 64), dtype=np.int64)
+    zpart = (w1.astype(np.float64) @ (fixed.sum(axis=0).astype(np.float64) / 2.0 ** 24))
+    for r in range(replicas):
+        zs[r, :sq] = np.rint(zpart / replicas * 2.0 ** 24).astype(np.int64)
+    oh2, ol2 = np.full((M, Cout), 7, np.float16), np.full((M, Cout), 7, np.float16)
+    assert emu.emu_mbconv_back(ptr(xh), ptr(xl), H, W, C, cexp, ptr(sums.view(np.uint64)), replicas, sq, ptr(w1), ptr(b1), ptr(w2q), ptr(b2), sqp, ptr(w),
+                               ptr(bias), ptr(rh) if residual else None, ptr(rl) if residual else None, ptr(oh2), ptr(ol2), Cout, ptr(zs.view(np.uint64))) == 0
+    got2 = oh2.astype(np.float64) + ol2.astype(np.float64)
+    assert np.abs(got2 - want).max() <= 3e-6 * np.abs(want).max()
 
 
 def test_squeeze_excite_kernel(emu):
