@@ -292,7 +292,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
   unsigned long long* se_arena = static_cast<unsigned long long*>(dalloc(se_words * sizeof(unsigned long long)));
   int se_block = 0;
   size_t se_used = 0;
-  {
+  // the accumulators are zeroed once per frame: by the stem kernel when it is ONE launch (one frame per pass), else by a launch of its own
+  const bool zero_in_stem = N == 1 && se_words % 2 == 0;
+  if (!zero_in_stem) {
     Op op;
     op.name = "se_pool_zero";
     op.kernel = "zero_u64";
@@ -312,6 +314,10 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
     sp.W = net_w();
     sp.w = dupload(wk);
     sp.b = dupload(f.b);
+    if (zero_in_stem) {
+      sp.zero = se_arena;
+      sp.zero_n = se_words;
+    }
     x = new_act(P + "0", 32, N * (net_h() / 2), net_w() / 2);
     x->frames = N;
     for (int fi = 0; fi < N; ++fi) {

@@ -41,6 +41,8 @@ struct StemParams {
   const float* w;   // [27][32]  (k = (ci*3+ky)*3+kx, co fastest), BN scale folded
   const float* b;   // [32]
   ActView out;      // C = 32
+  unsigned long long* zero;  // optional: the squeeze-excite accumulators of the frame, zeroed here (every block's pool comes later)
+  size_t zero_n;
 };
 
 struct DwParams {

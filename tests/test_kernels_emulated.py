@@ -201,11 +201,6 @@ def test_depthwise_pool_kernel(emu, C, k, stride, H, W):
     assert _rel(got, want) <= 2e-6
     pooled = sums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
     assert np.abs(pooled - got.astype(np.float64).sum(axis=(1, 2))).max() <= 1e-4
-    # the squeeze FC taken from the workgroups' own sums (linear in them): sq numbers, the rest of the 64-wide rows untouched
-    z = zsums.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
-    want_z = w1.astype(np.float64) @ pooled
-    assert np.abs(z[:sq] - want_z).max() <= 3e-6 * max(1.0, np.abs(want_z).max())
-    assert not z[sq:].any()
     # fp16 engine: single plane, SiLU variant rounded to fp16
     o16 = np.zeros((OH, OW, C), np.float16)
     sums2 = np.zeros((replicas, C), dtype=np.uint64)

@@ -33,6 +33,52 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const h8* src, float* out, l
   }
 }
 
+// The same loop with R 16-byte LDS reads (ds_read_b128, conflict-free, random data: the operands of the MFMAs) per 4 MFMAs -- what a
+// register tile costs in LDS traffic: the parity 3x3 kernel reads 8 fragments per 12 MFMAs (R = 2.7); a 2x larger register tile would
+// read 1.3.  If the pipe is POWER-limited, LDS energy comes out of the MFMA budget and the rate falls with R.
+template <int R>
+__global__ __launch_bounds__(512, 2) void mfma_lds_loop(const h8* src, float* out, long long* clk, int iters) {
+  __shared__ h8 lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = src[i & 1023];
+  __syncthreads();
+  h8 a = src[threadIdx.x], b = src[512 + threadIdx.x], a2 = b, b2 = a;
+  f16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  const long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    if (R >= 1) a = lds[(i * 67 + threadIdx.x) & 4095];
+    if (R >= 2) b = lds[(i * 131 + 1024 + threadIdx.x) & 4095];
+    if (R >= 3) a2 = lds[(i * 197 + 2048 + threadIdx.x) & 4095];
+    if (R >= 4) b2 = lds[(i * 263 + 3072 + threadIdx.x) & 4095];
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2, a2, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2, a, c3, 0, 0, 0);
+  }
+  const long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  float s = 0;
+  for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
+}
+
+template <int R>
+static void lds_row(const h8* src, float* out, long long* clk, hipEvent_t e0, hipEvent_t e1, int n) {
+  const int iters = 40000;
+  hipLaunchKernelGGL(mfma_lds_loop<R>, dim3(n), dim3(512), 0, 0, src, out, clk, 4000);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma_lds_loop<R>, dim3(n), dim3(512), 0, 0, src, out, clk, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)n * 8 * iters * 4 * 32 * 32 * 16 * 2;
+  std::printf("%d\t%d\t%.2f\t%.3f\t%.1f\t%.2f\t%.0f\n", n, R, R / 4.0, ms, flop / ms * 1e-9, flop / ms * 1e-9 / n, (double)clk[0] / clk[1] * 100.0);
+}
+
 int main() {
   float* out;
   long long* clk;
@@ -64,6 +110,22 @@ int main() {
       hipEventElapsedTime(&ms, e0, e1);
       const double flop = (double)n * 8 * iters * 4 * 32 * 32 * 16 * 2;
       std::printf("%d\t%.3f\t%.1f\t%.2f\t%.0f\n", n, ms, flop / ms * 1e-9, flop / ms * 1e-9 / n, (double)clk[0] / clk[1] * 100.0);
+    }
+  }
+  {
+    unsigned s = 12345;
+    for (auto& v : h) {
+      s = s * 1664525u + 1013904223u;
+      v = (_Float16)(((int)(s >> 9) % 2001 - 1000) * 0.001f);
+    }
+    hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    std::printf("# random fp16 operands read from LDS: R ds_read_b128 per 4 MFMAs\n# active_CUs\tR\treads_per_MFMA\tms\tTFLOP/s\tTFLOP/s_per_CU\tshader_clock_MHz\n");
+    for (int n : {64, 256}) {
+      lds_row<0>(src, out, clk, e0, e1, n);
+      lds_row<1>(src, out, clk, e0, e1, n);
+      lds_row<2>(src, out, clk, e0, e1, n);
+      lds_row<3>(src, out, clk, e0, e1, n);
+      lds_row<4>(src, out, clk, e0, e1, n);
     }
   }
   return 0;
