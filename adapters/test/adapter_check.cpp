@@ -3,10 +3,12 @@
 //   adapter_check <kind> <blob> <out>  -> one synthetic 720p BGR frame through HipBackend (kind = segmentation|depth|
 //                                         domain) or EgoLanesHipEngine (kind = egolanes); writes logits + mask to <out>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <string>
 
+#include "autospeed_hip_stages.hpp"
 #include "egolanes_hip_engine.hpp"
 #include "hip_backend.hpp"
 #define VP_HIP_DEFINE_MASK_KERNELS 1
@@ -60,7 +62,34 @@ int main(int argc, char ** argv)
     for (int x = 0; x < 1280 * 3; ++x) frame.data[(size_t)y * frame.step + x] = (uint8_t)((x * 7 + y * 13 + (x ^ y)) & 255);
   std::ofstream f(out, std::ios::binary);
   f.write(reinterpret_cast<const char *>(frame.data), (std::streamsize)frame.step * 720);
-  if (kind == "egolanes") {
+  if (kind == "autospeed") {
+    // the AutoSpeed engine's two CPU stages (blob = a raw fp32 detector output [attrs][boxes] written by the test): letterbox tensor,
+    // then the kept detections, appended to <out> after the frame
+    using autoware_pov::vision::autospeed::AutoSpeedHipStages;
+    using autoware_pov::vision::autospeed::Detection;
+    if (argc < 6) return fail("autospeed: adapter_check autospeed RAW.bin OUT ATTRS BOXES");
+    const int attrs = std::atoi(argv[4]), boxes = std::atoi(argv[5]);
+    std::ifstream rf(blob, std::ios::binary);
+    std::vector<float> raw((size_t)attrs * boxes);
+    rf.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)(raw.size() * sizeof(float)));
+    if (!rf) return fail("autospeed: raw tensor file too short");
+    AutoSpeedHipStages st(640, 640, boxes, attrs);
+    std::vector<float> input((size_t)3 * 640 * 640);
+    st.preprocessAutoSpeed(frame, input.data());
+    if (st.inputDevice() == nullptr) return fail("autospeed: device tensor");
+    f.write(reinterpret_cast<const char *>(input.data()), (std::streamsize)(input.size() * sizeof(float)));
+    const std::vector<Detection> det = st.postProcess(raw.data(), attrs, boxes, 0.25f, 0.45f);
+    const int n = (int)det.size();
+    f.write(reinterpret_cast<const char *>(&n), sizeof n);
+    f.write(reinterpret_cast<const char *>(det.data()), (std::streamsize)(det.size() * sizeof(Detection)));
+    if (!st.postProcess(raw.data(), 3, boxes, 0.25f, 0.45f).empty()) return fail("autospeed: a tensor without class rows must give {}");
+    cv::Mat bad(10, 10, CV_8UC1);
+    try {
+      st.preprocessAutoSpeed(bad, input.data());
+      return fail("autospeed: a non-BGR8 image must throw");
+    } catch (const std::runtime_error &) {
+    }
+  } else if (kind == "egolanes") {
     EgoLanesHipEngine e(blob, "hip", "fp32");
     try {
       e.getRawTensorData();

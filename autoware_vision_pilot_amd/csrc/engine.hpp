@@ -43,6 +43,8 @@ std::vector<char> onnx_to_blob(const std::string& path);
 
 // Pillow's resample coefficient tables (engine.cpp): bounds [out][2], coefficients [out][ksize] with 22 fractional bits; returns ksize
 int pil_coeffs(int in_size, int out_size, int filter, std::vector<int>* bounds, std::vector<int>* kk);
+// 11-bit fixed-point bilinear taps of the cv::resize INTER_LINEAR restatement ([dst][4] = i0, i1, w0, w1; engine_io.cpp, oracle/pre_post.py linear_taps_u8)
+void linear_taps_u8(int src, int dst, std::vector<int>* tab);
 
 // a value left the representable range (vp_status VP_ERR_RANGE): a weight beyond fp16 at load, inf / NaN in a network's output
 struct RangeError : std::runtime_error {

@@ -18,7 +18,7 @@ void Engine::set_decode_mode(int mode) {
 }
 
 // 11-bit fixed-point bilinear taps -- must stay bit-identical to oracle/pre_post.py linear_taps_u8.
-static void linear_taps_u8(int src, int dst, std::vector<int>* tab) {
+void linear_taps_u8(int src, int dst, std::vector<int>* tab) {
   tab->resize((size_t)dst * 4);
   const double scale = (double)src / (double)dst;
   for (int d = 0; d < dst; ++d) {

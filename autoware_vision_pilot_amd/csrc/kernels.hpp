@@ -119,6 +119,36 @@ struct MbBackParams {
   ActView out;         // H x W x Cout_pad (hi, lo)
 };
 
+// AutoSpeed detector pre / post-processing (kernels_detect.hip; autospeed/onnxruntime_engine.cpp:71-113, :170-290).
+struct LetterboxParams {
+  const uint8_t* frame;  // device, h x w x 3 BGR
+  int stride;            // bytes per row
+  const int* xtab;       // [new_w][4] bilinear taps of the resize to new_w x new_h (as PreprocessParams)
+  const int* ytab;       // [new_h][4]
+  int new_w, new_h, pad_x, pad_y;
+  int out_h, out_w;
+  float* out;            // [3][out_h][out_w] planes R, G, B in [0, 1]; 114 / 255 outside the pasted image
+};
+
+struct Detection {       // == autoware_pov::vision::autospeed::Detection (detection.hpp:8-12) == vp_detection
+  float x1, y1, x2, y2, confidence;
+  int class_id;
+};
+
+struct DetectParams {
+  const float* raw;      // [num_attrs][num_boxes]: cx, cy, w, h (letterbox pixels), then the class scores
+  int num_attrs, num_boxes;
+  float conf_thresh, iou_thresh;
+  float scale;           // letterbox geometry of the frame the tensor came from
+  int pad_x, pad_y, orig_w, orig_h;
+  float* boxes;          // scratch [num_boxes][4]: candidate boxes in sorted order
+  int* cls;              // scratch [num_boxes]
+  Detection* out;        // [out_cap]
+  int out_cap;
+  int* count;            // [2]: detections kept (may exceed out_cap: only out_cap are written), candidates above the threshold
+};
+constexpr int kDetectMaxBoxes = 16384;
+
 struct FcParams {
   const float* x;
   const float* w;  // [N][K]
@@ -186,6 +216,8 @@ hipError_t launch_stem(const StemParams& p, hipStream_t st);
 hipError_t launch_dwconv(const DwParams& p, hipStream_t st);
 bool mbconv_front_supported(const MbFrontParams& p);
 hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st);
+hipError_t launch_letterbox(const LetterboxParams& p, hipStream_t st);
+hipError_t launch_detect_decode_nms(const DetectParams& p, hipStream_t st);
 bool mbconv_back_supported(const MbBackParams& p);
 hipError_t launch_mbconv_back(const MbBackParams& p, hipStream_t st);
 hipError_t launch_pool_partial(const PoolParams& p, hipStream_t st);

@@ -87,6 +87,14 @@ _SIGS = {
     "vp_tensor_read": (C.c_int, [_P, C.c_int, _P]),
     "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
+    "vp_detect_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "vp_detect_destroy": (None, [_P]),
+    "vp_detect_last_error": (C.c_char_p, [_P]),
+    "vp_detect_preprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "vp_detect_input_device": (C.c_int, [_P, C.POINTER(_P)]),
+    "vp_detect_letterbox": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_detect_set_letterbox": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vp_detect_postprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, C.c_int, C.POINTER(C.c_int)]),
     "vp_version": (C.c_char_p, []),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
@@ -528,3 +536,60 @@ def resample_coeffs(in_size, out_size, mode):
     if ks <= 0:
         raise VpError(f"vp_resample_coeffs failed ({ks})")
     return b, k[: out_size * ks].reshape(out_size, ks)
+
+
+class Detector:
+    """AutoSpeed detector pre / post-processing on the device (vp_detect_*): the Python twin of AutoSpeedOnnxEngine's preprocessAutoSpeed and
+    postProcess (VisionPilot/middleware_recipes/common/backends/autospeed/onnxruntime_engine.cpp:71-113, :170-290).  The detector network
+    itself is the caller's: `preprocess(frame)` -> its input tensor, `postprocess(raw, conf, iou)` -> the kept detections."""
+
+    def __init__(self, net_h=640, net_w=640, max_boxes=8400, max_attrs=84, gpu_id=0):
+        self._lib = load()
+        self._h = _P()
+        self.net_h, self.net_w = net_h, net_w
+        err = C.create_string_buffer(512)
+        rc = self._lib.vp_detect_create(C.byref(self._h), gpu_id, net_h, net_w, max_boxes, max_attrs, err, len(err))
+        if rc != 0:
+            self._h = None
+            raise VpError(f"vp_detect_create failed ({rc}): {err.value.decode(errors='replace')}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vp_detect_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise VpError(f"{what} failed ({rc}): {self._lib.vp_detect_last_error(self._h).decode(errors='replace')}")
+
+    def preprocess(self, frame_bgr_u8):
+        """HxWx3 BGR uint8 -> ([3][net_h][net_w] float32 planes R, G, B in [0, 1], (scale, pad_x, pad_y))."""
+        f = frame_bgr_u8
+        if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3 or f.strides[2] != 1 or f.strides[1] != 3:
+            f = np.ascontiguousarray(f, dtype=np.uint8)
+        out = np.empty((3, self.net_h, self.net_w), np.float32)
+        self._check(self._lib.vp_detect_preprocess(self._h, _ptr(f), f.shape[0], f.shape[1], f.strides[0], _ptr(out)), "vp_detect_preprocess")
+        return out, self.letterbox()
+
+    def letterbox(self):
+        s, px, py = C.c_float(), C.c_int(), C.c_int()
+        self._check(self._lib.vp_detect_letterbox(self._h, C.byref(s), C.byref(px), C.byref(py)), "vp_detect_letterbox")
+        return np.float32(s.value), px.value, py.value
+
+    def set_letterbox(self, scale, pad_x, pad_y, orig_w, orig_h):
+        self._check(self._lib.vp_detect_set_letterbox(self._h, float(scale), pad_x, pad_y, orig_w, orig_h), "vp_detect_set_letterbox")
+
+    def postprocess(self, raw, conf_thresh, iou_thresh, cap=None):
+        """raw [num_attrs][num_boxes] float32 -> ([n][6] float32 rows x1, y1, x2, y2, confidence, class_id; total kept)."""
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        cap = raw.shape[1] if cap is None else cap
+        out = np.zeros((max(cap, 1), 6), np.float32)
+        n = C.c_int()
+        self._check(self._lib.vp_detect_postprocess(self._h, _ptr(raw), 0, raw.shape[0], raw.shape[1], float(conf_thresh), float(iou_thresh), _ptr(out), cap,
+                                                    C.byref(n)), "vp_detect_postprocess")
+        k = min(n.value, cap)
+        det = out[:k].copy()
+        det[:, 5] = out[:k, 5].view(np.int32).astype(np.float32)   # class_id is an int in the struct
+        return det, n.value

@@ -256,6 +256,36 @@ int vp_tensor_count(const vp_engine* e);
 int vp_tensor_info(const vp_engine* e, int i, const char** name, int* c, int* h, int* w);
 int vp_tensor_read(vp_engine* e, int i, float* dst_chw);                       /* fp32 CHW copy of an activation */
 
+/* ---- AutoSpeed detector: letterbox preprocess and decode + NMS on the device ------------------------------------
+ * Replaces AutoSpeedOnnxEngine::preprocessAutoSpeed (VisionPilot/middleware_recipes/common/backends/autospeed/
+ * onnxruntime_engine.cpp:71-113) and ::postProcess / ::computeIoU / ::applyNMS (:170-290); the TensorRT engine (tensorrt_engine.cpp)
+ * holds the same two stages.  The detector network is NOT part of this library: the host runs it between the two calls and hands its
+ * output tensor [num_attrs][num_boxes] (cx, cy, w, h in letterbox pixels, then the class scores) to vp_detect_postprocess.
+ * vp_detection is the reference's `Detection` (autospeed/detection.hpp:8-12), field for field. */
+typedef struct vp_detect vp_detect;
+typedef struct vp_detection {
+  float x1, y1, x2, y2; /* image coordinates, clamped to the frame */
+  float confidence;
+  int class_id;         /* -1: no class score was positive (the reference's argmax starts from 0) */
+} vp_detection;
+/* net_h x net_w: the detector's input (640 x 640); max_boxes <= 16384 and max_attrs >= 5 bound the output tensors accepted later */
+int vp_detect_create(vp_detect** out, int gpu_id, int net_h, int net_w, int max_boxes, int max_attrs, char* err, size_t err_len);
+void vp_detect_destroy(vp_detect* d);
+const char* vp_detect_last_error(const vp_detect* d);
+/* BGR8 frame -> [3][net_h][net_w] fp32 planes R, G, B in [0, 1]: resize keeping the aspect (scale = min(net_w / w, net_h / h), new size
+ * truncated), centred on a canvas of 114s.  The tensor stays on the device (vp_detect_input_device); dst_host_chw may be NULL.  Remembers
+ * the letterbox geometry for the next vp_detect_postprocess (the reference's scale_, pad_x_, pad_y_, orig_width_, orig_height_). */
+int vp_detect_preprocess(vp_detect* d, const uint8_t* bgr, int h, int w, int stride_bytes, float* dst_host_chw);
+int vp_detect_input_device(const vp_detect* d, void** dev_f32_chw);
+int vp_detect_letterbox(const vp_detect* d, float* scale, int* pad_x, int* pad_y);
+int vp_detect_set_letterbox(vp_detect* d, float scale, int pad_x, int pad_y, int orig_w, int orig_h); /* geometry from elsewhere */
+/* raw: host pointer, or device pointer when raw_on_device != 0.  Per box: strict-'>' argmax of the class scores from 0, `score <
+ * conf_thresh` dropped, box back to image coordinates and clamped; then sorted by confidence (descending; equal confidences keep the box
+ * order, which the reference's std::sort leaves unspecified) and greedily suppressed per class at IoU > iou_thresh.  *count = detections
+ * kept; min(*count, out_cap) of them are written, in the reference's output order. */
+int vp_detect_postprocess(vp_detect* d, const float* raw, int raw_on_device, int num_attrs, int num_boxes, float conf_thresh, float iou_thresh,
+                          vp_detection* out, int out_cap, int* count);
+
 /* ---- single-operator entry (unit parity tests of the MFMA conv kernel; not used by callers) -------------- */
 /* mode 0: Conv2d k=ks stride 1 pad ks/2, weight [Cout][Cin][ks][ks]; mode 1: ConvTranspose2d k2 s2, weight
  * [Cin][Cout][2][2].  act: 0 none 1 GELU 2 SiLU.  res_mode: 0 none 1 add 2 mul-add; res has the output shape.

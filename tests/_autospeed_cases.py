@@ -1,0 +1,49 @@
+"""Shared inputs of the AutoSpeed pre / post-processing tests (CPU-emulated and GPU): synthetic frames and detector output tensors with
+the cases the reference's code distinguishes -- ties in confidence, boxes of different classes that overlap, boxes outside the frame,
+scores of zero and below, a threshold of zero, nothing above the threshold, more detections than the caller's buffer."""
+import numpy as np
+
+from oracle import autospeed
+
+
+def frame(h, w, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    base = ((x * 3 + y * 5 + seed * 17) % 256).astype(np.int32)
+    img = np.stack([(base + 40 * c) % 256 for c in range(3)], axis=2) + rng.integers(-20, 21, size=(h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def raw_tensor(num_boxes, num_classes, seed, net=640, clusters=40, p_obj=0.12):
+    """[4 + classes][boxes] fp32 like a YOLO head's: most boxes near zero score, clusters of overlapping boxes around a few objects."""
+    rng = np.random.default_rng(seed)
+    raw = np.zeros((4 + num_classes, num_boxes), np.float32)
+    centres = rng.uniform(-20, net + 20, size=(clusters, 2))
+    sizes = rng.uniform(10, 220, size=(clusters, 2))
+    owner = rng.integers(0, clusters, size=num_boxes)
+    raw[0] = centres[owner, 0] + rng.normal(0, 6, num_boxes)
+    raw[1] = centres[owner, 1] + rng.normal(0, 6, num_boxes)
+    raw[2] = np.abs(sizes[owner, 0] * rng.uniform(0.8, 1.25, num_boxes))
+    raw[3] = np.abs(sizes[owner, 1] * rng.uniform(0.8, 1.25, num_boxes))
+    raw[4:] = rng.uniform(-0.05, 0.08, size=(num_classes, num_boxes))
+    obj = rng.random(num_boxes) < p_obj
+    cls = owner % num_classes
+    conf = np.round(rng.uniform(0.2, 0.99, num_boxes), 2)            # two decimals: plenty of EQUAL confidences
+    raw[4 + cls[obj], np.nonzero(obj)[0]] = conf[obj]
+    second = obj & (rng.random(num_boxes) < 0.3)                     # a second class scoring exactly the same: the first one wins
+    raw[4 + (cls[second] + 1) % num_classes, np.nonzero(second)[0]] = conf[second]
+    if num_boxes > 8:
+        raw[4:, 3] = 0.0                                             # all scores zero: class -1, confidence 0
+        raw[4:, 5] = -1.0
+        raw[4:, 7] = np.nan                                          # NaN never wins the strict '>'
+    return raw
+
+
+def check(det_got, n_got, raw, conf, iou, geom, orig_w, orig_h, cap=None):
+    scale, pad_x, pad_y = geom
+    want = autospeed.postprocess(raw, conf, iou, scale, pad_x, pad_y, orig_w, orig_h)
+    assert n_got == len(want), (n_got, len(want))
+    k = len(want) if cap is None else min(cap, len(want))
+    assert det_got.shape == (k, 6)
+    assert np.array_equal(det_got.view(np.uint32), want[:k].view(np.uint32))      # bit for bit, in the reference's order
+    return len(want)

@@ -8,6 +8,7 @@ alignas(16) VP_EMU_LDS char smem[160 << 10];
 alignas(16) VP_EMU_LDS unsigned char dw_smem[160 << 10];
 alignas(16) VP_EMU_LDS unsigned char se_smem[64 << 10];
 alignas(16) VP_EMU_LDS unsigned char bk_smem[64 << 10];
+alignas(16) VP_EMU_LDS unsigned char det_smem[160 << 10];
 alignas(16) VP_EMU_LDS float xs[40 << 10];
 alignas(16) VP_EMU_LDS float sh[40 << 10];
 }  // namespace vp
@@ -122,6 +123,13 @@ int emu_se_gate_scale(const unsigned long long* sums, int replicas, int C, int C
   q.w = w; q.out_hi = static_cast<half_t*>(out_hi); q.out_lo = static_cast<half_t*>(out_lo); q.rows = rows; q.C = C; q.w2 = w2; q.b2 = b2;
   q.sq = sq; q.Creal = Creal; q.frames = frames;
   return launch_se_gate_scale(p, q, nullptr);
+}
+int emu_detect(const float* raw, int num_attrs, int num_boxes, float conf, float iou, float scale, int pad_x, int pad_y, int orig_w, int orig_h, float* boxes, int* cls,
+               void* out, int out_cap, int* count) {
+  DetectParams p{};
+  p.raw = raw; p.num_attrs = num_attrs; p.num_boxes = num_boxes; p.conf_thresh = conf; p.iou_thresh = iou; p.scale = scale; p.pad_x = pad_x; p.pad_y = pad_y;
+  p.orig_w = orig_w; p.orig_h = orig_h; p.boxes = boxes; p.cls = cls; p.out = static_cast<Detection*>(out); p.out_cap = out_cap; p.count = count;
+  return launch_detect_decode_nms(p, nullptr);
 }
 int emu_fc(const float* x, const float* w, const float* b, float* out, int N, int K, int act) {
   FcParams p{};

@@ -26,6 +26,7 @@ int emu_mbconv_front(void*, void*, int, int, int, const void*, const void*, cons
 int emu_mbconv_back(void*, void*, int, int, int, int, const unsigned long long*, int, int, const float*, const float*, const float*, const float*, int, const float*, const float*,
                     void*, void*, void*, void*, int, const unsigned long long*);
 int emu_fc(const float*, const float*, const float*, float*, int, int, int);
+int emu_detect(const float*, int, int, float, float, float, int, int, int, int, float*, int*, void*, int, int*);
 int emu_pool_partial(void*, void*, int, int, int, float*, int);
 int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
 int emu_depth_viz(const float*, size_t, const uint8_t*, uint8_t*);
@@ -161,6 +162,20 @@ int main(int argc, char** argv) {
       std::vector<float> w1 = rnd(sq * C, 0.2f), b1 = rnd(sq, 0.1f), w2q = rnd((size_t)sqp * C, 0.5f), b2 = rnd(C, 0.1f), pw = rnd((size_t)cout * C), pb = rnd(cout);
       bad |= emu_mbconv_back(ih.data(), il.data(), h, ww, C, C, sums.data(), 8, sq, w1.data(), b1.data(), w2q.data(), b2.data(), sqp, pw.data(), pb.data(), rh.data(), rl.data(),
                              oh_.data(), ol_.data(), cout, cfg ? sums.data() : nullptr);
+    }
+    {  // detector decode + NMS (kernels_detect.hip): LDS candidate list, bitonic sort, suppression flags written between barriers
+      const int nb = 600, na = 7;
+      std::vector<float> raw = rnd((size_t)na * nb, 0.5f);
+      for (int i = 0; i < nb; ++i) {
+        raw[i] = 40.0f + (float)(i % 23) * 9.0f;
+        raw[nb + i] = 50.0f + (float)(i % 17) * 11.0f;
+        raw[2 * nb + i] = 30.0f + (float)(i % 5);
+        raw[3 * nb + i] = 25.0f + (float)(i % 7);
+      }
+      std::vector<float> boxes((size_t)nb * 4);
+      std::vector<int> cls(nb), count(2);
+      std::vector<float> out((size_t)nb * 6);
+      bad |= emu_detect(raw.data(), na, nb, 0.1f, 0.4f, 0.5f, 0, 140, 1280, 720, boxes.data(), cls.data(), out.data(), nb, count.data());
     }
     std::vector<float> fx = rnd(200), fw = rnd(37 * 200, 0.1f), fb = rnd(37), fo(37);
     bad |= emu_fc(fx.data(), fw.data(), fb.data(), fo.data(), 37, 200, 1);

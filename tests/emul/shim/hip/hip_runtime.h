@@ -546,6 +546,7 @@ inline unsigned atomicMax(unsigned* p, unsigned v) {
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 inline float __expf(float x) { return expf(x); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline float __fdiv_rn(float a, float b) { return a / b; }
 inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __fadd_rn(float a, float b) { return a + b; }

@@ -95,3 +95,33 @@ def test_multicam_host_cpp(tmp_path, state_dicts):
             assert len(np.unique(got)) > 1          # a real class map, not a constant
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_autospeed_stages_adapter_matches_oracle(tmp_path):
+    """adapters/autospeed_hip_stages.hpp driven as AutoSpeedOnnxEngine::inference drives its two CPU stages (preprocessAutoSpeed -> the
+    detector -> postProcess, onnxruntime_engine.cpp:115-168): the letterbox tensor and the kept detections, bit for bit against the oracle."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _autospeed_cases as cases
+    from oracle import autospeed
+
+    _build()
+    raw = cases.raw_tensor(8400, 4, 21)
+    rawf, out = tmp_path / "raw.bin", tmp_path / "out.bin"
+    raw.tofile(rawf)
+    r = subprocess.run([BIN, "autospeed", str(rawf), str(out), "8", "8400"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    blob = np.fromfile(out, dtype=np.uint8)
+    frame = blob[:720 * 1280 * 3].reshape(720, 1280, 3)
+    rest = blob[720 * 1280 * 3:]
+    want_in, (scale, px, py) = autospeed.preprocess(frame)
+    n_in = 3 * 640 * 640 * 4
+    assert np.array_equal(rest[:n_in].view(np.float32).reshape(3, 640, 640), want_in)
+    n = int(rest[n_in:n_in + 4].view(np.int32)[0])
+    want = autospeed.postprocess(raw, 0.25, 0.45, scale, px, py, 1280, 720)
+    assert n == len(want) and n > 5
+    got = rest[n_in + 4:n_in + 4 + 24 * n].view(np.float32).reshape(n, 6).copy()
+    got[:, 5] = rest[n_in + 4:n_in + 4 + 24 * n].view(np.int32).reshape(n, 6)[:, 5].astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
