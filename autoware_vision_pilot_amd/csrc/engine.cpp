@@ -412,7 +412,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           mp.out = z->view();
           mp.k = S.k;
           mp.stride = stride;
-          mp.sums = sums;
+          mp.sums = zsums ? nullptr : sums;   // the back half starts from the squeeze sums: the per-channel sums are not needed
           mp.replicas = se_rep;
           mp.w1 = d_se_w1;
           mp.sq = sq;

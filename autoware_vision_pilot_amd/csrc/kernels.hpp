@@ -68,7 +68,7 @@ struct MbFrontParams {
   const float* b_dw;    // [Cexp_pad]
   ActView out;          // H/stride x W/stride x Cexp_pad, (hi, lo)
   int k, stride;
-  unsigned long long* sums;  // [replicas][Cexp_pad] fixed-point channel sums (as DwParams)
+  unsigned long long* sums;  // [replicas][Cexp_pad] fixed-point channel sums (as DwParams); may be null when zsums is given
   int replicas;
   // optional: the squeeze FC of the block's squeeze-excite, taken here from the workgroup's own channel sums (it is linear in them):
   // zsums[replica][j] += fixed(sum_c w1[j][c] * patch_sum[c]) -- the back half (mbconv_back) then starts from sq numbers, not from the means

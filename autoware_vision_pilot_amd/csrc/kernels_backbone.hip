@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     for (int i = 0; i < 8; ++i) acc[i] = fmaf(in[k], wk[i], acc[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = p.out.lo ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
+  for (int i = 0; i < 8; ++i) acc[i] = silu_f16(acc[i]);  // x * rcp(1 + exp2(-x log2 e)) in fp32 (v_exp_f32 / v_rcp_f32, |error| <= 3e-7 |silu|): every mode since round 3 -- libm's expf + IEEE division cost 3-9 us per launch (tools/mbf_check.hip)
   store8(p.out, (size_t)pix * 32 + g * 8, acc);
 }
 
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void dwconv_pool_kernel(const DwParams pin, co
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = SPLIT ? silu_f(acc[i]) : silu_f16(acc[i]);  // VP_FP16: common.hpp ACT_*_F16
+    for (int i = 0; i < 8; ++i) acc[i] = silu_f16(acc[i]);  // as in stem_kernel
     store8(p.out, (size_t)pix * p.out.C + cc, acc);
 #pragma unroll
     for (int i = 0; i < 8; ++i) atomicAdd(&red64[og * 8 + i], (unsigned long long)(long long)__float2ll_rn(acc[i] * kPoolFix));

@@ -22,6 +22,11 @@
 
 namespace vp {
 
+// SiLU of the fused halves: x * rcp(1 + exp2(-x log2 e)) on v_exp_f32 / v_rcp_f32 (about 1 ulp each: |error| <= 3e-7 |silu(x)|, the class of the
+// GELU in the convolution epilogues).  silu_f's libm expf + IEEE division are ~30 instructions per value: 3-9 us of EVERY front launch
+// (46 values per thread; tools/mbf_check.hip, profiles/r03_mbf_check.txt).
+__device__ __forceinline__ float silu_mb(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+
 template <int K, int S>
 struct MbTile {
   static constexpr int TH = S == 1 ? 8 : 4, TW = 16;
@@ -35,10 +40,11 @@ struct MbTile {
   static constexpr int E_BYTES = HPX * EPITCH;
   static constexpr int STAGE = 2 * X_BYTES + 2 * W_BYTES;
   static constexpr int MAIN = STAGE > E_BYTES ? STAGE : E_BYTES;   // the expanded tile overlays the staging buffers
-  static constexpr int LDS = MAIN + K * K * 32 * 4 + 32 * 8;       // + depthwise filter slice + pool accumulators
+  static constexpr int LDS = MAIN + K * K * 32 * 4 + 32 * 8 + 64 * 32 * 4;   // + depthwise filter slice + pool accumulators + squeeze-FC slice
 };
 
-template <int K, int S>
+// ABL (tools/mbf_check.hip only): 1 = no expand loop, 2 = no depthwise taps, 4 = no pool atomics (LDS and global), 8 = no SiLU
+template <int K, int S, int ABL = 0>
 __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
   using T = MbTile<K, S>;
   constexpr int TH = T::TH, TW = T::TW, IW = T::IW, HPX = T::HPX, NF = T::NF, NFW = T::NFW, XP = T::XPITCH, EP = T::EPITCH;
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   unsigned char* const es = dw_smem;                                             // [HPX][EP] fp32, after the GEMM
   float* const wl = reinterpret_cast<float*>(dw_smem + T::MAIN);                 // [K*K][32]
   unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(dw_smem + T::MAIN + K * K * 32 * 4);  // [32]
+  float* const w1s = reinterpret_cast<float*>(dw_smem + T::MAIN + K * K * 32 * 4 + 32 * 8);                       // [sq][32] squeeze FC, this workgroup's 32 channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int OW = p.out.W, OH = p.out.H;
@@ -69,6 +76,9 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     *reinterpret_cast<f32x4_t*>(wl + tp * 32 + j * 4) = *reinterpret_cast<const f32x4_t*>(p.w_dw + (size_t)tp * Cexp + c0 + j * 4);
   }
   if (tid < 32) red64[tid] = 0ull;
+  if (p.w1)  // fetched now, used after the last barrier: the tail of the kernel is then LDS reads + one atomic per squeeze unit
+    for (int i = tid; i < p.sq * 8; i += 256)
+      *reinterpret_cast<f32x4_t*>(w1s + (i >> 3) * 32 + (i & 7) * 4) = *reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)(i >> 3) * p.out.C + blockIdx.y * 32 + (i & 7) * 4);
 
   // ---- 1: expand GEMM over the halo patch.  A = weights (32 expanded channels x 16 k), B = pixels (32 halo pixels x 16 k); a lane's
   // 16 accumulators of a tile are channels 8 g + 4 (lane >> 5) + r (g, r = 0..3) of halo pixel 32 f + (lane & 31).
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     }                                                                                                  \
   }
   VP_MB_LOAD(0)
-  for (int c = 0; c < KC; ++c) {
+  for (int c = 0; c < ((ABL & 1) ? 0 : KC); ++c) {
 #pragma unroll
     for (int i = 0; i < PCS; ++i) {
       const int q = tid + 256 * i;
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
         for (int g = 0; g < 4; ++g) {
           f32x4_t v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = in_img ? silu_f(acc[j][4 * g + r] + be[g][r]) : 0.0f;
+          for (int r = 0; r < 4; ++r) v[r] = in_img ? ((ABL & 8) ? acc[j][4 * g + r] + be[g][r] : silu_mb(acc[j][4 * g + r] + be[g][r])) : 0.0f;
           *reinterpret_cast<f32x4_t*>(es + hp * EP + (8 * g + 4 * (lane >> 5)) * 4) = v;
         }
       }
@@ -166,7 +176,10 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   }
   __syncthreads();
 
-  // ---- 3: depthwise + SiLU + store + pool.  Item = (output pixel of the patch, channel octet): 128 x 4 (stride 1) or 64 x 4 items.
+  // ---- 3: depthwise + SiLU + store + pool.  Item = (output pixel of the patch, channel octet): 128 x 4 (stride 1) or 64 x 4 items.  Pool: an
+  // LDS atomic per value (2^24 fixed-point integers: any order gives the same bits).  Measured alternative, not kept: summing a thread's
+  // items in registers and the lanes of an octet by shuffles before ONE atomic per (wave, octet) is ~1 us SLOWER per launch (64 64-bit
+  // ds_bpermutes against 16 same-address LDS atomics, which the LDS resolves at a lane a clock).
   constexpr int ITEMS = TH * TW * 4;
   for (int it = tid; it < ITEMS; it += 256) {
     const int og = it & 3, pl = it >> 2;
@@ -184,9 +197,9 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
       }
     }
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky)
+    for (int ky = 0; ky < ((ABL & 2) ? 1 : K); ++ky)
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
+      for (int kx = 0; kx < ((ABL & 2) ? 1 : K); ++kx) {
         const unsigned char* src = es + ((ty * S + ky) * IW + (tx * S + kx)) * EP + og * 32;
         const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src), v1 = *reinterpret_cast<const f32x4_t*>(src + 16);
         const float* wk = wl + (ky * K + kx) * 32 + og * 8;
@@ -197,22 +210,27 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
           a8[4 + i] = fmaf(v1[i], w1[i], a8[4 + i]);
         }
       }
+    if (!(ABL & 8)) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a8[i] = silu_f(a8[i]);
+      for (int i = 0; i < 8; ++i) a8[i] = silu_mb(a8[i]);
+    }
     store8(p.out, ((size_t)oy * OW + ox) * Cexp + cc, a8);
+    if (!(ABL & 4)) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&red64[og * 8 + i], (unsigned long long)(long long)__float2ll_rn(a8[i] * 16777216.0f));
+      for (int i = 0; i < 8; ++i) atomicAdd(&red64[og * 8 + i], (unsigned long long)(long long)__float2ll_rn(a8[i] * 16777216.0f));
+    }
   }
   __syncthreads();
-  if (tid < 32) {
-    const unsigned long long v = red64[tid];
+  if (ABL & 4) return;
+  if (p.sums && tid < 32) {  // the per-channel sums: only for a back half that rebuilds the means itself (device-scope atomics execute at the
+    const unsigned long long v = red64[tid];   // memory side: the 32 + sq of a workgroup were 3-6 us at the end of every launch)
     if (v != 0ull) atomicAdd(p.sums + (size_t)(blockIdx.x & (p.replicas - 1)) * Cexp + c0 + tid, v);
   }
   // squeeze FC of the squeeze-excite, this workgroup's share (32 channels x its patch): linear in the sums, so it can be taken here and
   // added up as integers like them -- mbconv_back then reads sq numbers instead of streaming the FC matrix through every workgroup
   if (p.w1 && tid >= 64 && tid < 64 + p.sq) {
     const int j = tid - 64;
-    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)j * Cexp + c0);
+    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(w1s + j * 32);
     float z = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -225,17 +243,17 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 }
 
 bool mbconv_front_supported(const MbFrontParams& p) {
-  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.w_dw && p.b_dw && p.sums && (p.k == 3 || p.k == 5) &&
+  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.w_dw && p.b_dw && (p.sums || (p.w1 && p.zsums)) && (p.k == 3 || p.k == 5) &&
          (p.stride == 1 || p.stride == 2) && (!p.w1 || (p.zsums && p.sq >= 1 && p.sq <= 64)) && (p.in.C & 31) == 0 && (p.out.C & 31) == 0 && p.replicas >= 1 && (p.replicas & (p.replicas - 1)) == 0 &&
          p.out.H == p.in.H / p.stride && p.out.W == p.in.W / p.stride && p.in.H % p.stride == 0 && p.in.W % p.stride == 0;
 }
 
-template <int K, int S>
+template <int K, int S, int ABL = 0>
 static hipError_t launch_mb(const MbFrontParams& p, hipStream_t st) {
   using T = MbTile<K, S>;
   static_assert(T::LDS <= 160 * 1024, "LDS budget");
   static LdsAttrOnce once;
-  auto k = mbconv_front_kernel<K, S>;
+  auto k = mbconv_front_kernel<K, S, ABL>;
   if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(k), T::LDS); e != hipSuccess) return e;
   const dim3 grid(((p.out.H + T::TH - 1) / T::TH) * ((p.out.W + T::TW - 1) / T::TW), p.out.C / 32);
   hipLaunchKernelGGL(k, grid, dim3(256), T::LDS, st, p);

@@ -259,6 +259,11 @@ def test_mbconv_front_kernel(emu, cin, cexp, k, stride, H, W):
     want_z = w1.astype(np.float64) @ pooled
     assert np.abs(z[:sq] - want_z).max() <= 3e-6 * max(1.0, np.abs(want_z).max())
     assert not z[sq:].any()
+    # the engine's form: no per-channel sums at all (the back half starts from the squeeze sums) -- same tensor, same squeeze sums
+    oh2, ol2, zs2 = np.zeros_like(oh), np.zeros_like(ol), np.zeros_like(zsums)
+    assert emu.emu_mbconv_front(ptr(xh), ptr(xl), H, W, cinp, ptr(wh), ptr(wlo), ptr(bep), ptr(wk), ptr(bdp), ptr(oh2), ptr(ol2), cexpp, k, stride,
+                                None, replicas, ptr(w1), sq, ptr(zs2)) == 0
+    assert np.array_equal(oh2, oh) and np.array_equal(ol2, ol) and np.array_equal(zs2.sum(axis=0), zsums.sum(axis=0))
 
 
 @pytest.mark.parametrize("cexp,cout,sq,H,W,residual", [(1152, 192, 48, 10, 20, True), (144, 40, 6, 9, 13, False), (240, 40, 10, 40, 80, True),
