@@ -122,7 +122,7 @@ int vp_detect_preprocess(vp_detect* d, const uint8_t* bgr, int h, int w, int str
     const float scale = std::min((float)d->net_w / (float)w, (float)d->net_h / (float)h);
     const int new_w = (int)((float)w * scale), new_h = (int)((float)h * scale);
     if (new_w < 1 || new_h < 1 || new_w > d->net_w || new_h > d->net_h) throw std::invalid_argument("vp_detect_preprocess: the frame collapses under the letterbox scale");
-    const size_t bytes = (size_t)h * stride_bytes;
+    const size_t bytes = (size_t)(h - 1) * stride_bytes + (size_t)3 * w;   // a strided view may END with its last pixel: never read a full last stride
     if (bytes > d->frame_cap) {
       if (d->d_frame) VP_HIP_CHECK(hipFree(d->d_frame));
       d->d_frame = nullptr;

@@ -261,7 +261,9 @@ int vp_tensor_read(vp_engine* e, int i, float* dst_chw);                       /
  * onnxruntime_engine.cpp:71-113) and ::postProcess / ::computeIoU / ::applyNMS (:170-290); the TensorRT engine (tensorrt_engine.cpp)
  * holds the same two stages.  The detector network is NOT part of this library: the host runs it between the two calls and hands its
  * output tensor [num_attrs][num_boxes] (cx, cy, w, h in letterbox pixels, then the class scores) to vp_detect_postprocess.
- * vp_detection is the reference's `Detection` (autospeed/detection.hpp:8-12), field for field. */
+ * vp_detection is the reference's `Detection` (autospeed/detection.hpp:8-12), field for field.  A handle owns its stream and buffers and is
+ * not thread-safe (one handle per calling thread, as the reference has one engine object per thread); every call returns synchronised.
+ * With raw_on_device the caller's producer must have finished writing the tensor (the call does not wait on foreign streams). */
 typedef struct vp_detect vp_detect;
 typedef struct vp_detection {
   float x1, y1, x2, y2; /* image coordinates, clamped to the frame */

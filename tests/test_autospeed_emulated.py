@@ -81,6 +81,11 @@ def test_letterbox_kernel_bit_exact(emu_lib, shape):
         view = np.ascontiguousarray(np.pad(f, ((0, 0), (0, 7), (0, 0))))[:, :shape[1]]   # a strided view: rows longer than 3 w
         got2, _ = det.preprocess(view)
         assert np.array_equal(got2, want)
+        flat = np.zeros(shape[0] * (shape[1] + 7) * 3 - 21, np.uint8)                  # ... that ENDS with the last pixel of the last row
+        tight = np.lib.stride_tricks.as_strided(flat, shape=(shape[0], shape[1], 3), strides=((shape[1] + 7) * 3, 3, 1))
+        tight[:] = f
+        got3, _ = det.preprocess(tight)
+        assert np.array_equal(got3, want)
     finally:
         det.close()
 
