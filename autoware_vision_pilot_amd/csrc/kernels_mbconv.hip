@@ -43,7 +43,8 @@ struct MbTile {
   static constexpr int LDS = MAIN + K * K * 32 * 4 + 32 * 8 + 64 * 32 * 4;   // + depthwise filter slice + pool accumulators + squeeze-FC slice
 };
 
-// ABL (tools/mbf_check.hip only): 1 = no expand loop, 2 = no depthwise taps, 4 = no pool atomics (LDS and global), 8 = no SiLU
+// ABL (tools/mbf_check.hip only): 1 = no expand loop, 2 = no depthwise taps, 4 = no pool atomics (LDS and global), 8 = no SiLU,
+// 16 = expand loop without its global loads after chunk 0, 32 = expand loop without LDS staging / fragment reads / MFMAs (loads only)
 template <int K, int S, int ABL = 0>
 __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
   using T = MbTile<K, S>;
@@ -119,6 +120,14 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   }
   VP_MB_LOAD(0)
   for (int c = 0; c < ((ABL & 1) ? 0 : KC); ++c) {
+    if constexpr ((ABL & 32) != 0) {  // loads only: fold the pieces into one accumulator element so that they stay
+      u32x4 t_ = rw_hi ^ rw_lo;
+#pragma unroll
+      for (int i = 0; i < PCS; ++i) t_ ^= rx_hi[i] ^ rx_lo[i];
+      acc[0][0] += __uint_as_float((t_[0] ^ t_[1] ^ t_[2] ^ t_[3]) & 0x3f800000u);
+      if (c + 1 < KC) VP_MB_LOAD(c + 1)
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < PCS; ++i) {
       const int q = tid + 256 * i;
@@ -132,7 +141,9 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
       *reinterpret_cast<u32x4*>(ws_lo + w_row * XP + w_part * 16) = rw_lo;
     }
     __syncthreads();
-    if (c + 1 < KC) VP_MB_LOAD(c + 1)
+    if constexpr ((ABL & 16) == 0) {
+      if (c + 1 < KC) VP_MB_LOAD(c + 1)
+    }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       const int fo = (lane & 31) * XP + ss * 32 + (lane >> 5) * 16;

@@ -59,7 +59,7 @@ static void run(int cin, int cexp, int H, int W) {
   pz.sums = nullptr;   // the engine's form: the back half starts from the squeeze sums, no per-channel sums
   const float t_nosums = time_it([&] { return launch_mb<K, S, 0>(pz, 0); });
   std::printf("k%d s%d  %4d -> %4d  %3dx%-3d  %4d workgroups, %d K chunks | engine form (squeeze sums only) %5.1f us | with per-channel sums %5.1f | no expand loop %5.1f | no taps %5.1f | no pool atomics %5.1f | no SiLU %5.1f | "
-              "no loop, no taps %5.1f | nothing but loads of the tile and the store %5.1f\n", K, S, cin, cexp, H, W, grid, Cin / 32, t_nosums, T_(0), T_(1), T_(2), T_(4), T_(8), T_(3), T_(15));
+              "no loop, no taps %5.1f | nothing but loads of the tile and the store %5.1f | loop without its loads %5.1f | loop with loads only %5.1f\n", K, S, cin, cexp, H, W, grid, Cin / 32, t_nosums, T_(0), T_(1), T_(2), T_(4), T_(8), T_(3), T_(15), T_(16), T_(32));
 }
 
 int main() {
