@@ -32,7 +32,6 @@ struct MbTile {
   static constexpr int TH = S == 1 ? 8 : 4, TW = 16;
   static constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, HPX = IH * IW;
   static constexpr int NF = (HPX + 31) / 32;          // 32-pixel MFMA column tiles of the halo
-  static constexpr int NFW = (NF + 3) / 4;            // per wave (4 waves)
   static constexpr int XPITCH = 80;                   // bytes per staged pixel row (32 channels fp16 + 16: conflict-free ds_read_b128)
   static constexpr int X_BYTES = NF * 32 * XPITCH;    // one plane of the input chunk
   static constexpr int W_BYTES = 32 * XPITCH;         // one plane of the weight chunk (32 expanded channels x 32 input channels)
@@ -43,12 +42,16 @@ struct MbTile {
   static constexpr int LDS = MAIN + K * K * 32 * 4 + 32 * 8 + 64 * 32 * 4;   // + depthwise filter slice + pool accumulators + squeeze-FC slice
 };
 
+// NW = waves of the workgroup: 4 where the grid is several workgroups per CU (the 80x160 and 160x320 maps), 8 on the smaller maps -- there a
+// CU holds ONE workgroup, and with one wave per SIMD the chain LDS stage -> barrier -> fragment reads -> dependent MFMAs -> barrier of a K chunk
+// ran strictly one after the other (1.05 us per chunk, profiles/r03_mbf_check.txt); two waves per SIMD interleave their halves of it.
 // ABL (tools/mbf_check.hip only): 1 = no expand loop, 2 = no depthwise taps, 4 = no pool atomics (LDS and global), 8 = no SiLU,
 // 16 = expand loop without its global loads after chunk 0, 32 = expand loop without LDS staging / fragment reads / MFMAs (loads only)
-template <int K, int S, int ABL = 0>
-__global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
+template <int K, int S, int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontParams p) {
   using T = MbTile<K, S>;
-  constexpr int TH = T::TH, TW = T::TW, IW = T::IW, HPX = T::HPX, NF = T::NF, NFW = T::NFW, XP = T::XPITCH, EP = T::EPITCH;
+  constexpr int NT = 64 * NW;
+  constexpr int TH = T::TH, TW = T::TW, IW = T::IW, HPX = T::HPX, NF = T::NF, NFW = (NF + NW - 1) / NW, XP = T::XPITCH, EP = T::EPITCH;
   constexpr int pad = (K - 1) / 2;
   extern __shared__ unsigned char dw_smem[];
   unsigned char* const xs_hi = dw_smem;
@@ -72,13 +75,13 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // depthwise filter slice + pool accumulators (read after several barriers)
-  for (int i = tid; i < K * K * 8; i += 256) {
+  for (int i = tid; i < K * K * 8; i += NT) {
     const int tp = i >> 3, j = i & 7;
     *reinterpret_cast<f32x4_t*>(wl + tp * 32 + j * 4) = *reinterpret_cast<const f32x4_t*>(p.w_dw + (size_t)tp * Cexp + c0 + j * 4);
   }
   if (tid < 32) red64[tid] = 0ull;
   if (p.w1)  // fetched now, used after the last barrier: the tail of the kernel is then LDS reads + one atomic per squeeze unit
-    for (int i = tid; i < p.sq * 8; i += 256)
+    for (int i = tid; i < p.sq * 8; i += NT)
       *reinterpret_cast<f32x4_t*>(w1s + (i >> 3) * 32 + (i & 7) * 4) = *reinterpret_cast<const f32x4_t*>(p.w1 + (size_t)(i >> 3) * p.out.C + blockIdx.y * 32 + (i & 7) * 4);
 
   // ---- 1: expand GEMM over the halo patch.  A = weights (32 expanded channels x 16 k), B = pixels (32 halo pixels x 16 k); a lane's
@@ -89,14 +92,14 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
   const int KC = Cin >> 5;
-  // staging plan: 16-byte piece i of this thread = (halo pixel, 8-channel part) q = tid + 256 i of a chunk; element offset of the piece in
+  // staging plan: 16-byte piece i of this thread = (halo pixel, 8-channel part) q = tid + NT i of a chunk; element offset of the piece in
   // chunk 0, or -1 (outside the image / past the patch: zeros).  The pieces of chunk c + 1 are REQUESTED before the MFMAs of chunk c and
   // parked in registers: the loop is a latency chain (load -> LDS -> barrier -> fragments -> MFMA) of 1-6 links, one per 32 input channels
-  constexpr int PCS = (NF * 32 * 4 + 255) / 256;
+  constexpr int PCS = (NF * 32 * 4 + NT - 1) / NT;
   int x_off[PCS];
 #pragma unroll
   for (int i = 0; i < PCS; ++i) {
-    const int q = tid + 256 * i, hp = q >> 2, part = q & 3;
+    const int q = tid + NT * i, hp = q >> 2, part = q & 3;
     const int hy = hp / IW, hx = hp - hy * IW;
     const int gy = iy0 + hy, gx = ix0 + hx;
     const bool ok = q < NF * 32 * 4 && hp < HPX && (unsigned)gy < (unsigned)p.in.H && (unsigned)gx < (unsigned)p.in.W;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     }
 #pragma unroll
     for (int i = 0; i < PCS; ++i) {
-      const int q = tid + 256 * i;
+      const int q = tid + NT * i;
       if (q < NF * 32 * 4) {
         *reinterpret_cast<u32x4*>(xs_hi + (q >> 2) * XP + (q & 3) * 16) = rx_hi[i];
         *reinterpret_cast<u32x4*>(xs_lo + (q >> 2) * XP + (q & 3) * 16) = rx_lo[i];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
       const h8_t a_hi = *reinterpret_cast<const h8_t*>(ws_hi + fo), a_lo = *reinterpret_cast<const h8_t*>(ws_lo + fo);
 #pragma unroll
       for (int j = 0; j < NFW; ++j) {
-        const int f = wave + 4 * j;
+        const int f = wave + NW * j;
         if (f < NF) {
           const h8_t b_hi = *reinterpret_cast<const h8_t*>(xs_hi + f * 32 * XP + fo), b_lo = *reinterpret_cast<const h8_t*>(xs_lo + f * 32 * XP + fo);
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     for (int g = 0; g < 4; ++g) be[g] = *reinterpret_cast<const f32x4_t*>(p.b_exp + c0 + 8 * g + 4 * (lane >> 5));
 #pragma unroll
     for (int j = 0; j < NFW; ++j) {
-      const int f = wave + 4 * j;
+      const int f = wave + NW * j;
       const int hp = f * 32 + (lane & 31);
       if (f < NF && hp < HPX) {
         const int hy = hp / IW, hx = hp - hy * IW;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   // items in registers and the lanes of an octet by shuffles before ONE atomic per (wave, octet) is ~1 us SLOWER per launch (64 64-bit
   // ds_bpermutes against 16 same-address LDS atomics, which the LDS resolves at a lane a clock).
   constexpr int ITEMS = TH * TW * 4;
-  for (int it = tid; it < ITEMS; it += 256) {
+  for (int it = tid; it < ITEMS; it += NT) {
     const int og = it & 3, pl = it >> 2;
     const int ty = pl / TW, tx = pl - ty * TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
@@ -259,16 +262,21 @@ bool mbconv_front_supported(const MbFrontParams& p) {
          p.out.H == p.in.H / p.stride && p.out.W == p.in.W / p.stride && p.in.H % p.stride == 0 && p.in.W % p.stride == 0;
 }
 
-template <int K, int S, int ABL = 0>
-static hipError_t launch_mb(const MbFrontParams& p, hipStream_t st) {
+template <int K, int S, int NW, int ABL = 0>
+static hipError_t launch_mb_nw(const MbFrontParams& p, hipStream_t st) {
   using T = MbTile<K, S>;
   static_assert(T::LDS <= 160 * 1024, "LDS budget");
   static LdsAttrOnce once;
-  auto k = mbconv_front_kernel<K, S, ABL>;
+  auto k = mbconv_front_kernel<K, S, NW, ABL>;
   if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(k), T::LDS); e != hipSuccess) return e;
   const dim3 grid(((p.out.H + T::TH - 1) / T::TH) * ((p.out.W + T::TW - 1) / T::TW), p.out.C / 32);
-  hipLaunchKernelGGL(k, grid, dim3(256), T::LDS, st, p);
+  hipLaunchKernelGGL(k, grid, dim3(64 * NW), T::LDS, st, p);
   return hipGetLastError();
+}
+template <int K, int S, int ABL = 0>
+static hipError_t launch_mb(const MbFrontParams& p, hipStream_t st) {
+  // maps up to 40x80 (<= 200 workgroups: one per CU): eight waves; the big maps keep four (three workgroups per CU)
+  return p.out.H * p.out.W <= 3200 ? launch_mb_nw<K, S, 8, ABL>(p, st) : launch_mb_nw<K, S, 4, ABL>(p, st);
 }
 
 hipError_t launch_mbconv_front(const MbFrontParams& p, hipStream_t st) {
@@ -555,7 +563,8 @@ static hipError_t launch_mbb(const MbBackParams& p, hipStream_t st) {
 
 hipError_t launch_mbconv_back(const MbBackParams& p, hipStream_t st) {
   if (!mbconv_back_supported(p)) return hipErrorInvalidValue;
-  // 80x160 and 160x320 (K = 2 ... 10 steps): a wave per pixel tile, four waves; the smaller maps: eight waves, an eighth of K each
+  // 80x160 and 160x320 (K = 2 ... 10 steps): a wave per pixel tile, four waves; the smaller maps: eight waves, an eighth of K each.  (64 pixels
+  // x eight waves on the 80x160 maps measured: 7.1 / 7.4 us against 6.3 / 8.7 for K = 96 / 160 -- a wash, not kept: tools/mbb_check.hip.)
   return p.in.H * p.in.W >= 12800 ? launch_mbb<4, 4>(p, st) : launch_mbb<1, 8>(p, st);
 }
 

@@ -211,12 +211,13 @@ def test_depthwise_pool_kernel(emu, C, k, stride, H, W):
 
 
 @pytest.mark.parametrize("cin,cexp,k,stride,H,W", [(16, 96, 3, 2, 16, 32), (24, 144, 3, 1, 11, 21), (40, 240, 5, 1, 9, 18), (24, 144, 5, 2, 18, 22), (80, 480, 3, 1, 8, 16),
-                                                   (112, 160, 5, 2, 20, 24), (40, 96, 3, 2, 12, 20), (192, 96, 5, 1, 10, 12)])
+                                                   (112, 160, 5, 2, 20, 24), (40, 96, 3, 2, 12, 20), (192, 96, 5, 1, 10, 12), (16, 32, 3, 1, 60, 64), (24, 32, 5, 2, 120, 128)])
 def test_mbconv_front_kernel(emu, cin, cexp, k, stride, H, W):
     """kernels_mbconv.hip: expand 1x1 + SiLU -> depthwise k x k / stride + SiLU -> pool sums in ONE launch (the expanded tensor never leaves
     the CU; the depthwise halo is re-expanded by neighbouring workgroups) against the two torch ops: all four (k, stride) instantiations,
     channel counts padded to 32 (16 -> 32, 24 -> 32, 40 -> 64; 144 -> 160, 240 -> 256), 1 ... 6 K chunks of 32 channels (from two on, two chunks are
-    in flight: every (k, stride) in that form too, odd and even chunk counts), maps that are not a
+    in flight: every (k, stride) in that form too, odd and even chunk counts), both workgroup shapes (eight waves up to 3200 output pixels,
+    four above), maps that are not a
     multiple of the patch, the zero padding of the EXPANDED tensor at the border (expand(0) = SiLU(bias) != 0 there), pad channels exactly 0."""
     rng = np.random.default_rng(cin * 7 + k)
     cinp, cexpp = (cin + 31) // 32 * 32, (cexp + 31) // 32 * 32

@@ -145,6 +145,9 @@ static void run(int cexp, int cout, int sq, int H, int W, bool residual, float w
     }
   const float tz = wide ? time_it([&] { return launch_mbb<4, 4, 0>(pz, 0); }) : time_it([&] { return launch_mbb<1, 8, 0>(pz, 0); });
   const float tzg = wide ? time_it([&] { return launch_mbb<4, 4, 2>(pz, 0); }) : time_it([&] { return launch_mbb<1, 8, 2>(pz, 0); });
+  if (M >= 12800 && M < 32768)   // the three workgroup shapes on the 80x160 maps (the library takes <4, 4>)
+    std::printf("      80x160: <WM 4, 4 waves> %5.1f us | <2, 8> %5.1f | <1, 8> %5.1f\n", time_it([&] { return launch_mbb<4, 4, 0>(pz, 0); }), time_it([&] { return launch_mbb<2, 8, 0>(pz, 0); }),
+                time_it([&] { return launch_mbb<1, 8, 0>(pz, 0); }));
 #define T_(ABL) (wide ? time_it([&] { return launch_mbb<4, 4, ABL>(p, 0); }) : time_it([&] { return launch_mbb<1, 8, ABL>(p, 0); }))
   std::printf("%4d -> %3d  sq %2d  %3dx%-3d res %d ws %4.2f | err %.1e rel %.1e pad %.0e | zsums: err %.1e %5.1f us (noGEMM %5.1f) | here: %5.1f us | noGate %5.1f | noGEMM %5.1f | neither %5.1f | noGEMM: -means %5.1f  -fc1 %5.1f  -fc2 %5.1f  "
               "means only %5.1f  fc1 only %5.1f  fc2 only %5.1f\n", cexp, cout, sq, H, W, (int)residual, wscale, emax, emax / rmax, pad, ezmax, tz, tzg, T_(0), T_(1), T_(2), T_(3), T_(2 + 4), T_(2 + 8), T_(2 + 16),
