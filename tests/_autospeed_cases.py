@@ -39,6 +39,19 @@ def raw_tensor(num_boxes, num_classes, seed, net=640, clusters=40, p_obj=0.12):
     return raw
 
 
+def untie(raw, seed):
+    """Every positive class score made distinct, NaNs removed: the reference's std::sort is not stable, so tensors pinned against the
+    reference's own binary (oracle/pin_autospeed_ref.py, tests/golden/autospeed_ref.npz) must not contain equal confidences."""
+    rng = np.random.default_rng(seed)
+    r = raw.copy()
+    pos = r[4:] > 0.1
+    r[4:][pos] += (rng.permutation(int(pos.sum())).astype(np.float32) + 1) * np.float32(1e-6)
+    r[4:][np.isnan(r[4:])] = 0.0
+    best = r[4:].max(axis=0)
+    assert len(np.unique(best[best > 0.1])) == int((best > 0.1).sum())
+    return r
+
+
 def check(det_got, n_got, raw, conf, iou, geom, orig_w, orig_h, cap=None):
     scale, pad_x, pad_y = geom
     want = autospeed.postprocess(raw, conf, iou, scale, pad_x, pad_y, orig_w, orig_h)
