@@ -81,6 +81,12 @@ int emu_stem(const float* in, int H, int W, const float* w, const float* b, void
   StemParams p{in, H, W, w, b, view(out_hi, out_lo, H / 2, W / 2, 32)};
   return launch_stem(p, nullptr);
 }
+int emu_stem_zero(const float* in, int H, int W, const float* w, const float* b, void* out_hi, void* out_lo, unsigned long long* zero, size_t zero_n) {
+  StemParams p{in, H, W, w, b, view(out_hi, out_lo, H / 2, W / 2, 32)};
+  p.zero = zero;   // the frame's squeeze-excite accumulators, zeroed by this launch (engine.cpp build_backbone)
+  p.zero_n = zero_n;
+  return launch_stem(p, nullptr);
+}
 int emu_dwconv(void* in_hi, void* in_lo, int H, int W, int C, void* out_hi, void* out_lo, int OH, int OW, const float* w, const float* b, int k,
                int stride, unsigned long long* sums, int replicas) {
   DwParams p{view(in_hi, in_lo, H, W, C), view(out_hi, out_lo, OH, OW, C), w, b, k, stride, sums, replicas};

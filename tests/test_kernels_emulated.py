@@ -178,6 +178,13 @@ def test_stem_kernel(emu, split):
     assert emu.emu_stem(ptr(x), H, W, ptr(w27), ptr(b), ptr(hi), ptr(lo)) == 0
     got = hi.astype(np.float32) + (lo.astype(np.float32) if split else 0)
     assert _rel(got.transpose(2, 0, 1), want) <= (2e-6 if split else 2e-3)
+    # the launch that also zeroes the frame's squeeze-excite accumulators (one frame per pass): the whole arena, nothing beyond it, same tensor
+    arena = np.full(5000 + 2, 0xDEADBEEF, dtype=np.uint64)
+    hi2, lo2 = np.zeros_like(hi), (np.zeros_like(hi) if split else None)
+    emu.emu_stem_zero.argtypes = [ct.c_void_p, ct.c_int, ct.c_int] + [ct.c_void_p] * 5 + [ct.c_size_t]
+    assert emu.emu_stem_zero(ptr(x), H, W, ptr(w27), ptr(b), ptr(hi2), ptr(lo2), ptr(arena), 5000) == 0
+    assert not arena[:5000].any() and np.all(arena[5000:] == 0xDEADBEEF)
+    assert np.array_equal(hi2, hi) and (not split or np.array_equal(lo2, lo))
 
 
 @pytest.mark.parametrize("C,k,stride,H,W", [(48, 3, 1, 12, 20), (144, 5, 2, 13, 21), (32, 3, 2, 16, 16), (56, 5, 1, 9, 11)])
