@@ -10,6 +10,7 @@
 #define AUTOSPEED_HIP_STAGES_HPP_
 
 #include <cstring>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -48,8 +49,9 @@ public:
   // letterbox to the detector's input, / 255, planes R, G, B into `buffer` (3 * H * W floats, host); remembers scale_, pad_x_, pad_y_, orig size
   void preprocessAutoSpeed(const cv::Mat & input_image, float * buffer)
   {
-    if (input_image.empty() || input_image.type() != CV_8UC3 ||
-        vp_detect_preprocess(d_, input_image.data, input_image.rows, input_image.cols, static_cast<int>(input_image.step), buffer) != VP_OK)
+    if (input_image.empty() || input_image.type() != CV_8UC3)   // the C call is never made: its last-error text would be a stale one
+      throw std::runtime_error("[hip_stages] preprocess: input image is empty or not CV_8UC3");
+    if (vp_detect_preprocess(d_, input_image.data, input_image.rows, input_image.cols, static_cast<int>(input_image.step), buffer) != VP_OK)
       throw std::runtime_error(std::string("[hip_stages] preprocess: ") + vp_detect_last_error(d_));
   }
   // the tensor the last preprocessAutoSpeed produced, on the device (a runtime that binds device memory skips the host copy)
@@ -59,15 +61,21 @@ public:
     vp_detect_input_device(d_, &p);
     return static_cast<const float *>(p);
   }
-  // raw_output: [num_attrs][num_boxes] fp32 on the host (output_tensors_[0].GetTensorData<float>()); empty vector on failure, as the
-  // reference returns {} when it has no output tensor
+  // raw_output: [num_attrs][num_boxes] fp32 on the host (output_tensors_[0].GetTensorData<float>()).  {} for "no tensor" (null pointer /
+  // no boxes), as the reference returns {} when it has no output tensor; a DEVICE failure (VP_ERR_HIP) throws instead of looking like
+  // "no detections", and a bad argument is logged through lastError() before the empty return
   std::vector<Detection> postProcess(const float * raw_output, int num_attrs, int num_boxes, float conf_thresh, float iou_thresh, bool raw_on_device = false)
   {
-    std::vector<Detection> out(static_cast<size_t>(num_boxes > 0 ? num_boxes : 0));
+    if (raw_output == nullptr || num_boxes <= 0) return {};
+    std::vector<Detection> out(static_cast<size_t>(num_boxes));
     int n = 0;
-    if (vp_detect_postprocess(d_, raw_output, raw_on_device ? 1 : 0, num_attrs, num_boxes, conf_thresh, iou_thresh,
-                              reinterpret_cast<vp_detection *>(out.data()), static_cast<int>(out.size()), &n) != VP_OK)
+    const int rc = vp_detect_postprocess(d_, raw_output, raw_on_device ? 1 : 0, num_attrs, num_boxes, conf_thresh, iou_thresh,
+                                         reinterpret_cast<vp_detection *>(out.data()), static_cast<int>(out.size()), &n);
+    if (rc == VP_ERR_HIP) throw std::runtime_error(std::string("[hip_stages] postProcess: ") + vp_detect_last_error(d_));
+    if (rc != VP_OK) {
+      std::fprintf(stderr, "[hip_stages] postProcess: %s\n", vp_detect_last_error(d_));
       return {};
+    }
     out.resize(static_cast<size_t>(n));
     return out;
   }

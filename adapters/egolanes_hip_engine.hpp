@@ -32,6 +32,7 @@ public:
     if (vp_create(&engine_, VP_EGOLANES, model_path.c_str(), prec, device_id, err, sizeof(err)) != VP_OK)
       throw std::runtime_error(std::string("[hip_engine] ") + err);
     vp_set_input_format(engine_, VP_BGR8, VP_PLANES_RGB);  // resize, BGR->RGB, ImageNet norm: onnxruntime_engine.cpp:72-102
+    vp_set_norm_form(engine_, VP_NORM_OPENCV);             // convertTo(CV_32FC3, 1.0 / 255.0), then (x - MEAN[c]) / STD[c]: :85, :94-100
     vp_input_hw(engine_, &in_h_, &in_w_);
   }
   ~EgoLanesHipEngine() { vp_destroy(engine_); }

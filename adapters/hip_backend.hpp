@@ -92,6 +92,9 @@ public:
     // middleware 'common' convention: BGR8 frame in, B,G,R planes with BGR-ordered constants
     // (onnx_runtime_backend.cpp:47-57); the EgoLanes engines use RGB planes (onnxruntime_engine.cpp:80-100)
     vp_set_input_format(engine_, VP_BGR8, kind == VP_EGOLANES ? VP_PLANES_RGB : VP_PLANES_BGR);
+    // the C++ front-end's own float expression: convertTo(CV_32FC3, 1.0 / 255.0) = q * fl(1/255), then subtract / divide
+    // (onnx_runtime_backend.cpp:45-49, tensorrt_backend.cpp:164-168) -- not torchvision's q / 255
+    vp_set_norm_form(engine_, VP_NORM_OPENCV);
     vp_input_hw(engine_, &in_h_, &in_w_);
   }
   ~HipBackend() override

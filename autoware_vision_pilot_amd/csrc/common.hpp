@@ -39,6 +39,10 @@ struct ConvGemmParams {
   const half_t* w_hi;  // [taps][CoutW][Cin]
   const half_t* w_lo;
   const float* bias;   // [CoutW]
+  // [CoutW] 2^-s of the per-output-row power-of-two PRESCALE the engine folds into the weights at load (w_hi + w_lo = w * 2^s, row maximum in
+  // [2^13, 2^14): neither fp16 plane of a weight is subnormal -- engine_internal.hpp prescale_exp); every epilogue evaluates
+  // fmaf(acc, wscale[co], bias[co]): the product is exact (power of two), so the result is that of un-scaled weights carried exactly
+  const float* wscale;
   int ks;              // 1 or 3 (stride 1, pad ks/2)
   int Ncols;           // GEMM columns to store (multiple of 32): Cout_pad, or 4*Cout_pad for STORE_SHUFFLE2
   int CoutW;           // weight rows allocated (multiple of the CO tile)

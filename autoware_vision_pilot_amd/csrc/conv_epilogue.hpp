@@ -44,14 +44,14 @@ __device__ __forceinline__ uint8_t decode_pixel(const float (&v)[4], int Creal, 
 // STORE / RES / ACT >= 0 fix the mode at compile time; -1 reads it from the parameter block.
 template <int STORE = -1, int RES = -1, int ACT = -1>
 __device__ __forceinline__ void epilogue_store8(const ConvGemmParams& p, int M, int m, int co, float v[8], const f32x4_t& b0,
-                                                const f32x4_t& b1, long long o_pre = -1) {
+                                                const f32x4_t& b1, const f32x4_t& s0, const f32x4_t& s1, long long o_pre = -1) {
   const int act = ACT >= 0 ? ACT : p.act;
   const int res_mode = RES >= 0 ? RES : p.res_mode;
   const int store_mode = STORE >= 0 ? STORE : p.store_mode;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    v[r] = apply_act(v[r] + b0[r], act);
-    v[4 + r] = apply_act(v[4 + r] + b1[r], act);
+    v[r] = apply_act(fmaf(v[r], s0[r], b0[r]), act);   // s = 2^-prescale of the weight row (ConvGemmParams::wscale): exact
+    v[4 + r] = apply_act(fmaf(v[4 + r], s1[r], b1[r]), act);
   }
   if (store_mode == STORE_NCHW_F32) {
 #pragma unroll
@@ -139,6 +139,7 @@ template <int STORE, int RES, int ACT, int PXT, int RPI, int PITCH, class PixMap
 __device__ __forceinline__ void epilogue_rows(const ConvGemmParams& p, const char* stage, int r0, int c8, int co, const PixMap& pix,
                                               int M) {
   const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+  const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p.wscale + co), s1 = *reinterpret_cast<const f32x4_t*>(p.wscale + co + 4);
   if constexpr (STORE == STORE_SHUFFLE2 && std::is_same<PixMap, PixLinear>::value) {
     // Pixel-shuffle store over a linear pixel tile: the two integer divisions (quadrant of the channel, row of the
     // pixel) are done ONCE per thread; the row loop then advances (y, x) and the output offset incrementally.  The
@@ -150,10 +151,10 @@ __device__ __forceinline__ void epilogue_rows(const ConvGemmParams& p, const cha
     const int W2 = 2 * p.W;
     for (int r = r0; r < PXT && m < pix.M; r += RPI) {
       const long long o = ((long long)(2 * y + (q >> 1)) * W2 + (2 * x + (q & 1))) * p.Cstore + c;
-      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
-      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
-      float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-      epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1, o);
+      const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+      const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
+      float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1, s0, s1, o);
       m += RPI;
       x += RPI;
       while (x >= p.W) {
@@ -166,10 +167,10 @@ __device__ __forceinline__ void epilogue_rows(const ConvGemmParams& p, const cha
     for (int r = r0; r < PXT; r += RPI) {
       const int m = pix(r);
       if (m < 0) continue;
-      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
-      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
-      float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-      epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1);
+      const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32);
+      const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(stage + r * PITCH + c8 * 32 + 16);
+      float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+      epilogue_store8<STORE, RES, ACT>(p, M, m, co, v, b0, b1, s0, s1);
     }
   }
 }
@@ -252,9 +253,12 @@ __device__ __forceinline__ void epilogue_regs_fp16(const ConvGemmParams& p, char
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int cl = (i * WCO + wco) * 32 + 4 * (lane >> 5);  // channel (within the CO tile) of register group g=0, r=0
-    f32x4_t b[4];
+    f32x4_t b[4], sc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4_t*>(p.bias + co0 + cl + 8 * g);
+    for (int g = 0; g < 4; ++g) {
+      b[g] = *reinterpret_cast<const f32x4_t*>(p.bias + co0 + cl + 8 * g);
+      sc[g] = *reinterpret_cast<const f32x4_t*>(p.wscale + co0 + cl + 8 * g);
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       char* row = stage + ((wpx * NT + j) * 32 + (lane & 31)) * PITCH + cl * 2;
@@ -269,7 +273,7 @@ __device__ __forceinline__ void epilogue_regs_fp16(const ConvGemmParams& p, char
           } else {
             v = acc[i][j][4 * g + r];
           }
-          h[r] = (half_t)apply_act(v + b[g][r], ACT);
+          h[r] = (half_t)apply_act(fmaf(v, sc[g][r], b[g][r]), ACT);
         }
         *reinterpret_cast<h4_t*>(row + g * 16) = h;
         if constexpr (ACT != ACT_NONE) __builtin_amdgcn_sched_barrier(0);  // keep activation chains from interleaving (VGPR pressure)

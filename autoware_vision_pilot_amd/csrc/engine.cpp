@@ -90,14 +90,38 @@ Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) { return fold_
 // common_layers.py:5-14 Conv: `conv` (no bias) + `norm` (BatchNorm2d eps 1e-3)
 Folded fold_conv_norm(const WeightBlob& blob, const std::string& p) { return fold_conv(blob, p + ".conv", p + ".norm", 1e-3f); }
 
-void split_half(float v, half_t* hi, half_t* lo) {
-  // Both precision modes carry weights on fp16 planes: a folded weight beyond the fp16 range (or non-finite) would load as inf and
-  // every result would silently be garbage.  (Small weights are safe: below 2^-14 the hi plane is subnormal and the lo plane picks up less,
-  // a loss of relative precision on values that contribute nothing at the 1e-3 bar.)
+void split_half(float v, float pre, half_t* hi, half_t* lo) {
+  // Both precision modes carry weights on fp16 planes: a folded weight beyond the fp16 range (or non-finite) is refused at load (the
+  // prescale could carry it, the activations it produces would not survive).  Small weights: see prescale_exp (engine_internal.hpp).
   if (!(std::fabs(v) <= 65504.0f)) throw RangeError("weight " + std::to_string(v) + " is outside the fp16 range the matrix pipe carries (|w| <= 65504): re-scale the checkpoint");
-  const half_t h = (half_t)v;
+  const float x = v * pre;
+  const half_t h = (half_t)x;
   *hi = h;
-  *lo = (half_t)(v - (float)h);
+  *lo = (half_t)(x - (float)h);
+}
+
+int prescale_exp(float amax) {
+  if (!(amax > 0.0f) || !std::isfinite(amax)) return 0;
+  int e = 0;
+  std::frexp(amax, &e);  // amax = m * 2^e, m in [0.5, 1)  =>  amax * 2^(14 - e) in [2^13, 2^14)
+  return std::max(-8, std::min(14 - e, 60));
+}
+
+RowScale row_prescale(const float* w, size_t rows, size_t per, size_t rows_alloc) {
+  RowScale rs;
+  rs.pre.assign(rows, 1.0f);
+  rs.post.assign(std::max(rows, rows_alloc), 1.0f);
+  for (size_t r = 0; r < rows; ++r) {
+    float amax = 0.0f;
+    for (size_t i = 0; i < per; ++i) {
+      const float a = std::fabs(w[r * per + i]);
+      if (a > amax) amax = a;   // NaN compares false: split_half reports it
+    }
+    const int s = prescale_exp(amax);
+    rs.pre[r] = std::ldexp(1.0f, s);
+    rs.post[r] = std::ldexp(1.0f, -s);
+  }
+  return rs;
 }
 
 // ==================================================================================================== Engine
@@ -240,6 +264,12 @@ void* Engine::dalloc(size_t bytes, bool zero) {
   if (zero) VP_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
   return p;
 }
+void Engine::dfree(void* p) {
+  if (!p) return;
+  auto it = std::find(allocs_.begin(), allocs_.end(), p);
+  if (it != allocs_.end()) allocs_.erase(it);
+  hipFree(p);
+}
 const void* Engine::zero_page() {
   if (!d_zero_) d_zero_ = dalloc(256, true);
   return d_zero_;
@@ -341,7 +371,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       const Act* y = x;
       // parity mode, one frame per pass: expand 1x1 -> depthwise (+ pool) as ONE launch, the expanded tensor never leaves the CU
       // (kernels_mbconv.hip).  VP_MBCONV_FUSE=0 (developer knob, A/B timing): the two launches.
-      static const char* env_mb = std::getenv("VP_MBCONV_FUSE");
+      const char* env_mb = dev_option("VP_MBCONV_FUSE");
       const bool fuse_front = S.e != 1 && split() && N == 1 && !(env_mb && env_mb[0] == '0');
       Folded f_exp;
       if (fuse_front) {
@@ -369,7 +399,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       se_used += (size_t)N * se_rep * z->C;
       ++se_block;
       // fused front + fused back: the squeeze FC travels with the pool sums ([se_rep][64] fixed-point numbers, same arena: zeroed per frame)
-      static const char* env_mbb0 = std::getenv("VP_MBCONV_BACK");
+      const char* env_mbb0 = dev_option("VP_MBCONV_BACK");
       unsigned long long* zsums = nullptr;
       if (fuse_front && !(env_mbb0 && env_mbb0[0] == '0')) {
         if (se_used + (size_t)se_rep * 64 > se_words) throw std::runtime_error("SE arena too small");
@@ -398,8 +428,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           if (f_exp.cout != cexp || f_exp.cin != cin || f_exp.k != 1) throw std::runtime_error("expand conv shape mismatch: " + bp);
           std::vector<half_t> wh((size_t)z->C * x->C, (half_t)0.0f), wlo(wh.size(), (half_t)0.0f);
           std::vector<float> be(z->C, 0.0f);
+          const RowScale rs = row_prescale(f_exp.w.data(), cexp, cin, z->C);
           for (int co = 0; co < cexp; ++co) {
-            for (int ci = 0; ci < cin; ++ci) split_half(f_exp.w[(size_t)co * cin + ci], &wh[(size_t)co * x->C + ci], &wlo[(size_t)co * x->C + ci]);
+            for (int ci = 0; ci < cin; ++ci) split_half(f_exp.w[(size_t)co * cin + ci], rs.pre[co], &wh[(size_t)co * x->C + ci], &wlo[(size_t)co * x->C + ci]);
             be[co] = f_exp.b[co];
           }
           MbFrontParams mp{};
@@ -407,6 +438,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           mp.w_hi = dupload(wh);
           mp.w_lo = dupload(wlo);
           mp.b_exp = dupload(be);
+          mp.s_exp = dupload(rs.post);
           mp.w_dw = dupload(wk);
           mp.b_dw = dupload(bk);
           mp.out = z->view();
@@ -451,7 +483,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       // squeeze-excite -> per-frame scaled projection weights
       // parity mode, one frame per pass: squeeze-excite tail + projection (+ residual) as ONE launch (kernels_mbconv.hip, back half).
       // VP_MBCONV_BACK=0 (developer knob, A/B timing): se_gate_scale + the projection GEMM (+ its split-K finish).
-      static const char* env_mbb = std::getenv("VP_MBCONV_BACK");
+      const char* env_mbb = dev_option("VP_MBCONV_BACK");
       const bool fuse_back = split() && N == 1 && !(env_mbb && env_mbb[0] == '0');
       SeParams se{};
       const float *se_w2 = nullptr, *se_b2 = nullptr;
@@ -494,11 +526,12 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         Act* out = new_act(bp + std::to_string(j), S.cout, z->H, z->W);
         out->frames = N;
         std::vector<float> wf((size_t)out->C * z->C, 0.0f), bias(out->C, 0.0f);
+        const RowScale rs = row_prescale(f.w.data(), S.cout, cexp, out->C);   // the gate (0, 1) multiplies on the device: the row maximum only shrinks
         for (int co = 0; co < S.cout; ++co) {
-          for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c];
+          for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c] * rs.pre[co];
           bias[co] = f.b[co];
         }
-        for (float v : wf)
+        for (float v : f.w)
           if (!(std::fabs(v) <= 65504.0f)) throw RangeError("projection weight " + std::to_string(v) + " of " + bp + " is outside the fp16 range the matrix pipe carries (|w| <= 65504): re-scale the checkpoint");
         const int sqp = round_up(sq, 4);
         std::vector<float> w2q((size_t)sqp * z->C, 0.0f);
@@ -514,6 +547,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         mb.sqp = sqp;
         mb.w = dupload(wf);
         mb.bias = dupload(bias);
+        mb.wscale = dupload(rs.post);
         if (residual) mb.res = x->view();
         mb.out = out->view();
         if (!mbconv_back_supported(mb)) throw std::runtime_error("fused MBConv back: unsupported shape: " + bp);
@@ -537,8 +571,9 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         PackedConv pc;
         choose_conv_cfg(HWz, ncols, z->C, 1, o, &pc);  // per frame: every frame has its own gate, hence its own scaled weights
         std::vector<float> wf((size_t)pc.CoutW * z->C, 0.0f), bias(pc.CoutW, 0.0f);
+        const RowScale rs = row_prescale(f.w.data(), S.cout, cexp, pc.CoutW);   // se_gate_scale multiplies by the gate (0, 1) and splits on the device
         for (int co = 0; co < S.cout; ++co) {
-          for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c];
+          for (int c = 0; c < cexp; ++c) wf[(size_t)co * z->C + c] = f.w[(size_t)co * cexp + c] * rs.pre[co];
           bias[co] = f.b[co];
         }
         ScaleWParams sw{};
@@ -562,6 +597,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           ops_.push_back(std::move(op));
         }
         pc.bias = dupload(bias);
+        pc.wscale = dupload(rs.post);
         Act* out = new_act(bp + std::to_string(j), S.cout, z->H, z->W);
         out->frames = N;
         for (int fi = 0; fi < N; ++fi) {
@@ -776,6 +812,7 @@ void Engine::build_model(const WeightBlob& blob) {
         pp.stdv[c] = std_rgb[colour];
       }
       pp.out = d_input_ + (size_t)fi * 3 * net_h() * net_w();
+      pp.norm_form = norm_form_;
       if (resize_mode_ != 0) return launch_pil_resample(pil_params(pp), st);
       return launch_preprocess(pp, st);
     };
@@ -854,6 +891,7 @@ void Engine::build_autodrive(const WeightBlob& blob) {
       pp.stdv[c] = std_rgb[colour];
     }
     pp.out = d_input_;
+    pp.norm_form = norm_form_;
     if (resize_mode_ != 0) return launch_pil_resample(pil_params(pp), st);
     return launch_preprocess(pp, st);
   });
@@ -1109,8 +1147,11 @@ void Engine::finish_plan() {
     probe.name = "finite_probe";
     probe.kernel = "finite_probe";
     probe.bytes = 4.0 * out_c_ * out_h_ * out_w_;
-    probe.run = [this](hipStream_t st) {
-      return finite_check_ ? launch_finite_probe(d_logits_, (size_t)out_c_ * out_h_ * out_w_, d_status_, st) : hipSuccess;
+    probe.run = [this](hipStream_t st) -> hipError_t {
+      if (!finite_check_) return hipSuccess;
+      // per-pass flag: cleared here (a 4-byte memset node in the captured graph), then OR-ed by the scan
+      if (hipError_t e = hipMemsetAsync(d_status_, 0, sizeof(unsigned), st); e != hipSuccess) return e;
+      return launch_finite_probe(d_logits_, (size_t)out_c_ * out_h_ * out_w_, d_status_, st);
     };
     ops_.push_back(std::move(probe));
   }

@@ -95,6 +95,10 @@ class Engine {
   // configuration
   void set_input_format(int pixel_format, int plane_order);
   void set_decode_mode(int mode);
+  // u8 -> [0, 1] ahead of (x - mean) / std: 0 = q / 255 (torchvision to_tensor: the Python operator API), 1 = q * fl(1/255)
+  // (cv::Mat::convertTo(CV_32FC3, 1.0 / 255.0): the C++ front-ends, onnx_runtime_backend.cpp:45, onnxruntime_engine.cpp:85)
+  void set_norm_form(int form);
+  int norm_form() const { return norm_form_; }
   // frame resize ahead of the network: 0 = the integer bilinear modelled on cv::resize INTER_LINEAR (the C++ nodes; default of the scene
   // networks), 1 / 2 = Pillow's antialiased BILINEAR / BICUBIC (the Python scripts' Image.resize; 1 is AutoDrive's default)
   void set_resize_mode(int mode);
@@ -129,6 +133,7 @@ class Engine {
     }
   }
   void check_status();  // throws RangeError if the last fetched pass flagged a non-finite output
+  bool poll_status();   // the same verdict without the throw (vp_infer_multi polls every member, then reports once)
   void copy_outputs_device(void* logits_dst, void* mask_dst);
   void mask_resized(uint8_t* dst, int h, int w);
   void depth_resized(float* dst, int h, int w);
@@ -186,11 +191,15 @@ class Engine {
     half_t* w_hi = nullptr;
     half_t* w_lo = nullptr;
     float* bias = nullptr;
+    float* wscale = nullptr;  // [CoutW] 2^-prescale of the weight rows (engine_internal.hpp prescale_exp)
     int CoutW = 0, tile = 0, bk = 32, nsplit = 1;
   };
   void construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base);
   void release();  // frees every device / host resource; idempotent (destructor and failed construction)
   void* dalloc(size_t bytes, bool zero = true);
+  void dfree(void* p);  // hipFree + forget (buffers that are re-grown at run time; the caller has synchronised the stream)
+  template <class T>
+  void upload_grow(T*& d, size_t& cap_elems, const std::vector<T>& v);  // re-uses d while v fits, else frees it and allocates anew
   const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)
   template <class T>
   T* dupload(const std::vector<T>& v);
@@ -227,7 +236,7 @@ class Engine {
   size_t first_net_op_ = 0;  // ops_[0] is the preprocess op (skipped for vp_infer_tensor)
 
   // input
-  int pixel_format_ = 0, plane_order_ = 0, decode_mode_ = 0;
+  int pixel_format_ = 0, plane_order_ = 0, decode_mode_ = 0, norm_form_ = 0;
   uint8_t* d_frame_ = nullptr;
   size_t frame_cap_ = 0;
   int frame_h_ = 0, frame_w_ = 0, frame_stride_ = 0;
@@ -241,6 +250,7 @@ class Engine {
   int* d_pil_vb_ = nullptr;
   int* d_pil_vk_ = nullptr;
   int pil_hks_ = 0, pil_vks_ = 0;
+  size_t pil_cap_[5] = {0, 0, 0, 0, 0};  // capacities (elements) of hb, hk, vb, vk, tmp
   uint8_t* d_pil_tmp_ = nullptr;
   PilResampleParams pil_params(const PreprocessParams& pp) const;
   bool input_is_tensor_ = false;

@@ -37,7 +37,7 @@ void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOp
     // walking 8-18 dependent staging steps): slices of >= 3 steps up to ~128 workgroups.  Measured (parity mode, per launch incl.
     // the finish kernel): 25 -> 15 us on stages 6 / 7, 20 -> 15 on stage 5, SceneSeg single stream 2.076 -> 2.015 ms.
     // VP_PROJ_SPLIT = minimum steps per slice (0 = never split).
-    const char* e = std::getenv("VP_PROJ_SPLIT");
+    const char* e = dev_option("VP_PROJ_SPLIT");
     const int min_steps = e ? std::atoi(e) : 3;
     if (min_steps > 0 && S >= 2 * min_steps) ns = std::max(1, std::min<int>(S / min_steps, (int)cdiv(128, blocks)));
   }
@@ -60,6 +60,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.w_hi = pc.w_hi;
   p.w_lo = pc.w_lo;
   p.bias = pc.bias;
+  p.wscale = pc.wscale;
   p.ks = ks;
   p.Ncols = ncols;
   p.CoutW = pc.CoutW;
@@ -76,7 +77,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.zeros = static_cast<const half_t*>(zero_page());
   // the head's logits convolution decodes the mask in its epilogue (one launch and a 2.4 MB re-read less per network)
   const bool fuse_decode = store_mode == STORE_NCHW_F32 && o.logits_out == d_logits_ && d_mask_ && cout_real <= 8 && ncols <= 32 && kind_ >= 0 &&
-                           kind_ != 4 && !(std::getenv("VP_FUSE_DECODE") && std::getenv("VP_FUSE_DECODE")[0] == '0');
+                           kind_ != 4 && !(dev_option("VP_FUSE_DECODE") && dev_option("VP_FUSE_DECODE")[0] == '0');
   if (fuse_decode) {
     p.mask_out = d_mask_;
     decode_fused_ = true;
@@ -105,7 +106,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     int ht = tile - 100;
     // ---- optional per-layer tile autotune (VP_AUTOTUNE=1 enables; measured +-1 % on the frames-in-flight bench, so
     // the static heuristic is the default): time the tile shapes that share this weight packing and keep the fastest.  The K order per output is identical for every tile, so the choice never changes a result bit.
-    static const char* at_env = std::getenv("VP_AUTOTUNE");
+    const char* at_env = dev_option("VP_AUTOTUNE");
     const bool explicit_tile = o.tile >= 100;
     if (!explicit_tile && at_env && at_env[0] == '1' && kind_ >= 0) {
       std::vector<int> cand;
@@ -157,7 +158,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     }
     // the heads' logits convolution: weights stationary in registers, 16x16x32 MFMA, LDS-DMA halo (kernels_head.hip); same weight
     // packing as halo tile 4.  VP_HEAD_CONV=0 keeps the halo kernel.
-    if (ht == 4 && o.tile < 0 && head_conv_supported(p) && !(std::getenv("VP_HEAD_CONV") && std::getenv("VP_HEAD_CONV")[0] == '0')) {
+    if (ht == 4 && o.tile < 0 && head_conv_supported(p) && !(dev_option("VP_HEAD_CONV") && dev_option("VP_HEAD_CONV")[0] == '0')) {
       const void* zeros = zero_page();
       op.kernel = std::string("head_conv3x3<c") + std::to_string(p.Cin) + (sp ? ",x3>" : ",x1>") + (fuse_decode ? "+decode" : "");
       op.run = [this, p, zeros, fuse_decode](hipStream_t st) {
@@ -187,7 +188,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
     op.kernel = std::string("gemm_dma<co256,px128,") + (sp ? "x3>" : "x1>") + (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p](hipStream_t st) { return launch_gemm_dma(p, st); };
-  } else if (tile == 5 || (!(std::getenv("VP_CONVT_RS") && std::getenv("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
+  } else if (tile == 5 || (!(dev_option("VP_CONVT_RS") && dev_option("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
     if (!convt_rs_supported(p, sp))
       throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
     op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
@@ -225,7 +226,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   // ---- 3x3: LDS-resident halo kernel (kernels_conv3x3.hip) unless overridden (tile >= 100 selects a halo tile)
   int halo = -1;
   if (ks == 3 && cstride == 1 && in->H >= 8 && in->W >= 16) {
-    static const char* env = std::getenv("VP_CONV3X3");
+    const char* env = dev_option("VP_CONV3X3");
     const bool force_v1 = (env && std::strcmp(env, "v1") == 0) || (o.tile >= 0 && o.tile < 100);
     if (o.tile >= 100) {
       halo = o.tile - 100;
@@ -233,7 +234,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
       const long long t256 = cdiv(in->H, 16) * cdiv(in->W, 16), t128 = cdiv(in->H, 8) * cdiv(in->W, 16);
       if (ncols <= 32) {
-        halo = (std::getenv("VP_HEAD_TILE5") && t256 >= 400) ? 5 : 4;
+        halo = (dev_option("VP_HEAD_TILE5") && t256 >= 400) ? 5 : 4;
       } else if (ncols % 128 != 0) {
         halo = (!split() && t256 * cdiv(ncols, 64) >= 400) ? 2 : 3;
       } else {
@@ -248,7 +249,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     // parity mode, 128-channel tiles: the pipelined kernels of kernels_conv3x3_x3.hip -- halo tile 7 (8x16 patches, two
     // independent workgroups per CU; also the split-K shape of the small-map layers) or 6 (16x16 patches, one 8-wave workgroup)
     {
-      static const char* envx = std::getenv("VP_X3_TILE");  // developer knob: 0 = halo kernel, 6 / 7 = force that shape
+      const char* envx = dev_option("VP_X3_TILE");  // developer knob: 0 = halo kernel, 6 / 7 = force that shape
       auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
       const long long wgs16 = cdiv(in->H, 16) * cdiv(in->W, 16) * (ncols / 128), wgs8 = cdiv(in->H, 8) * cdiv(in->W, 16) * (ncols / 128);
       // measured per layer (profiles/r02_layers_*): the 4-wave shape wins where the K loop is short (Cin <= 128: prologue and
@@ -260,7 +261,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured
         // on MI355X, the 4-wave shape without split-K took 139 vs 100 us on decode_layer_5 (200 patches) and its split-K form
         // (kernel support kept, tile 107 + nsplit) 63 vs 47 / 79 vs 70 us on decode_layer_1 / 3 (profiles/r02_splitk_x3w4.txt)
-        static const char* envw = std::getenv("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
+        const char* envw = dev_option("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
         if (plain && wgs16 >= (envw ? std::atoi(envw) : 160)) halo = want == 6 ? 6 : 7;
         (void)wgs8;
       }
@@ -269,7 +270,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     // of a 20x40 region (kernels_conv3x3_map.hip, halo tile 11): the 8x16 tiles re-stream the weights once per pixel tile and are bound by
     // that traffic.  Any epilogue (it always ends in the finish kernel).  VP_MAP3X3=0 (developer knob, A/B timing): the tiled kernels.
     {
-      static const char* envm = std::getenv("VP_MAP3X3");
+      const char* envm = dev_option("VP_MAP3X3");
       const bool on = !(envm && envm[0] == '0');
       if (o.tile == 111 || (on && split() && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && cin_pad >= 256 &&
                             conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
@@ -301,7 +302,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     if (o.nsplit > 0) {
       ns = o.nsplit;
     } else if (halo == 4 && o.logits_out && cout <= 4 && (cin_pad == 64 || cin_pad == 128) && o.res_mode == RES_NONE && o.act == ACT_NONE &&
-               cstride == 1 && !(std::getenv("VP_HEAD_CONV") && std::getenv("VP_HEAD_CONV")[0] == '0')) {
+               cstride == 1 && !(dev_option("VP_HEAD_CONV") && dev_option("VP_HEAD_CONV")[0] == '0')) {
       ns = 1;  // a head's logits convolution goes to kernels_head.hip (persistent workgroups: needs no split on any map size)
     } else if (blocks < 256 && split()) {
       // parity mode (measured per layer with VP_NSPLIT_FORCE = 1..16, profiles/r02_splitk_sweep_fp16x3.txt): ONE full round of
@@ -317,10 +318,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       while (ns > 2 && ns * slice_mb > 24.0) --ns;
       ns = std::min(ns, std::max(1, KC / 2));
     }
-    if (const char* e = std::getenv("VP_NSPLIT_PCT")) {  // developer knob (split-K sweeps): percentage applied to the heuristic's factor
+    if (const char* e = dev_option("VP_NSPLIT_PCT")) {  // developer knob (split-K sweeps): percentage applied to the heuristic's factor
       if (o.nsplit <= 0 && ns > 1) ns = std::max(1, (int)(ns * std::atoi(e) / 100.0 + 0.5));
     }
-    if (const char* e = std::getenv("VP_NSPLIT_FORCE")) {  // developer knob: one factor for every layer the heuristic splits
+    if (const char* e = dev_option("VP_NSPLIT_FORCE")) {  // developer knob: one factor for every layer the heuristic splits
       if (o.nsplit <= 0 && ns > 1) ns = std::max(1, std::atoi(e));
     }
     pc.nsplit = std::max(1, std::min(ns, KC));
@@ -331,7 +332,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     // 320x640) 108.0 -> 102.2; 389 -> 381 frames/s with it everywhere.  So: only the short-K big-map case (as for tile 7);
     // VP_X3_C64=1 wherever the epilogue fits (plain, or anything behind split-K), =0 nowhere.
     if (halo == 3 && split() && o.tile < 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 && cstride == 1) {
-      const char* e8 = std::getenv("VP_X3_C64");
+      const char* e8 = dev_option("VP_X3_C64");
       const bool plain8 = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
       const bool fits = plain8 || pc.nsplit > 1;
       const bool want8 = e8 ? e8[0] == '1' : (pc.nsplit == 1 && cin_pad <= 128 && M >= 65536);
@@ -345,6 +346,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }
   std::vector<half_t> hi((size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
+  const RowScale rs = row_prescale(w.data(), cout, (size_t)cin * taps, pc.CoutW);
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int t = 0; t < taps; ++t) {
@@ -357,7 +359,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
                          : halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         half_t h, l;
-        split_half(v, &h, &l);
+        split_half(v, rs.pre[co], &h, &l);
         hi[d] = h;
         if (split()) lo[d] = l;
       }
@@ -366,6 +368,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
   pc.bias = dupload(bias);
+  pc.wscale = dupload(rs.post);
   Act* out = nullptr;
   int store = STORE_NHWC;
   if (o.logits_out) {
@@ -383,17 +386,17 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
 // 21.7: the fp16 engines take it from 2048 pixels up only.  VP_GEMM_DMA=1: wherever the shape fits, =0: never.
 bool Engine::gemm_dma_wanted(int H, int W, int ncols, int cin_pad, int cin2_pad, int cstore) const {
   const int M = H * W;
-  const char* e = std::getenv("VP_GEMM_DMA");
+  const char* e = dev_option("VP_GEMM_DMA");
   if (e && e[0] == '0') return false;
   if (!split() && M < 2048 && !(e && e[0] == '1')) return false;
-  const char* rs = std::getenv("VP_CONVT_RS");  // the register-stationary kernel's shapes are its own (and keep the plain weight layout)
+  const char* rs = dev_option("VP_CONVT_RS");  // the register-stationary kernel's shapes are its own (and keep the plain weight layout)
   if (!(rs && rs[0] == '0') && convt_rs_shape_case(H, W, cin_pad, cin2_pad, ncols, cstore) != 0) return false;
   return gemm_dma_shape_ok(M, ncols, cin_pad, cin2_pad, cstore);
 }
 
 // split-K factor of that kernel: towards ~160 workgroups while a slice keeps >= 8 K steps (VP_GEMM_DMA_NSPLIT: developer knob)
 int Engine::gemm_dma_nsplit(int M, int ncols, int kw) const {
-  if (const char* e = std::getenv("VP_GEMM_DMA_NSPLIT")) return std::max(1, std::atoi(e));
+  if (const char* e = dev_option("VP_GEMM_DMA_NSPLIT")) return std::max(1, std::atoi(e));
   const int tiles = ((M + 127) / 128) * (ncols / 256), steps = kw / 32;
   int ns = 1;
   while (tiles * ns < 128 && steps / (ns + 1) >= 8) ++ns;
@@ -421,21 +424,26 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
     oo.tile = 6;
     oo.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad);
   }
-  if (const char* e = std::getenv("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
-  if (const char* e = std::getenv("VP_CONVT_BK")) oo.bk = std::atoi(e);
+  if (const char* e = dev_option("VP_CONVT_TILE")) oo.tile = std::atoi(e);  // developer knobs (tile / BK sweeps)
+  if (const char* e = dev_option("VP_CONVT_BK")) oo.bk = std::atoi(e);
   choose_conv_cfg(in->H * in->W, ncols, cin_pad, 1, oo, &pc);
   if (pc.tile == 6 && !(gemm_dma_shape_ok(in->H * in->W, ncols, cin_pad, 0, cpad) && pc.CoutW == ncols))  // before the weights are packed in its layout
     throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
   std::vector<half_t> hi((size_t)pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
-  std::vector<float> bias(pc.CoutW, 0.0f);
+  std::vector<float> bias(pc.CoutW, 0.0f), post(pc.CoutW, 1.0f);
   for (int q = 0; q < 4; ++q)
     for (int co = 0; co < cout; ++co) {
       const int n = q * cpad + co;
       bias[n] = b[co];
+      float amax = 0.0f;   // prescale per GEMM row n = (quadrant, output channel)
+      for (int ci = 0; ci < cin; ++ci) amax = std::max(amax, std::fabs(w[((size_t)ci * cout + co) * 4 + q]));
+      const int sexp = prescale_exp(amax);
+      const float pre = std::ldexp(1.0f, sexp);
+      post[n] = std::ldexp(1.0f, -sexp);
       for (int ci = 0; ci < cin; ++ci) {
         const float v = w[((size_t)ci * cout + co) * 4 + q];  // [ci][co][dy][dx], q = dy*2+dx
         half_t h, l;
-        split_half(v, &h, &l);
+        split_half(v, pre, &h, &l);
         const size_t d = pc.tile == 6 ? gemm_dma_pack_index(n, ci, cin_pad) : (size_t)n * cin_pad + ci;
         hi[d] = h;
         if (split()) lo[d] = l;
@@ -444,6 +452,7 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
   pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
   pc.bias = dupload(bias);
+  pc.wscale = dupload(post);
   push_conv_op(name, in, pc, 1, ncols, o, out, STORE_SHUFFLE2, cout);
   return out;
 }
@@ -460,7 +469,7 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
   if (wt.size() != (size_t)cin * cout * 4) throw std::runtime_error("convT weight size mismatch: " + up_name);
   if (ws.size() != (size_t)cout * cs) throw std::runtime_error("skip conv weight size mismatch: " + skip_name);
   if (skip_in->H != in->H * 2 || skip_in->W != in->W * 2) throw std::runtime_error("skip tensor size mismatch: " + skip_name);
-  static const char* env = std::getenv("VP_FUSE_SKIP");
+  const char* env = dev_option("VP_FUSE_SKIP");
   const int cpad = round_up(cout, 32);
   const int ncols = 4 * cpad;
   ConvOpts o;
@@ -474,7 +483,7 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
     o.tile = 6;
     o.nsplit = gemm_dma_nsplit(in->H * in->W, ncols, cin_pad + cs_pad);
   }
-  if (const char* e = std::getenv("VP_CONVT_TILE")) o.tile = std::atoi(e);
+  if (const char* e = dev_option("VP_CONVT_TILE")) o.tile = std::atoi(e);
   PackedConv pc;
   choose_conv_cfg(in->H * in->W, ncols, cin_pad + cs_pad, 1, o, &pc);
   if (pc.tile == 6 && !(gemm_dma_shape_ok(in->H * in->W, ncols, cin_pad, cs_pad, cpad) && pc.CoutW == ncols))
@@ -491,24 +500,30 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
   Act* out = new_act(up_name, cout, in->H * 2, in->W * 2);
   const int kw = cin_pad + cs_pad;
   std::vector<half_t> hi((size_t)pc.CoutW * kw, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
-  std::vector<float> bias(pc.CoutW, 0.0f);
+  std::vector<float> bias(pc.CoutW, 0.0f), post(pc.CoutW, 1.0f);
   for (int q = 0; q < 4; ++q)
     for (int co = 0; co < cout; ++co) {
       const int n = q * cpad + co;
       bias[n] = bt[co] + bs[co];
+      float amax = 0.0f;   // prescale per GEMM row over BOTH weight sets of its K axis
+      for (int k = 0; k < cin + cs; ++k) amax = std::max(amax, std::fabs(k < cin ? wt[((size_t)k * cout + co) * 4 + q] : ws[(size_t)co * cs + (k - cin)]));
+      const int sexp = prescale_exp(amax);
+      const float pre = std::ldexp(1.0f, sexp);
+      post[n] = std::ldexp(1.0f, -sexp);
       for (int k = 0; k < cin + cs; ++k) {
         const float v = k < cin ? wt[((size_t)k * cout + co) * 4 + q] : ws[(size_t)co * cs + (k - cin)];
         const size_t col = k < cin ? k : cin_pad + (k - cin);
         half_t h, l;
-        split_half(v, &h, &l);
+        split_half(v, pre, &h, &l);
         const size_t d = pc.tile == 6 ? gemm_dma_pack_index(n, (int)col, kw) : (size_t)n * kw + col;
         hi[d] = h;
         if (split()) lo[d] = l;
       }
     }
-  pc.w_hi = dupload(hi);
+ pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
   pc.bias = dupload(bias);
+  pc.wscale = dupload(post);
   push_conv_op(up_name + "+" + skip_name.substr(skip_name.rfind('.') == std::string::npos ? 0 : skip_name.rfind('.') + 1), in, pc, 1, ncols, o,
                out, STORE_SHUFFLE2, cout);
   return out;

@@ -24,13 +24,37 @@ struct Folded {
 Folded fold_conv(const WeightBlob& blob, const std::string& conv, const std::string& norm, float eps);
 Folded fold_conv_bn(const WeightBlob& blob, const std::string& p);    // torchvision Conv2dNormActivation: `.0` conv, `.1` norm
 Folded fold_conv_norm(const WeightBlob& blob, const std::string& p);  // common_layers.py:5-14 Conv: `.conv`, `.norm`
-void split_half(float v, half_t* hi, half_t* lo);                     // throws RangeError beyond the fp16 range
+// (hi, lo) fp16 planes of v * pre, pre = the weight row's power-of-two prescale (an exact product); throws RangeError when v itself is
+// beyond the fp16 range or not finite
+void split_half(float v, float pre, half_t* hi, half_t* lo);
+// Per-output-row power-of-two PRESCALE of a weight matrix (round 4).  Unscaled, lo = fp16(w - fp16(w)) of a typical decoder weight is an fp16
+// SUBNORMAL (kaiming std 0.013 at K = 11520: |lo| <= 4e-6, spacing 6e-8) and the pair carries ~17 bits instead of 22.  With s such that the
+// row maximum lands in [2^13, 2^14) every weight within 2^-10 of the row maximum keeps both planes normal, and any smaller one is still exact
+// to 2^-25 absolute = 2^-38 of the row maximum; the kernels' epilogues multiply the fp32 accumulator by 2^-s (ConvGemmParams::wscale) before
+// the bias, which is exact.  Returns s (0 for an all-zero row), clamped so that 2^s and 2^-s are normal floats.
+int prescale_exp(float amax);
+struct RowScale {
+  std::vector<float> pre;    // [rows] 2^s
+  std::vector<float> post;   // [rows_alloc] 2^-s, 1 in the padding
+};
+// rows x per (contiguous rows) -> scales; rows_alloc >= rows entries in `post`
+RowScale row_prescale(const float* w, size_t rows, size_t per, size_t rows_alloc);
 
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
   VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return d;
+}
+
+template <class T>
+void Engine::upload_grow(T*& d, size_t& cap_elems, const std::vector<T>& v) {
+  if (v.size() > cap_elems) {
+    dfree(d);
+    d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
+    cap_elems = v.size();
+  }
+  VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
 }
 
 }  // namespace vp

@@ -11,6 +11,12 @@ void Engine::set_input_format(int pixel_format, int plane_order) {
   pixel_format_ = pixel_format;
   plane_order_ = plane_order;
 }
+void Engine::set_norm_form(int form) {
+  if (form < 0 || form > 1) throw std::invalid_argument("norm form: 0 = q / 255 (torchvision to_tensor), 1 = q * fl(1/255) (cv::Mat::convertTo)");
+  if (base_) throw std::invalid_argument("shared engine: the base engine owns the frame path");
+  if (form != norm_form_) { graph_valid_ = false; ++plan_epoch_; }
+  norm_form_ = form;
+}
 void Engine::set_decode_mode(int mode) {
   if (mode < 0 || mode > 2) throw std::invalid_argument("bad decode mode");
   if (mode != decode_mode_) { graph_valid_ = false; ++plan_epoch_; }
@@ -106,6 +112,7 @@ PilResampleParams Engine::pil_params(const PreprocessParams& pp) const {
     q.stdv[c] = pp.stdv[c];
   }
   q.out = pp.out;
+  q.norm_form = pp.norm_form;
   return q;
 }
 
@@ -127,11 +134,18 @@ void Engine::ensure_tables(int h, int w) {
     pil_hks_ = pil_coeffs(w, net_w(), resize_mode_, &hb, &hk);
     pil_vks_ = pil_coeffs(h, net_h(), resize_mode_, &vb, &vk);
     VP_HIP_CHECK(hipStreamSynchronize(stream_));
-    d_pil_hb_ = dupload(hb);
-    d_pil_hk_ = dupload(hk);
-    d_pil_vb_ = dupload(vb);
-    d_pil_vk_ = dupload(vk);
-    d_pil_tmp_ = static_cast<uint8_t*>(dalloc((size_t)h * net_w() * 3, false));
+    // capacity-tracked: a host alternating between frame geometries re-uses (or re-grows and FREES) these five buffers instead of
+    // leaking a set per change
+    upload_grow(d_pil_hb_, pil_cap_[0], hb);
+    upload_grow(d_pil_hk_, pil_cap_[1], hk);
+    upload_grow(d_pil_vb_, pil_cap_[2], vb);
+    upload_grow(d_pil_vk_, pil_cap_[3], vk);
+    const size_t tmp_need = (size_t)h * net_w() * 3;
+    if (tmp_need > pil_cap_[4]) {
+      dfree(d_pil_tmp_);
+      d_pil_tmp_ = static_cast<uint8_t*>(dalloc(tmp_need, false));
+      pil_cap_[4] = tmp_need;
+    }
     tab_h_ = h;
     tab_w_ = w;
     return;
@@ -160,6 +174,7 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int in
     throw std::invalid_argument("batched encoder: all frames of a pass share one geometry (upload slot 0 first to change it)");
   if (need * frames_ > frame_cap_) {
     VP_HIP_CHECK(hipStreamSynchronize(stream_));
+    dfree(d_frame_);
     d_frame_ = static_cast<uint8_t*>(dalloc(need * frames_, true));
     frame_cap_ = need * frames_;
     { graph_valid_ = false; ++plan_epoch_; }
@@ -350,16 +365,20 @@ void Engine::sync() {
   check_status();
 }
 
-// The probe's verdict on the pass whose outputs were last fetched (enqueue_fetch copies the flag behind them).  Loud, once: the flag is
-// cleared so that the next frame is judged on its own.
-void Engine::check_status() {
-  if (!status_pending_ || !h_status_) return;
+// The probe's verdict on the pass whose outputs were last fetched (enqueue_fetch copies the flag behind them).  The flag is PER PASS: the
+// probe op clears it before it scans (engine.cpp finish_plan), so a bad frame is reported once, by the call that fetches THAT frame, and a
+// pass that was enqueued but never fetched leaves nothing behind for a later frame.
+bool Engine::poll_status() {
+  if (!status_pending_ || !h_status_) return false;
   status_pending_ = false;
-  if (*h_status_ == 0) return;
+  const bool bad = *h_status_ != 0;
   *h_status_ = 0;
-  VP_HIP_CHECK(hipMemsetAsync(d_status_, 0, sizeof(unsigned), stream_));
-  throw RangeError("non-finite value (inf / NaN) in the network output: an activation left the fp16 range of the matrix pipe (|x| > 65504) "
-                   "or the input / weights were not finite; outputs of this frame are invalid");
+  return bad;
+}
+void Engine::check_status() {
+  if (poll_status())
+    throw RangeError("non-finite value (inf / NaN) in the network output: an activation left the fp16 range of the matrix pipe (|x| > 65504) "
+                     "or the input / weights were not finite; outputs of this frame are invalid");
 }
 
 void Engine::fetch_outputs() {
@@ -446,10 +465,12 @@ void Engine::mask_resized(uint8_t* dst, int h, int w) {
   if (!dst || h < 1 || w < 1) throw std::invalid_argument("bad resize target");
   const size_t need = (size_t)h * w, tabn = (size_t)(h + w);
   if (need > resize_cap_) {
+    dfree(d_resize_out_);   // only this family of calls uses it, and each returns synchronised
     d_resize_out_ = dalloc(std::max(need, (size_t)4 * h * w), false);
     resize_cap_ = std::max(need, (size_t)4 * h * w);
   }
   if (tabn * 4 > rs_tab_cap_) {
+    dfree(d_rs_tab_);
     d_rs_tab_ = static_cast<int*>(dalloc(tabn * 4 * sizeof(int), false));
     rs_tab_cap_ = tabn * 4;
   }
@@ -487,10 +508,12 @@ void Engine::visualize_mask(int viz_type, uint8_t* dst, int dst_h, int dst_w) {
   }
   const size_t need = (size_t)3 * h * w, tabn = (size_t)(h + w);
   if (need > resize_cap_) {
+    dfree(d_resize_out_);   // only this family of calls uses it, and each returns synchronised
     d_resize_out_ = dalloc(std::max(need, (size_t)4 * h * w), false);
     resize_cap_ = std::max(need, (size_t)4 * h * w);
   }
   if (tabn * 4 > rs_tab_cap_) {
+    dfree(d_rs_tab_);
     d_rs_tab_ = static_cast<int*>(dalloc(tabn * 4 * sizeof(int), false));
     rs_tab_cap_ = tabn * 4;
   }
@@ -507,10 +530,12 @@ void Engine::visualize_mask(int viz_type, uint8_t* dst, int dst_h, int dst_w) {
 void Engine::resize_depth_on_device(int h, int w) {
   const size_t need = (size_t)4 * h * w, tabn = (size_t)4 * (h + w);
   if (need > resize_cap_) {
+    dfree(d_resize_out_);   // only this family of calls uses it, and each returns synchronised
     d_resize_out_ = dalloc(need, false);
     resize_cap_ = need;
   }
   if (tabn > rs_tab_cap_) {
+    dfree(d_rs_tab_);
     d_rs_tab_ = static_cast<int*>(dalloc(tabn * sizeof(int), false));
     rs_tab_cap_ = tabn;
   }
@@ -552,6 +577,7 @@ void Engine::visualize_depth(uint8_t* dst, int h, int w) {
   }
   const size_t n = (size_t)h * w;
   if (3 * n > depth_viz_cap_) {
+    dfree(d_depth_viz_);
     d_depth_viz_ = dalloc(3 * n, false);
     depth_viz_cap_ = 3 * n;
   }

@@ -4,6 +4,9 @@
 
 namespace vp {
 
+// developer option set through vp_set_option (options.cpp), or nullptr -- the library never reads the environment
+const char* dev_option(const char* key);
+
 struct PreprocessParams {
   const uint8_t* frame;  // device, HxWx3
   int stride;            // bytes per row
@@ -13,6 +16,7 @@ struct PreprocessParams {
   int src_c[3];          // source byte index feeding output plane 0,1,2
   float mean[3], stdv[3];
   float* out;            // [3][out_h][out_w]
+  int norm_form;         // 0: q / 255 (torchvision to_tensor), 1: q * fl(1/255) (cv::Mat::convertTo) -- kernels_misc.hip unit_from_u8
 };
 
 // Pillow's antialiased resample (PIL.Image.resize with BILINEAR / BICUBIC; src/libImaging/Resample.c 8bpc path) + /255 + (x-mean)/std +
@@ -33,6 +37,7 @@ struct PilResampleParams {
   int src_c[3];
   float mean[3], stdv[3];
   float* out;            // [3][out_h][out_w]
+  int norm_form;         // as PreprocessParams
 };
 
 struct StemParams {
@@ -64,6 +69,7 @@ struct MbFrontParams {
   const half_t* w_hi;   // expand weights [Cexp_pad][Cin_pad], BN folded, (hi, lo); zero rows / columns in the padding
   const half_t* w_lo;
   const float* b_exp;   // [Cexp_pad]
+  const float* s_exp;   // [Cexp_pad] 2^-prescale of the expand weight rows (see ConvGemmParams::wscale)
   const float* w_dw;    // [k*k][Cexp_pad] fp32, BN folded
   const float* b_dw;    // [Cexp_pad]
   ActView out;          // H/stride x W/stride x Cexp_pad, (hi, lo)
@@ -113,8 +119,9 @@ struct MbBackParams {
   const float* w2q;    // excite FC as [sqp / 4][C][4]: w2q[(q * C + c) * 4 + i] = fc2.weight[c][4 q + i], zero beyond sq
   const float* b2;     // [C]
   int sqp;             // sq rounded up to a multiple of 4
-  const float* w;      // [out.C][C] fp32 projection weights (BN folded), zero rows / columns in the padding
+  const float* w;      // [out.C][C] fp32 projection weights (BN folded) TIMES the row's power-of-two prescale, zero rows / columns in the padding
   const float* bias;   // [out.C]
+  const float* wscale; // [out.C] 2^-prescale (see ConvGemmParams::wscale)
   ActView res;         // residual (the block's input, same geometry as out) or hi == nullptr
   ActView out;         // H x W x Cout_pad (hi, lo)
 };

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams
     }
   }
   const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
-  epilogue_store8(p, M, m, co, v, b0, b1);
+  const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p.wscale + co), s1 = *reinterpret_cast<const f32x4_t*>(p.wscale + co + 4);
+  epilogue_store8(p, M, m, co, v, b0, b1, s0, s1);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

@@ -350,9 +350,12 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int cl = (i * WCO + wco) * 32 + 4 * (lane >> 5);
-    f32x4_t b[4];
+    f32x4_t b[4], sc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) b[g] = *reinterpret_cast<const f32x4_t*>(p.bias + co0 + cl + 8 * g);
+    for (int g = 0; g < 4; ++g) {
+      b[g] = *reinterpret_cast<const f32x4_t*>(p.bias + co0 + cl + 8 * g);
+      sc[g] = *reinterpret_cast<const f32x4_t*>(p.wscale + co0 + cl + 8 * g);  // 2^-prescale of the weight rows: exact product
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       char* row = smem + ((wpx * NT + j) * 32 + (lane & 31)) * PITCH + cl * 2;
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
         h4_t h, l;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float x = apply_act(acc[i][j][4 * g + r] + b[g][r], ACT);
+          const float x = apply_act(fmaf(acc[i][j][4 * g + r], sc[g][r], b[g][r]), ACT);
           h[r] = (half_t)x;
           l[r] = (half_t)(x - (float)h[r]);
         }

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void convt_rs_kernel(const ConvGemmParams p
   const int pc = lane % CPR, r0 = lane / CPR;
   const int co = n0 + pc * 8;
   const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.bias + co), b1 = *reinterpret_cast<const f32x4_t*>(p.bias + co + 4);
+  const f32x4_t ws0 = *reinterpret_cast<const f32x4_t*>(p.wscale + co), ws1 = *reinterpret_cast<const f32x4_t*>(p.wscale + co + 4);
   char* const mypatch = patches + wave * PATCH_BYTES;
   char* const pw = mypatch + (lane & 31) * PP + (16 * NT * (lane >> 5)) * 4;  // + 64 T + 16 g
   const char* const pr = mypatch + r0 * PP + pc * 32;                          // + pass * RPP * PP
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void convt_rs_kernel(const ConvGemmParams p
         const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(pr + pass * RPP * PP);
         const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(pr + pass * RPP * PP + 16);
         float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        epilogue_store8<STORE_SHUFFLE2, RES_NONE, ACT_NONE>(p, M, m0 + r0 + pass * RPP, co, v, b0, b1, o0 + (long long)2 * pass * RPP * p.Cstore);
+        epilogue_store8<STORE_SHUFFLE2, RES_NONE, ACT_NONE>(p, M, m0 + r0 + pass * RPP, co, v, b0, b1, ws0, ws1, o0 + (long long)2 * pass * RPP * p.Cstore);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -204,7 +205,7 @@ hipError_t launch_rs_cfg(const ConvGemmParams& p, hipStream_t st) {
   const int n_tiles = (p.H * p.W) >> 5, slices = p.Ncols / (256 * NT);
   // persistent, one workgroup per CU: the pixel tiles are dealt round-robin to 256 / slices groups
   int groups = std::max(1, std::min(n_tiles, 256 / slices));
-  if (const char* e = std::getenv("VP_CONVT_RS_GROUPS")) groups = std::max(1, std::min(groups, std::atoi(e)));  // developer / test knob: more tiles per workgroup
+  if (const char* e = dev_option("VP_CONVT_RS_GROUPS")) groups = std::max(1, std::min(groups, std::atoi(e)));  // developer / test knob: more tiles per workgroup
   hipLaunchKernelGGL(k, dim3(slices * groups), dim3(512), lds, st, p, groups);
   return hipGetLastError();
 }

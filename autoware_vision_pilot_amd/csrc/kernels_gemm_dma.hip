@@ -219,18 +219,20 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
   // previous pass's stores
   {
     const float* bsrc = p.bias + co0 + wco * 64 + 32 * (lane >> 5);
+    const float* ssrc = p.wscale + co0 + wco * 64 + 32 * (lane >> 5);  // 2^-prescale of the weight rows (exact product)
 #pragma unroll
     for (int T = 0; T < MT; ++T)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bsrc + 16 * T + 4 * g);
+        const f32x4_t sv = *reinterpret_cast<const f32x4_t*>(ssrc + 16 * T + 4 * g);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[T][j][4 * g + r] += bv[r];
+          for (int r = 0; r < 4; ++r) acc[T][j][4 * g + r] = fmaf(acc[T][j][4 * g + r], sv[r], bv[r]);
       }
   }
-  const f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+  const f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, one4 = {1.f, 1.f, 1.f, 1.f};
   // pixel-shuffle address: quadrant / channel of this lane's piece are fixed, (y, x) of its first row divided ONCE, then advanced
   // by 8 pixels per pass (two integer divisions per 16-byte store were ~110 VALU instructions each)
   const int cq = co - quad * p.Cstore, W2 = 2 * p.W;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(const ConvGemmParams p
       const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(pr + pass * 8 * PP);
       const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(pr + pass * 8 * PP + 16);
       float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-      if (em < M) epilogue_store8<STORE_SHUFFLE2, RES_NONE, ACT_NONE>(p, M, em, co, v, b0, b1, ((long long)(2 * ey + qdy) * W2 + (2 * ex + qdx)) * p.Cstore + cq);
+      if (em < M) epilogue_store8<STORE_SHUFFLE2, RES_NONE, ACT_NONE>(p, M, em, co, v, b0, b1, one4, one4, ((long long)(2 * ey + qdy) * W2 + (2 * ex + qdx)) * p.Cstore + cq);
       em += 8;
       ex += 8;
       while (ex >= p.W) {

@@ -89,9 +89,12 @@ __global__ __launch_bounds__(256, 2) void head_conv3x3_kernel(const ConvGemmPara
       if constexpr (SPLIT) al[c] = real ? *reinterpret_cast<const h8_t*>(p.w_lo + o) : z8;
     }
   }
-  float bias4[4];
+  float bias4[4], ws4[4];   // ws4: 2^-prescale of the weight rows (ConvGemmParams::wscale), exact product
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bias4[r] = r < p.Creal ? p.bias[r] : 0.0f;
+  for (int r = 0; r < 4; ++r) {
+    bias4[r] = r < p.Creal ? p.bias[r] : 0.0f;
+    ws4[r] = r < p.Creal ? p.wscale[r] : 1.0f;
+  }
   const int b_lane = n * PITCH + (slab * 8 + kg) * 16;            // + ((row + dy) * HWD + dx) * PITCH + half * 64
 
   for (; t < n_tiles; t += gridDim.x) {
@@ -152,10 +155,10 @@ __global__ __launch_bounds__(256, 2) void head_conv3x3_kernel(const ConvGemmPara
         if constexpr (KS == 2) {
           const f32x4_t s = *reinterpret_cast<const f32x4_t*>(red + (row * 16 + n) * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (v[g][r] + s[r]) + bias4[r];
+          for (int r = 0; r < 4; ++r) o[r] = fmaf(v[g][r] + s[r], ws4[r], bias4[r]);
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = v[g][r] + bias4[r];
+          for (int r = 0; r < 4; ++r) o[r] = fmaf(v[g][r], ws4[r], bias4[r]);
         }
         const int m = y * p.W + x;
 #pragma unroll

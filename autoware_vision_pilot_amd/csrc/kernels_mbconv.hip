@@ -168,9 +168,12 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
 
   // ---- 2: bias + SiLU, zero outside the image, fp32 tile -> LDS (over the staging buffers)
   {
-    f32x4_t be[4];
+    f32x4_t be[4], se4[4];   // se4: 2^-prescale of the expand weight rows (MbFrontParams::s_exp), exact product
 #pragma unroll
-    for (int g = 0; g < 4; ++g) be[g] = *reinterpret_cast<const f32x4_t*>(p.b_exp + c0 + 8 * g + 4 * (lane >> 5));
+    for (int g = 0; g < 4; ++g) {
+      be[g] = *reinterpret_cast<const f32x4_t*>(p.b_exp + c0 + 8 * g + 4 * (lane >> 5));
+      se4[g] = *reinterpret_cast<const f32x4_t*>(p.s_exp + c0 + 8 * g + 4 * (lane >> 5));
+    }
 #pragma unroll
     for (int j = 0; j < NFW; ++j) {
       const int f = wave + NW * j;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
         for (int g = 0; g < 4; ++g) {
           f32x4_t v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = in_img ? ((ABL & 8) ? acc[j][4 * g + r] + be[g][r] : silu_mb(acc[j][4 * g + r] + be[g][r])) : 0.0f;
+          for (int r = 0; r < 4; ++r) v[r] = in_img ? ((ABL & 8) ? fmaf(acc[j][4 * g + r], se4[g][r], be[g][r]) : silu_mb(fmaf(acc[j][4 * g + r], se4[g][r], be[g][r]))) : 0.0f;
           *reinterpret_cast<f32x4_t*>(es + hp * EP + (8 * g + 4 * (lane >> 5)) * 4) = v;
         }
       }
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
 }
 
 bool mbconv_front_supported(const MbFrontParams& p) {
-  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.w_dw && p.b_dw && (p.sums || (p.w1 && p.zsums)) && (p.k == 3 || p.k == 5) &&
+  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.s_exp && p.w_dw && p.b_dw && (p.sums || (p.w1 && p.zsums)) && (p.k == 3 || p.k == 5) &&
          (p.stride == 1 || p.stride == 2) && (!p.w1 || (p.zsums && p.sq >= 1 && p.sq <= 64)) && (p.in.C & 31) == 0 && (p.out.C & 31) == 0 && p.replicas >= 1 && (p.replicas & (p.replicas - 1)) == 0 &&
          p.out.H == p.in.H / p.stride && p.out.W == p.in.W / p.stride && p.in.H % p.stride == 0 && p.in.W % p.stride == 0;
 }
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
     }
   }
   const f32x4_t bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + ec);
+  const f32x4_t ws4 = *reinterpret_cast<const f32x4_t*>(p.wscale + ec);   // 2^-prescale of the projection rows: exact product
 
   // ---- gate: means, squeeze FC (shared with se_gate_scale_kernel), excite FC + sigmoid for ALL channels
   if constexpr (ABL & 1) {
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
     h4_t o_hi, o_lo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float y = v[r] + bias4[r];
+      float y = fmaf(v[r], ws4[r], bias4[r]);
       if (p.res.hi) y += (float)r_hi[t][r] + (float)r_lo[t][r];
       o_hi[r] = (half_t)y;
       o_lo[r] = (half_t)(y - (float)o_hi[r]);
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
 
 bool mbconv_back_supported(const MbBackParams& p) {
   const SeParams& se = p.se;
-  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && se.sums && se.w1 && se.b1 && p.w2q && p.b2 && p.w && p.bias && se.frames <= 1 &&
+  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && se.sums && se.w1 && se.b1 && p.w2q && p.b2 && p.w && p.bias && p.wscale && se.frames <= 1 &&
          se.C == p.in.C && (se.C & 31) == 0 && se.C >= 32 && (p.out.C & 31) == 0 && se.sq >= 1 && se.sq <= 64 && p.sqp >= se.sq && (p.sqp & 3) == 0 && p.sqp <= 64 &&
          se.replicas >= 1 && p.out.H == p.in.H && p.out.W == p.in.W && p.in.H * p.in.W >= 1 &&
          (!p.res.hi || (p.res.lo && p.res.C == p.out.C && p.res.H == p.out.H && p.res.W == p.out.W));

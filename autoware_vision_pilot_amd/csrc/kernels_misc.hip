@@ -8,6 +8,15 @@ namespace vp {
 // Integer bilinear (definition: oracle/pre_post.py resize_bilinear_u8; modelled on cv::resize INTER_LINEAR,
 // onnx_runtime_backend.cpp:44) + /255 + (x-mean)/std + HWC->CHW (onnx_runtime_backend.cpp:45-57,
 // onnxruntime_engine.cpp:72-102).  Tap tables are built on the host so the device does integer math only.
+// The u8 -> [0, 1] step exists in two spellings that differ in the last bit for 322 of the 768 (byte, channel) pairs:
+//   norm_form 0  q / 255            torchvision to_tensor (Models/inference/scene_seg_infer.py:15-20): one IEEE division
+//   norm_form 1  q * fl(1 / 255)    cv::Mat::convertTo(CV_32FC3, 1.0 / 255.0) of the C++ front-ends (onnx_runtime_backend.cpp:45,
+//                                   tensorrt_backend.cpp:164, onnxruntime_engine.cpp:85): the scale is rounded to float once, then multiplied
+// followed in both by the float subtraction and the IEEE float division the sources spell out (cv::subtract / cv::divide by a Scalar
+// converted to float, :48-49; the scalar loop (x - MEAN[c]) / STD[c], onnxruntime_engine.cpp:98).
+__device__ __forceinline__ float unit_from_u8(int q, int norm_form) {
+  return norm_form ? __fmul_rn((float)q, (float)(1.0 / 255.0)) : __fdiv_rn((float)q, 255.0f);
+}
 __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams p) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= p.out_w) return;
@@ -22,7 +31,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreprocessParams 
     const int s1 = (int)r1[xt.x * 3 + sc] * xt.z + (int)r1[xt.y * 3 + sc] * xt.w;
     int q = (((yt.z * (s0 >> 4)) >> 16) + ((yt.w * (s1 >> 4)) >> 16) + 2) >> 2;
     q = min(max(q, 0), 255);
-    const float t = __fdiv_rn((float)q, 255.0f);
+    const float t = unit_from_u8(q, p.norm_form);
     p.out[((size_t)c * p.out_h + y) * p.out_w + x] = __fdiv_rn(__fsub_rn(t, p.mean[c]), p.stdv[c]);
   }
 }
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256) void pil_resample_v_kernel(const PilResamplePa
   for (int c = 0; c < 3; ++c) {
     const int sc = p.src_c[c];
     const int q = pil_clip8(sc == 0 ? a[0] : (sc == 1 ? a[1] : a[2]));
-    const float t = __fdiv_rn((float)q, 255.0f);   // torchvision to_tensor: u8 -> fp32 / 255
+    const float t = unit_from_u8(q, p.norm_form);   // default 0: torchvision to_tensor, u8 -> fp32 / 255
     p.out[((size_t)c * p.out_h + y) * p.out_w + x] = __fdiv_rn(__fsub_rn(t, p.mean[c]), p.stdv[c]);
   }
 }

@@ -5,6 +5,7 @@
 #include <fstream>
 
 #include "vp_handle.hpp"
+#include "engine_internal.hpp"
 
 namespace {
 
@@ -130,7 +131,6 @@ int vp_decode_logits_host(int gpu_id, const float* logits_nchw, int channels, in
   return rc;
 }
 
-const char* vp_version(void) { return "libvp_hip 0.1 (gfx950)"; }
 
 int vp_create_from_memory(vp_engine** out, int model_kind, const void* blob, size_t blob_bytes, int precision, int gpu_id, char* err,
                           size_t err_len) {
@@ -269,6 +269,10 @@ int vp_resample_coeffs(int in_size, int out_size, int resize_mode, int* bounds, 
   std::copy(k.begin(), k.end(), coeffs);
   return ksize;
 }
+int vp_set_norm_form(vp_engine* e, int form) {
+  return guarded(e, [&](vp::Engine& g) { g.set_norm_form(form); });
+}
+int vp_get_norm_form(const vp_engine* e) { return (e && e->impl) ? e->impl->norm_form() : VP_ERR_ARG; }
 int vp_get_resize_mode(const vp_engine* e) { return (e && e->impl) ? e->impl->resize_mode() : VP_ERR_ARG; }
 int vp_device_count(void) {
   int n = 0;
@@ -322,8 +326,14 @@ int vp_infer_multi(vp_engine* base, vp_engine* const* shared, int n_shared, cons
     g.enqueue_multi(heads);
     g.enqueue_fetch();
     for (int i = 0; i < n_shared; ++i) shared[i]->impl->enqueue_fetch();
-    g.sync();
-    for (int i = 0; i < n_shared; ++i) shared[i]->impl->check_status();
+    // one synchronisation, then EVERY member's verdict is collected (and thereby consumed) before anything is thrown: a bad frame is
+    // reported once, and no member keeps a stale flag for the next frame
+    VP_HIP_CHECK(hipStreamSynchronize(g.stream()));
+    bool bad = g.poll_status();
+    for (int i = 0; i < n_shared; ++i) bad = shared[i]->impl->poll_status() || bad;
+    if (bad)
+      throw vp::RangeError("non-finite value (inf / NaN) in a network output of this frame: an activation left the fp16 range of the matrix pipe "
+                           "(|x| > 65504) or the input / weights were not finite; outputs of this frame are invalid");
   });
 }
 int vp_enqueue_multi(vp_engine* base, vp_engine* const* shared, int n_shared) {
@@ -448,6 +458,43 @@ int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, d
 int vp_layer_kernel(const vp_engine* e, int i, const char** kernel) {
   if (!e || !e->impl || !kernel || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
   *kernel = e->impl->ops()[i].kernel.c_str();
+  return VP_OK;
+}
+// FNV-1a over (launch name, kernel tag) of every launch of the plan: two engines with equal hashes run the same kernels in the same order
+unsigned long long vp_plan_hash(const vp_engine* e) {
+  if (!e || !e->impl) return 0;
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](const std::string& t) {
+    for (unsigned char c : t) {
+      h ^= c;
+      h *= 1099511628211ull;
+    }
+    h ^= 0xffu;
+    h *= 1099511628211ull;
+  };
+  for (const vp::Op& op : e->impl->ops()) {
+    mix(op.name);
+    mix(op.kernel);
+  }
+  return h ? h : 1;
+}
+// host only: the (hi, lo) fp16 planes and the per-row 2^-s the engine makes of a weight matrix (engine.cpp row_prescale + split_half)
+int vp_split_weight_rows(const float* w, int rows, int per_row, uint16_t* hi, uint16_t* lo, float* post_scale) {
+  if (!w || rows < 1 || per_row < 1 || !hi || !lo || !post_scale) return VP_ERR_ARG;
+  try {
+    const vp::RowScale rs = vp::row_prescale(w, (size_t)rows, (size_t)per_row, (size_t)rows);
+    for (int r = 0; r < rows; ++r) {
+      post_scale[r] = rs.post[r];
+      for (int i = 0; i < per_row; ++i) {
+        vp::half_t h, l;
+        vp::split_half(w[(size_t)r * per_row + i], rs.pre[r], &h, &l);
+        std::memcpy(hi + (size_t)r * per_row + i, &h, 2);
+        std::memcpy(lo + (size_t)r * per_row + i, &l, 2);
+      }
+    }
+  } catch (const vp::RangeError&) {
+    return VP_ERR_RANGE;
+  }
   return VP_OK;
 }
 int vp_copy_outputs_device(vp_engine* e, void* logits_dst, void* mask_dst) {

@@ -79,6 +79,7 @@ struct vp_comm {
   void* h_gather = nullptr;   // pinned host copy, filled by vp_comm_fetch
   size_t last_bytes = 0;      // record size of the last vp_gather
   hipStream_t last_stream = nullptr;  // ... and the stream it was enqueued on: the only stream vp_comm_fetch's copy is ordered on
+  hipEvent_t last_done = nullptr;     // recorded behind every vp_gather: "is this communicator still in flight on that stream?"
   std::string err;
 };
 
@@ -149,6 +150,7 @@ void vp_comm_destroy(vp_comm* c) {
   if (!c) return;
   hipSetDevice(c->gpu);
   if (c->comm) rccl().CommDestroy(c->comm);
+  if (c->last_done) hipEventDestroy(c->last_done);
   if (c->d_gather) hipFree(c->d_gather);
   if (c->h_gather) hipHostFree(c->h_gather);
   delete c;
@@ -181,6 +183,15 @@ int vp_gather(vp_engine* e, vp_comm* c, int what) {
     return VP_ERR_STATE;
   }
   if (hipSetDevice(c->gpu) != hipSuccess) return VP_ERR_HIP;
+  // ONE COMMUNICATOR PER ENGINE IN FLIGHT, enforced (round 4; a comment until then): RCCL operations of one communicator must not run
+  // concurrently on two streams.  The same stream again is ordered by the stream; ANOTHER engine's stream is accepted only once the
+  // previous gather has completed there.
+  if (c->last_stream && c->last_stream != g.stream() && c->last_done && hipEventQuery(c->last_done) == hipErrorNotReady) {
+    c->err = e->err = "vp_gather: this communicator's previous all-gather is still in flight on another engine's stream -- one communicator per "
+                      "engine in flight (vp_comm_create one per in-flight engine, or vp_sync the other engine first)";
+    return VP_ERR_STATE;
+  }
+  if (!c->last_done && hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming) != hipSuccess) return VP_ERR_HIP;
   const ncclResult_t rc = rccl().AllGather(src, c->d_gather, bytes, ncclUint8, c->comm, g.stream());
   if (rc != ncclSuccess) {
     c->err = e->err = std::string("ncclAllGather: ") + rccl().GetErrorString(rc);
@@ -188,6 +199,7 @@ int vp_gather(vp_engine* e, vp_comm* c, int what) {
   }
   c->last_bytes = bytes;
   c->last_stream = e->impl->stream();
+  if (hipEventRecord(c->last_done, c->last_stream) != hipSuccess) return VP_ERR_HIP;
   return VP_OK;
 }
 

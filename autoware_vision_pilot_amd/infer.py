@@ -56,9 +56,17 @@ class _NetworkInfer:
         a = np.asarray(frame)
         if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
             raise ValueError("frame must be HxWx3 uint8 RGB")
-        self.model.set_resize_mode(_lib.VP_RESIZE_PIL_BICUBIC)
-        self.model.infer(a)
-        return self._post()
+        # the engine's resize mode is restored afterwards: a later self.model.infer(frame) by the caller resizes as documented
+        # (VP_RESIZE_CV_LINEAR unless the caller chose otherwise), not as this call did
+        prev = self.model.resize_mode()
+        if prev != _lib.VP_RESIZE_PIL_BICUBIC:
+            self.model.set_resize_mode(_lib.VP_RESIZE_PIL_BICUBIC)
+        try:
+            self.model.infer(a)
+            return self._post()
+        finally:
+            if prev != _lib.VP_RESIZE_PIL_BICUBIC:
+                self.model.set_resize_mode(prev)
 
 
 class SceneSegNetworkInfer(_NetworkInfer):

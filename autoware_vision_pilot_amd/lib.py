@@ -96,6 +96,13 @@ _SIGS = {
     "vp_detect_set_letterbox": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vp_detect_postprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, C.c_int, C.POINTER(C.c_int)]),
     "vp_version": (C.c_char_p, []),
+    "vp_set_norm_form": (C.c_int, [_P, C.c_int]),
+    "vp_get_norm_form": (C.c_int, [_P]),
+    "vp_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "vp_get_option": (C.c_char_p, [C.c_char_p]),
+    "vp_clear_options": (None, []),
+    "vp_plan_hash": (C.c_ulonglong, [_P]),
+    "vp_split_weight_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
 # multi-camera exchange (csrc/vp_comm.cpp): part of libvp_hip.so, absent from the CPU-emulated test build
@@ -112,6 +119,7 @@ _COMM_SIGS = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGS) + tuple(_COMM_SIGS)
 VP_OUT_LOGITS, VP_OUT_MASK = 1, 2
+VP_NORM_TORCHVISION, VP_NORM_OPENCV = 0, 1
 VP_RESIZE_CV_LINEAR, VP_RESIZE_PIL_BILINEAR, VP_RESIZE_PIL_BICUBIC = 0, 1, 2
 VP_GATHER_MASK, VP_GATHER_LOGITS = 0, 1
 VP_COMM_ID_BYTES = 128
@@ -152,6 +160,51 @@ def load():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_option(key, value):
+    """vp_set_option: a developer knob of the dispatch rules (process-wide, engines created afterwards); value None removes it.
+    The library never reads the environment -- tools that want the old `VP_X=... python tool.py` spelling call options_from_env()."""
+    rc = load().vp_set_option(key.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise ValueError(f"vp_set_option({key!r}): unknown key")
+
+
+def get_option(key):
+    v = load().vp_get_option(key.encode())
+    return None if v is None else v.decode()
+
+
+def clear_options():
+    load().vp_clear_options()
+
+
+def options_from_env(environ=None):
+    """DEVELOPER TOOLS ONLY (tools/*.py call it explicitly): copy the VP_* variables the dispatch rules know from the environment into
+    the library's option table.  Returns what was set."""
+    environ = os.environ if environ is None else environ
+    done = {}
+    for k, v in environ.items():
+        if k.startswith("VP_") and load().vp_set_option(k.encode(), v.encode()) == 0:
+            done[k] = v
+    return done
+
+
+def version():
+    return load().vp_version().decode()
+
+
+def split_weight_rows(w):
+    """vp_split_weight_rows (host only): fp32 [rows][per_row] -> (hi fp16, lo fp16, post_scale fp32 [rows])."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    rows, per = w.shape
+    hi = np.empty((rows, per), np.float16)
+    lo = np.empty((rows, per), np.float16)
+    post = np.empty(rows, np.float32)
+    rc = load().vp_split_weight_rows(_ptr(w), rows, per, _ptr(hi), _ptr(lo), _ptr(post))
+    if rc != 0:
+        raise (VpRangeError if rc == -5 else ValueError)(f"vp_split_weight_rows failed ({rc})")
+    return hi, lo, post
 
 
 def convert_onnx(onnx_path, vpw_path):
@@ -242,6 +295,16 @@ class Engine:
 
     def resize_mode(self):
         return self._lib.vp_get_resize_mode(self._h)
+
+    def set_norm_form(self, form):
+        """VP_NORM_TORCHVISION: q / 255 (to_tensor; default), VP_NORM_OPENCV: q * fl(1/255) (cv::Mat::convertTo, the C++ front-ends)."""
+        self._ck(self._lib.vp_set_norm_form(self._h, form))
+
+    def norm_form(self):
+        return self._lib.vp_get_norm_form(self._h)
+
+    def plan_hash(self):
+        return int(self._lib.vp_plan_hash(self._h))
 
     def input_hw(self):
         h, w = C.c_int(), C.c_int()

@@ -59,13 +59,15 @@ def workload_gflop(kinds):
 
 
 def kernel_source_hash():
-    """sha256 over the sources the 3x3 convolution kernels -- the roofline kernels -- are built from: tools/pmc_summarize.py stamps the
+    """sha256 over every kernel source and header of the library: tools/pmc_summarize.py stamps the
     PMC file with it, and a file taken on other sources is ignored (roofline.traffic = null) instead of going silently stale."""
     import hashlib
 
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "autoware_vision_pilot_amd", "csrc")
-    for f in ("kernels_conv3x3_x3.hip", "kernels_conv3x3.hip", "conv_epilogue.hpp", "lds_dma.hpp", "common.hpp"):
+    for f in sorted(os.listdir(csrc)):          # EVERY kernel source and header (round 4: the counters cover the whole plan)
+        if not f.endswith((".hip", ".hpp", ".inc")):
+            continue
         h.update(f.encode())
         h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
@@ -86,11 +88,14 @@ def pmc_traffic(tag):
     else:
         m = re.match(r"conv_gemm<bk(\d+),co(\d+),px(\d+),x(\d)(?:,regepi(\d))?>", tag)
         if not m:
-            pat = r"vp::" + re.escape(tag.split("<")[0]) + r"_kernel" + (re.escape("<" + tag.split("<")[1]) if "<" in tag else "")
+            # every other kernel family (mbconv_front / _back, conv3x3_map, gemm_dma, head_conv3x3, convt_rs, stem, ...): the tag's template
+            # arguments are abbreviations, so the counters are averaged over the family's instantiations
+            base = re.split(r"[<+]", tag)[0]
+            pat = r"vp::" + re.escape(base) + r"_kernel\b"
         else:
             pat = (rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'}, "
                    rf"\d, (true|false), {m.group(5) or 0}>")
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -204,6 +209,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, max 32)")
     ap.add_argument("--latency-iters", type=int, default=100)
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="developer knob of the dispatch rules (vp_set_option; repeatable) -- the library does not read the environment; "
+                         "whatever is set shows in the line's `library` and `plan_hash` fields")
     args = ap.parse_args()
     if args.kind:
         args.workload = args.kind
@@ -242,6 +250,9 @@ def main():
 
     from autoware_vision_pilot_amd import lib, synthetic, weights as vw
 
+    for kv in args.option:
+        key, _, val = kv.partition("=")
+        lib.set_option(key, val)
     kinds = WORKLOADS[args.workload]
     fw, fh = (int(v) for v in args.frame.split("x"))
     sds = [synthetic.make_state_dict(kinds[0], SEEDS[kinds[0]])]
@@ -322,6 +333,47 @@ def main():
                 dist.broadcast_object_list(ids, src=0)
             comms.append(lib.Comm(ids[0], rank, world, local_rank, rec))
     main_fig = three_figures(cams, args.steps, args.warmup, args.gather)
+
+    # ---- FpsTimer-style split of ONE camera's frame (the reference nodes' benchmark: common/benchmark/fps_timer.cpp:37-63, stamps at
+    # run_model_node.cpp:66,77,107/180,115/188): wall-clock stamps at the stage boundaries of a synchronous loop, medians.  The stages here
+    # are the device-side ones a frame goes through between the host buffers (the nodes' own "preprocess" stamp brackets a cv_bridge copy):
+    #   preprocess = pageable frame -> pinned staging -> H2D (vp_upload_frame) + the resize / normalise kernel
+    #   inference  = encoder + every network's context / neck / head + fused decode (the graph minus the preprocess launch)
+    #   output     = D2H of every network's fp32 logits + u8 mask (vp_fetch_outputs) + the nodes' resizes to the frame size on the device
+    #                (mask nearest, run_model_node.cpp:176-177; depth bilinear, :104) with their D2H
+    fps_timer = None
+    if rank == 0 and not args.no_secondary:
+        cam = cams[0]
+        cam.set_fork(True)
+        pre_kernel_us = 1e3 * float(cam.base.profile_layers(20)[0])          # launch 0 of the plan = the preprocess kernel (HIP events)
+        st = {"up": [], "net": [], "out": []}
+        for i in range(10 + max(30, args.latency_iters // 2)):
+            t0 = time.perf_counter()
+            cam.base.upload_frame(frame)
+            cam.sync()
+            t1 = time.perf_counter()
+            cam.enqueue()
+            cam.sync()
+            t2 = time.perf_counter()
+            for e in [cam.base] + cam.heads:
+                e.fetch_outputs()
+                if e.kind == "scene3d":
+                    e.depth_resized(fh, fw)
+                else:
+                    e.mask_resized(fh, fw)
+            t3 = time.perf_counter()
+            if i >= 10:
+                st["up"].append(1e6 * (t1 - t0))
+                st["net"].append(1e6 * (t2 - t1))
+                st["out"].append(1e6 * (t3 - t2))
+        cam.set_fork(False)
+        up, net, outp = (float(np.median(st[k])) for k in ("up", "net", "out"))
+        fps_timer = {"preprocess_us": round(up + pre_kernel_us, 1), "inference_us": round(net - pre_kernel_us, 1), "output_us": round(outp, 1),
+                     "total_us": round(up + net + outp, 1), "upload_us": round(up, 1), "preprocess_kernel_us": round(pre_kernel_us, 1),
+                     "note": "FpsTimer-style (fps_timer.cpp:37-63) medians of one camera, one frame at a time, a host sync at every stage boundary: "
+                             "preprocess = pageable frame -> pinned staging -> H2D + resize / normalise kernel; inference = shared encoder + all "
+                             "decoders + fused decode (heads forked); output = D2H of every network's logits + mask, then the nodes' resize to the "
+                             "frame size (mask nearest / depth bilinear) on the device + D2H"}
 
     # ---- host-to-host through the synchronous boundary call, one host thread per in-flight engine
     h2h = None
@@ -460,9 +512,13 @@ def main():
                 return "mfma", f["flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS
             return "hbm", f["bytes"] / (f["ms"] * 1e-3) / 1e9 / 8000.0
 
-        by_time = [{"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / tot_ms, 3),
-                    "bound": frac_of(k)[0], "frac": round(frac_of(k)[1], 4)}
-                   for k in sorted(single, key=lambda k: -fam[k]["ms"])[:5]]
+        by_time = []
+        for k in sorted(single, key=lambda k: -fam[k]["ms"])[:8]:
+            trk = pmc_traffic(k)
+            by_time.append({"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / tot_ms, 3),
+                            "bound": frac_of(k)[0], "frac": round(frac_of(k)[1], 4),
+                            "algorithmic_mb_per_launch": round(fam[k]["bytes"] / fam[k]["n"] / 1e6, 2),
+                            "traffic_mb_per_launch": round(trk["bytes"] / 1e6, 2) if trk else None})
         gflop = workload_gflop(kinds)
         frame_tflops = gflop * (main_fig["fps"] / world) / 1e3
         if dom.startswith("conv"):
@@ -512,8 +568,13 @@ def main():
                            "(vp_enqueue_multi / vp_infer_multi, the default) -- same kernels, bit-identical results"
                            + ("" if Camera.fork else "; --no-fork: forking disabled everywhere")),
             "roofline": roofline,
-            "rccl_world": world if args.gather else 0,
+            "rccl_world": world if (args.gather or world > 1) else 0,
+            "rccl_use": ("per-frame all-gather of the class maps (vp_gather) + " if args.gather else "") + ("barrier / max-over-ranks timing" if world > 1 else ("none" if not args.gather else "world 1")),
+            "library": lib.version(),
+            "plan_hash": {e.kind: f"{e.plan_hash():016x}" for e in engs},
         }
+        if fps_timer is not None:
+            out["fps_timer"] = fps_timer
         if three is not None:
             out.update(three)
         if h2h is not None:

@@ -142,6 +142,14 @@ int vp_get_resize_mode(const vp_engine* e);
 /* host only: one axis' tap tables of the VP_RESIZE_PIL_* modes -- bounds[out][2] = {first source index, taps}, coeffs[out][ksize] with
  * 22 fractional bits; returns ksize (> 0) or VP_ERR_ARG (coeffs_cap < out_size * ksize ints).  For tests / external checks. */
 int vp_resample_coeffs(int in_size, int out_size, int resize_mode, int* bounds, int* coeffs, int coeffs_cap);
+/* The u8 -> [0, 1] step ahead of (x - mean) / std exists in two spellings that differ in the last bit for 322 of the 768 (byte, channel)
+ * pairs (<= 7.2e-7): VP_NORM_TORCHVISION q / 255 -- torchvision's to_tensor, the Python operator API (Models/inference/scene_seg_infer.py:
+ * 15-20; default) -- and VP_NORM_OPENCV q * fl(1/255) -- cv::Mat::convertTo(CV_32FC3, 1.0 / 255.0) of the C++ front-ends
+ * (onnx_runtime_backend.cpp:45-49, tensorrt_backend.cpp:164-168, production_release onnxruntime_engine.cpp:85,94-100), which
+ * adapters/hip_backend.hpp and adapters/egolanes_hip_engine.hpp select.  VP_ERR_ARG on a shared engine. */
+enum vp_norm_form { VP_NORM_TORCHVISION = 0, VP_NORM_OPENCV = 1 };
+int vp_set_norm_form(vp_engine* e, int norm_form);
+int vp_get_norm_form(const vp_engine* e);
 int vp_get_decode_mode(const vp_engine* e);      /* the vp_decode_mode in force (>= 0), or VP_ERR_ARG */
 int vp_gpu_id(const vp_engine* e);               /* the device the engine lives on */
 int vp_device_count(void);                       /* GPUs visible to this process (0 = none): a thread-per-GPU host sizes its world with it */
@@ -231,7 +239,8 @@ int vp_timer_end(vp_engine* e, float* elapsed_ms);                             /
  *     frame : vp_enqueue(e);  vp_gather(e, c, VP_GATHER_MASK);            // overlaps the next in-flight frame's encoder
  *     read  : vp_comm_device_buffer (device consumer) or vp_comm_fetch (host copy, synchronises).
  * RCCL is bound with dlopen at the first vp_comm_* call (librccl.so is not a load-time dependency of libvp_hip.so).
- * One communicator per engine in flight: RCCL operations on one communicator must not run concurrently on two streams.
+ * One communicator per engine in flight: RCCL operations on one communicator must not run concurrently on two streams -- ENFORCED:
+ * vp_gather with an engine on another stream while the communicator's previous all-gather has not completed returns VP_ERR_STATE.
  * The reference has no counterpart (single camera per backend instance). */
 typedef struct vp_comm vp_comm;
 #define VP_COMM_ID_BYTES 128
@@ -299,6 +308,21 @@ int vp_detect_postprocess(vp_detect* d, const float* raw, int raw_on_device, int
 int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, int h, int w, const float* weight, const float* bias,
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,
                  char* err, size_t err_len);
+
+/* ---- developer options ------------------------------------------------------------------------------------
+ * The library NEVER reads the environment.  The dispatch rules' developer knobs (A/B timing of a kernel against the one it replaced,
+ * tile / split-K sweeps: DESIGN.md section 3, csrc/options.cpp for the key list) are set here, process-wide, and affect engines
+ * created AFTERWARDS; value NULL removes a key; an unknown key is VP_ERR_ARG.  No option is needed in production and none changes a
+ * result beyond fp32 summation order.  vp_version() lists every option in force; vp_plan_hash() = FNV-1a over (launch name, kernel
+ * tag) of an engine's plan, so a host (bench.py does) can record exactly which kernels ran. */
+int vp_set_option(const char* key, const char* value);
+const char* vp_get_option(const char* key);       /* NULL when unset */
+void vp_clear_options(void);
+unsigned long long vp_plan_hash(const vp_engine* e);
+/* host only (tests / external checks): the (hi, lo) fp16 planes the engine makes of a weight matrix [rows][per_row] and the per-row
+ * 2^-s of its power-of-two prescale: fp32(hi) + fp32(lo) = w * 2^s with the row maximum in [2^13, 2^14), post_scale[r] = 2^-s.
+ * VP_ERR_RANGE for a weight beyond the fp16 range, as vp_create*. */
+int vp_split_weight_rows(const float* w, int rows, int per_row, uint16_t* hi, uint16_t* lo, float* post_scale);
 
 const char* vp_version(void);
 

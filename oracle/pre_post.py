@@ -141,17 +141,25 @@ def resize_pil_u8(img, out_h, out_w, which=PIL_BILINEAR):
     return img
 
 
-def normalize_planes(img_u8, input_is_bgr, planes_rgb):
+def normalize_planes(img_u8, input_is_bgr, planes_rgb, norm_form="torchvision"):
     """uint8 HxWx3 -> fp32 3xHxW.  ``planes_rgb`` False gives B,G,R plane order (middleware 'common'
-    backends), True gives R,G,B (EgoLanes engine, Python).  Constants always follow the plane's colour."""
-    x = img_u8.astype(np.float32) / np.float32(255.0)
+    backends), True gives R,G,B (EgoLanes engine, Python).  Constants always follow the plane's colour.
+    norm_form: "torchvision" = q / 255 (to_tensor, Models/inference/scene_seg_infer.py:15-20); "opencv" = q * fl(1/255), the C++
+    front-ends' cv::Mat::convertTo(CV_32FC3, 1.0 / 255.0) (VisionPilot/middleware_recipes/common/backends/onnx_runtime_backend.cpp:45,
+    tensorrt_backend.cpp:164, production_release/src/inference/onnxruntime_engine.cpp:85) -- OpenCV's cvtScale for 8U -> 32F multiplies
+    by the scale converted to float (one rounding); then fp32 subtract and IEEE divide in both (cv::subtract / cv::divide with the
+    Scalar converted to float, onnx_runtime_backend.cpp:48-49; the scalar loop (x - MEAN[c]) / STD[c], onnxruntime_engine.cpp:98)."""
+    if norm_form == "opencv":
+        x = img_u8.astype(np.float32) * np.float32(1.0 / 255.0)
+    else:
+        x = img_u8.astype(np.float32) / np.float32(255.0)
     rgb = x[..., ::-1] if input_is_bgr else x
     rgb = (rgb - MEAN_RGB) / STD_RGB
     out = rgb if planes_rgb else rgb[..., ::-1]
     return np.ascontiguousarray(out.transpose(2, 0, 1)).astype(np.float32)
 
 
-def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False, out_h=NET_H, out_w=NET_W, resize="cv"):
+def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False, out_h=NET_H, out_w=NET_W, resize="cv", norm_form="torchvision"):
     """Any-size u8 frame -> 1x3xout_hxout_w fp32 network input (320x640 for the scene networks, 512x1024 for AutoDrive).
     resize: "cv" = the integer bilinear above (the C++ nodes' cv::resize), "pil_bilinear" / "pil_bicubic" = Pillow's antialiased
     resample (the Python scripts' Image.resize: AutoDrive's BILINEAR, the scene visualisations' default BICUBIC)."""
@@ -159,7 +167,7 @@ def preprocess(frame_u8, input_is_bgr=True, planes_rgb=False, out_h=NET_H, out_w
         small = resize_bilinear_u8(frame_u8, out_h, out_w)
     else:
         small = resize_pil_u8(frame_u8, out_h, out_w, {"pil_bilinear": PIL_BILINEAR, "pil_bicubic": PIL_BICUBIC}[resize])
-    return normalize_planes(small, input_is_bgr, planes_rgb)[None]
+    return normalize_planes(small, input_is_bgr, planes_rgb, norm_form)[None]
 
 
 # ------------------------------------------------------------------------------------------ decode

@@ -24,6 +24,24 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def vp_opts():
+    """Developer options of the library under test (vp_set_option; the library does not read the environment): `setenv` / `delenv` like
+    monkeypatch, everything cleared afterwards.  Acts on whichever library autoware_vision_pilot_amd.lib is bound to (the emulated one
+    inside an `emu_lib` module)."""
+    from autoware_vision_pilot_amd import lib
+
+    class _Opts:
+        def setenv(self, key, value):
+            lib.set_option(key, value)
+
+        def delenv(self, key):
+            lib.set_option(key, None)
+
+    yield _Opts()
+    lib.clear_options()
+
+
 SEEDS = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}
 FRAME_SEED = 1
 

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE (see shim/hip/hip_runtime.h): storage for the kernels' dynamic LDS + plain-C entry points onto the
 // kernel launchers for the CPU tests (tests/test_kernels_emulated.py).  Linked with every csrc/ source compiled for the host
 // (build.py), so the emulated library also exports the whole C ABI of include/vp_hip.h.
+#include <vector>
 #include "act_io.hpp"
 
 namespace vp {  // dynamic-LDS arrays of the kernels (per worker thread = per running workgroup): 160 KiB, the size of a CU's LDS
@@ -53,6 +54,13 @@ int emu_preprocess(const uint8_t* frame, int stride, const int* xtab, const int*
   for (int c = 0; c < 3; ++c) { p.src_c[c] = src_c[c]; p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
   return launch_preprocess(p, nullptr);
 }
+int emu_preprocess_form(const uint8_t* frame, int stride, const int* xtab, const int* ytab, int out_h, int out_w, const int* src_c,
+                        const float* mean3, const float* std3, float* out, int norm_form) {
+  PreprocessParams p{};
+  p.frame = frame; p.stride = stride; p.xtab = xtab; p.ytab = ytab; p.out_h = out_h; p.out_w = out_w; p.out = out; p.norm_form = norm_form;
+  for (int c = 0; c < 3; ++c) { p.src_c[c] = src_c[c]; p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
+  return launch_preprocess(p, nullptr);
+}
 int emu_pil_resample(const uint8_t* frame, int stride, int in_h, int in_w, int out_h, int out_w, const int* hb, const int* hk, int hks, const int* vb,
                      const int* vk, int vks, uint8_t* tmp, const int* src_c, const float* mean3, const float* std3, float* out) {
   PilResampleParams p{};
@@ -101,6 +109,8 @@ int emu_mbconv_front(void* in_hi, void* in_lo, int H, int W, int Cin, const void
                      const float* b_dw, void* out_hi, void* out_lo, int Cexp, int k, int stride, unsigned long long* sums, int replicas, const float* w1, int sq,
                      unsigned long long* zsums) {
   MbFrontParams p{};
+  static const std::vector<float> ones(4096, 1.0f);   // un-prescaled test weights (MbFrontParams::s_exp)
+  p.s_exp = ones.data();
   p.w1 = w1; p.sq = sq; p.zsums = zsums;
   p.in = view(in_hi, in_lo, H, W, Cin);
   p.w_hi = static_cast<const half_t*>(w_hi); p.w_lo = static_cast<const half_t*>(w_lo); p.b_exp = b_exp; p.w_dw = w_dw; p.b_dw = b_dw;
@@ -112,6 +122,8 @@ int emu_mbconv_back(void* in_hi, void* in_lo, int H, int W, int C, int Creal, co
                     const float* b1, const float* w2q, const float* b2, int sqp, const float* w, const float* bias, void* res_hi, void* res_lo,
                     void* out_hi, void* out_lo, int Cout, const unsigned long long* zsums) {
   MbBackParams p{};
+  static const std::vector<float> ones(4096, 1.0f);   // un-prescaled test weights (MbBackParams::wscale)
+  p.wscale = ones.data();
   p.zsums = zsums;
   p.in = view(in_hi, in_lo, H, W, C);
   p.se.sums = sums; p.se.replicas = replicas; p.se.C = C; p.se.Creal = Creal; p.se.sq = sq; p.se.inv_hw = 1.0f / (float)(H * W); p.se.w1 = w1; p.se.b1 = b1;

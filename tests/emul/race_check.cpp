@@ -115,9 +115,9 @@ int main(int argc, char** argv) {
     bad |= conv(precision, 1, 128, 64, 4, 8, 2, 1, -1, -1, -1);                                                                               // short-K ConvTranspose GEMM
     if (precision == 0 && !quick) bad |= conv(0, 1, 128, 64, 32, 64, 2, 0, -1, -1, -1);  // >= 2048 px: kernels_convt_rs.hip picked by the engine
     // register-stationary ConvTranspose (kernels_convt_rs.hip): three DMA tile buffers, one barrier per tile, wave-private patches; 7-8 tiles per workgroup
-    setenv("VP_CONVT_RS_GROUPS", "9", 1);
+    vp_set_option("VP_CONVT_RS_GROUPS", "9");
     if (!quick) bad |= conv(precision, 1, 128, 128, 32, 64, 2, 0, 5, -1, 1);  // (2048 pixels minimum: ~2 min under the sanitizer, not in the suite's subset)
-    unsetenv("VP_CONVT_RS_GROUPS");
+    vp_set_option("VP_CONVT_RS_GROUPS", nullptr);
     // LDS-DMA GEMM (kernels_gemm_dma.hip): three-stage ring, one barrier per K step, patches over the ring; 256 pixels = two tiles, 8 K steps
     if (precision == 1 || quick) bad |= conv(1, 1, 256, 256, 8, quick ? 16 : 32, 2, 0, 6, -1, quick ? 2 : 1);
     // a head's logits convolution (kernels_head.hip) is reached through mode 3 only: see conv_logits below

@@ -40,7 +40,9 @@ def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, engines, mtype, kind
     rest = raw[720 * 1280 * 3:]
     eng = engines(kind, "fp16x3")
     eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB if kind == "egolanes" else lib.VP_PLANES_BGR)
+    eng.set_norm_form(lib.VP_NORM_OPENCV)   # the adapters compute the C++ front-ends' q * fl(1/255) (hip_backend.hpp, egolanes_hip_engine.hpp)
     eng.infer(frame)
+    assert np.array_equal(eng.input_tensor(), pre_post.preprocess(frame, input_is_bgr=True, planes_rgb=(kind == "egolanes"), norm_form="opencv"))
     lg = eng.logits()
     n = lg.size * 4
     assert np.array_equal(rest[:n].view(np.float32).reshape(lg.shape), lg)
@@ -54,6 +56,7 @@ def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, engines, mtype, kind
     else:
         assert np.array_equal(tail.view(np.float32).reshape(80, 160), pre_post.egolanes_planes(lg)[0])
     eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
+    eng.set_norm_form(lib.VP_NORM_TORCHVISION)
 
 
 @pytest.mark.gpu

@@ -145,27 +145,27 @@ def _skip_case(lib, cin, cs, cout, h, w, precision, seed):
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
-def test_convt_register_stationary_kernel(emu_lib, precision, monkeypatch):
+def test_convt_register_stationary_kernel(emu_lib, precision, vp_opts):
     """kernels_convt_rs.hip (tile 5): weights stationary in registers, pixel tiles by LDS-DMA three deep, permuted weight rows +
     wave-private patch epilogue.  K = 128 (every workgroup covers the four quadrants) with one and with many tiles per workgroup
     (the prologue / steady-state / tail wait counts), K = 256 + 32 with the fused skip link (one quadrant per workgroup; ragged
     real channel counts below the padded ones), and the refusal of shapes it does not cover."""
     _case(emu_lib, 128, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=41)                  # 64 tiles, one per workgroup
-    monkeypatch.setenv("VP_CONVT_RS_GROUPS", "5")
+    vp_opts.setenv("VP_CONVT_RS_GROUPS", "5")
     _case(emu_lib, 128, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=42)                  # 12-13 tiles per workgroup
     _case(emu_lib, 100, 120, 34, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=43)                  # channels padded to 128 / 128
-    monkeypatch.setenv("VP_CONVT_RS_GROUPS", "3")
+    vp_opts.setenv("VP_CONVT_RS_GROUPS", "3")
     a = _skip_case(emu_lib, 256, 24, 256, 16, 128, precision, seed=44)                              # 64 tiles x 4 quadrant slices, 21-22 per workgroup
-    monkeypatch.setenv("VP_CONVT_RS", "0")
+    vp_opts.setenv("VP_CONVT_RS", "0")
     b = _skip_case(emu_lib, 256, 24, 256, 16, 128, precision, seed=44)                              # same layer through the GEMM kernel
     assert float(np.abs(a - b).max()) <= (4e-3 if precision == 0 else 2e-5)
-    monkeypatch.delenv("VP_CONVT_RS")
+    vp_opts.delenv("VP_CONVT_RS")
     with pytest.raises(emu_lib.VpError):
         _case(emu_lib, 64, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=45)               # K = 64: not covered
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
-def test_head_logits_conv_kernel(emu_lib, precision, monkeypatch):
+def test_head_logits_conv_kernel(emu_lib, precision, vp_opts):
     """kernels_head.hip through vp_op_conv2d mode 3 (fp32 NCHW logits written by the kernel): 16x16x32 MFMA with the weights
     stationary in registers, LDS-DMA halo with the zero page for the border and the pad slots, persistent workgroups; 64 channels
     (one slab, 8x16 tiles) and 128 channels (two slabs meeting in LDS, 4x16 tiles), 1 and 3 logit channels, maps that are not a
@@ -181,27 +181,27 @@ def test_head_logits_conv_kernel(emu_lib, precision, monkeypatch):
         got = emu_lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
         err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
         assert got.shape == ref.shape and err <= tol, (cin, cout, h, w, err)
-        monkeypatch.setenv("VP_HEAD_CONV", "0")                          # same layer through the halo kernel's 32-channel tile
+        vp_opts.setenv("VP_HEAD_CONV", "0")                          # same layer through the halo kernel's 32-channel tile
         halo = emu_lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
-        monkeypatch.delenv("VP_HEAD_CONV")
+        vp_opts.delenv("VP_HEAD_CONV")
         assert float((np.abs(halo - ref) / np.maximum(1.0, np.abs(ref))).max()) <= tol
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
-def test_gemm_dma_kernel(emu_lib, precision, monkeypatch):
+def test_gemm_dma_kernel(emu_lib, precision, vp_opts):
     """kernels_gemm_dma.hip (tile 6): both operands by LDS-DMA three K steps deep, slot swizzle and weight-row permutation applied
     on the DMA's global side, wave-private patch epilogue; ragged pixel count (last tile re-reads the last pixel), K of 8 and of
     more steps, the fused skip link (K extension from the 2H x 2W tensor, quadrant of the workgroup), two weight-row tiles per
     quadrant; against torch and against the implicit-GEMM kernel on the same layer."""
-    monkeypatch.setenv("VP_GEMM_DMA", "1")          # fp16 engines take it only on request
+    vp_opts.setenv("VP_GEMM_DMA", "1")          # fp16 engines take it only on request
     _case(emu_lib, 256, 256, 9, 15, 2, 1, 0, 0, precision, [(6, -1, 1)], seed=51)                   # 135 pixels: one full tile + 7 pixels
     _case(emu_lib, 320, 512, 8, 16, 2, 1, 0, 0, precision, [(6, -1, 1), (6, -1, 3)], seed=52)       # 10 K steps, 8 weight tiles; 3 K slices (3 + 3 + 4 steps)
     a = _skip_case(emu_lib, 256, 24, 256, 10, 16, precision, seed=53)                               # 8 + 1 K steps, 160 pixels
     b = _skip_case(emu_lib, 512, 40, 512, 12, 20, precision, seed=54)                               # 16 + 2 K steps, two tiles per quadrant
-    monkeypatch.setenv("VP_GEMM_DMA", "0")
+    vp_opts.setenv("VP_GEMM_DMA", "0")
     assert float(np.abs(a - _skip_case(emu_lib, 256, 24, 256, 10, 16, precision, seed=53)).max()) <= (4e-3 if precision == 0 else 2e-5)
     assert float(np.abs(b - _skip_case(emu_lib, 512, 40, 512, 12, 20, precision, seed=54)).max()) <= (4e-3 if precision == 0 else 2e-5)
-    monkeypatch.setenv("VP_GEMM_DMA", "1")
+    vp_opts.setenv("VP_GEMM_DMA", "1")
     with pytest.raises(emu_lib.VpError):
         _case(emu_lib, 256, 96, 9, 15, 2, 1, 0, 0, precision, [(6, -1, 1)], seed=55)                # 4 * 96 rows: not a multiple of 256
 

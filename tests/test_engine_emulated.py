@@ -218,7 +218,7 @@ def test_range_guard_is_loud_on_cpu(emu_lib):
         eng.close()
 
 
-def test_kernel_plan_is_the_committed_one(emu_lib):
+def test_kernel_plan_is_the_committed_one(emu_lib, monkeypatch):
     """WHICH kernel every layer of every network gets (vp_layer_kernel), both precisions, against tests/golden/kernel_plan.json: the
     dispatch rules of engine.cpp (tile shapes, split-K, the pipelined / register-stationary / LDS-DMA kernels, fused decode) are host
     code and untested as rules otherwise -- a wrong predicate silently picks a slower kernel.  Deliberate rule changes regenerate the file
@@ -229,6 +229,11 @@ def test_kernel_plan_is_the_committed_one(emu_lib):
     from dump_kernel_plan import kernel_plan
 
     want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_plan.json")))
+    # a HOSTILE environment: every knob the dispatch rules used to read from it (round 3) set to its most disruptive value -- the plan
+    # below must still be the committed one, because the library no longer reads the environment (csrc/options.cpp)
+    for k, v in {"VP_X3_TILE": "0", "VP_MAP3X3": "0", "VP_MBCONV_FUSE": "0", "VP_MBCONV_BACK": "0", "VP_CONV3X3": "v1", "VP_HEAD_CONV": "0", "VP_CONVT_RS": "0",
+                 "VP_GEMM_DMA": "0", "VP_FUSE_SKIP": "0", "VP_FUSE_DECODE": "0", "VP_NSPLIT_FORCE": "1", "VP_PROJ_SPLIT": "0", "VP_CONVT_TILE": "2", "VP_X3_C64": "1"}.items():
+        monkeypatch.setenv(k, v)
     got = kernel_plan(emu_lib)
     assert sorted(got) == sorted(want)
     for key in want:
@@ -239,3 +244,18 @@ def test_kernel_plan_is_the_committed_one(emu_lib):
     assert seg["SceneNeck.decode_layer_4"] == "conv3x3_x3w8<co128,px256>" and seg["SceneSegHead.decode_layer_8"] == "conv3x3_x3w4<co128,px128>"
     assert seg["SceneSegHead.decode_layer_10"].startswith("head_conv3x3<c64,x3>+decode")
     assert seg["SceneSegHead.upsample_layer_4"] == "convt_rs<k128,x3>" and seg["SceneNeck.upsample_layer_2+skip_link_layer_2"].startswith("gemm_dma<")
+    # the same knobs through vp_set_option DO change the plan -- and its hash, which bench.py records
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+
+    blob = vw.pack_state_dict(synthetic.make_state_dict("egolanes", 2))
+    eng = emu_lib.Engine("egolanes", blob, precision="fp16x3")
+    h0, k0 = eng.plan_hash(), eng.layer_kernels()
+    eng.close()
+    emu_lib.set_option("VP_MAP3X3", "0")
+    try:
+        eng = emu_lib.Engine("egolanes", blob, precision="fp16x3")
+        h1, k1 = eng.plan_hash(), eng.layer_kernels()
+        eng.close()
+    finally:
+        emu_lib.clear_options()
+    assert h0 != 0 and h0 != h1 and any("conv3x3_map" in k for k in k0) and not any("conv3x3_map" in k for k in k1)

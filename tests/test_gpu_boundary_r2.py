@@ -162,6 +162,22 @@ def test_rccl_gather_world_1(engines, frame720):
         assert np.array_equal(lg[0].reshape(3, 320, 640), eng.logits())
         with pytest.raises(ValueError):
             lib.Comm(lib.Comm.unique_id(), 2, 1, 0, 16)  # rank >= world
+        # one communicator per engine IN FLIGHT, enforced: a second engine (its own stream) may not use the communicator while the first
+        # engine's all-gather has not completed (VP_ERR_STATE); once it has, sequential use is legal
+        other = engines("scene3d", "fp16")
+        other.upload_frame(frame720)
+        other.enqueue()
+        other.sync()
+        for _ in range(20):                               # ~20 frames of work queued ahead of the gather: it cannot have completed
+            eng.enqueue()
+        comm.gather(eng, lib.VP_GATHER_MASK)
+        with pytest.raises(lib.VpError, match="one communicator per"):
+            comm.gather(other, lib.VP_GATHER_LOGITS)
+        eng.sync()
+        comm.gather(other, lib.VP_GATHER_LOGITS)          # the first stream has drained: accepted
+        got = comm.fetch(other, np.float32)
+        other.fetch_outputs()
+        assert np.array_equal(got[0][: 320 * 640].reshape(320, 640), other.logits()[0])
     finally:
         comm.close()
 

@@ -121,7 +121,7 @@ def test_conv_op_transpose_detecting():
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
-def test_convt_register_stationary_kernel(precision, monkeypatch):
+def test_convt_register_stationary_kernel(precision, vp_opts):
     """kernels_convt_rs.hip (tile 5; the engine's choice for the two large-map up-sampling stages of every head): weights
     stationary in registers, pixel tiles by LDS-DMA, LDS-only barriers with explicit vmcnt waits.  K = 128 at the head's real
     size (160x320 -> 320x640: 6-7 tiles per workgroup) and with one tile per workgroup; K = 256 + 32 with the fused skip link
@@ -158,13 +158,13 @@ def test_convt_register_stationary_kernel(precision, monkeypatch):
     assert (np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
     for _ in range(3):
         assert np.array_equal(got, lib.op_conv2d(x, wcat, bcat, mode=2, res=sk, res_mode=cs, precision=precision))
-    monkeypatch.setenv("VP_CONVT_RS", "0")
+    vp_opts.setenv("VP_CONVT_RS", "0")
     gemm = lib.op_conv2d(x, wcat, bcat, mode=2, res=sk, res_mode=cs, precision=precision)
     assert (np.abs(gemm - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
-def test_head_logits_conv_kernel(precision, monkeypatch):
+def test_head_logits_conv_kernel(precision, vp_opts):
     """kernels_head.hip (vp_op_conv2d mode 3: the kernel writes fp32 NCHW logits): 16x16x32 MFMA, weights stationary in registers,
     LDS-DMA halo with the zero page; the heads' real shapes (64 -> 3 and 128 -> 1 on 320x640: 12 / 25 tiles per persistent
     workgroup) and ragged maps, against torch and against the halo kernel's 32-channel tile; same bits run to run."""
@@ -181,19 +181,19 @@ def test_head_logits_conv_kernel(precision, monkeypatch):
         err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
         assert got.shape == ref.shape and err.max() <= tol, (cin, cout, h, w, err.max(), np.unravel_index(err.argmax(), err.shape))
         assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision))
-        monkeypatch.setenv("VP_HEAD_CONV", "0")
+        vp_opts.setenv("VP_HEAD_CONV", "0")
         halo = lib.op_conv2d(x, wt, b, ks=3, mode=3, precision=precision)
-        monkeypatch.delenv("VP_HEAD_CONV")
+        vp_opts.delenv("VP_HEAD_CONV")
         assert (np.abs(halo - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
-def test_gemm_dma_kernel(precision, monkeypatch):
+def test_gemm_dma_kernel(precision, vp_opts):
     """kernels_gemm_dma.hip (tile 6; the engine's choice for the three small-map up-sampling stages in the parity mode): the neck's
     real shapes incl. the fused skip link, against torch and the implicit-GEMM kernel; same bits run to run (asynchronous DMA ring)."""
     from autoware_vision_pilot_amd import lib
 
-    monkeypatch.setenv("VP_GEMM_DMA", "1")
+    vp_opts.setenv("VP_GEMM_DMA", "1")
     tol = 1.5e-3 if precision == 0 else 2e-5
     rng = np.random.default_rng(123 + precision)
     for cin, cs, cout, h, w in ((1280, 80, 1280, 10, 20), (768, 40, 768, 20, 40), (512, 24, 512, 40, 80), (256, 0, 256, 9, 15)):
@@ -217,9 +217,9 @@ def test_gemm_dma_kernel(precision, monkeypatch):
         for _ in range(3):
             assert np.array_equal(got, run())
         if cs:
-            monkeypatch.setenv("VP_GEMM_DMA", "0")
+            vp_opts.setenv("VP_GEMM_DMA", "0")
             assert (np.abs(run() - ref) / np.maximum(1.0, np.abs(ref))).max() <= tol
-            monkeypatch.setenv("VP_GEMM_DMA", "1")
+            vp_opts.setenv("VP_GEMM_DMA", "1")
 
 
 @pytest.mark.parametrize("cin,cout,h,w,act,res_mode,nsplit", [(1280, 768, 20, 40, 1, 0, -1), (512, 512, 40, 80, 1, 0, -1), (96, 40, 40, 80, 0, 0, 3), (256, 64, 20, 40, 1, 2, 5)])

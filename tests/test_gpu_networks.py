@@ -42,11 +42,14 @@ def test_preprocess_bit_exact(engines, size):
     frame = pre_post.synthetic_frame(size[0], size[1], 5, smooth=False)
     for pix, planes in [(lib.VP_BGR8, lib.VP_PLANES_BGR), (lib.VP_BGR8, lib.VP_PLANES_RGB), (lib.VP_RGB8, lib.VP_PLANES_RGB)]:
         eng.set_input_format(pix, planes)
-        eng.infer(frame)
-        got = eng.input_tensor()
-        ref = pre_post.preprocess(frame, input_is_bgr=(pix == lib.VP_BGR8), planes_rgb=(planes == lib.VP_PLANES_RGB))
-        assert np.array_equal(got, ref), f"{size} fmt={pix} planes={planes}: {np.abs(got - ref).max()}"
+        for form, name in ((lib.VP_NORM_TORCHVISION, "torchvision"), (lib.VP_NORM_OPENCV, "opencv")):   # q / 255 (Python API) and q * fl(1/255) (C++ front-ends)
+            eng.set_norm_form(form)
+            eng.infer(frame)
+            got = eng.input_tensor()
+            ref = pre_post.preprocess(frame, input_is_bgr=(pix == lib.VP_BGR8), planes_rgb=(planes == lib.VP_PLANES_RGB), norm_form=name)
+            assert np.array_equal(got, ref), f"{size} fmt={pix} planes={planes} {name}: {np.abs(got - ref).max()}"
     eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
+    eng.set_norm_form(lib.VP_NORM_TORCHVISION)
 
 
 def test_preprocess_strided_rows(engines):

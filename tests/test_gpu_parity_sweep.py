@@ -7,16 +7,14 @@ down to the oracle's own fp32 rounding, so the bar on the maps is stated in its 
     * against the oracle's map the flip count must be ZERO, except for pixels whose oracle decision margin (top-1 minus top-2 logit;
       |logit| for the threshold decodes) is at most twice the MEASURED maximum logit error of that pass -- a flip there is a tie
       inside the float tolerance, and each one is reported.
-    * ILL-SCALED passes.  fp16x3 carries 22-23 significand bits (two fp16 planes, the lo x lo product dropped) against fp32's 24: its
-      rounding error is a few times the fp32 reference's own, RELATIVE TO THE SCALE OF THE TENSORS.  The base weight seeds (the ones every
-      other test uses) give |logits| <= 16 and errors of 3e-5 ... 5e-4: the plain bar, with margin.  Other seeds of the same generator
-      scale the encoder output up by 15-170x (|activations| to 1800, |logits| 59 ... 773); there an absolute 1e-3 is 1e-5 ... 1e-6 of the
-      tensor's range -- below what a 22-bit format can hold through ~100 layers, and on the worst of them below what fp32 holds: the CPU
-      reference itself is then 0.5e-3 ... 3.8e-2 away from an fp64 evaluation of the same network.  A pass that misses the plain bar is
-      therefore judged by scale: (a) |error| <= 1e-3 x max|logits| / 16 (the bar grows with the tensor once it exceeds the well-scaled
-      range: 6e-5 of the range), or failing that (b) against an fp64 evaluation, the engine no further from it than 4x the fp32
-      reference is.  The row says which rule applied; a pass that meets the plain bar never takes this path.
-The table goes to gpurun_out/ (copied to profiles/r03_parity_sweep.tsv): per pass max abs / rel logit error, pixels under 1e-3
+    * Passes that miss the plain bar are judged against an fp64 EVALUATION of the same network, every one of them (round 4; no
+      builder-defined scale rule): the bar |error| <= 1e-3 x max(1, |ref|) is stated against the fp32 CPU reference, and on the ill-scaled
+      weight seeds of this sweep (the same generator scales the encoder output up by 15-170x: |activations| to 1800, |logits| 59 ... 773)
+      that reference is itself 0.5e-3 ... 3.8e-2 away from fp64 -- a distance from it says as much about the reference as about the
+      engine.  Such a pass must satisfy   engine_vs_fp64 <= K64 x fp32ref_vs_fp64   with K64 = 4: fp16x3 carries 22 significand bits
+      (two fp16 planes, the lo x lo product dropped) against fp32's 24, a unit round-off 4x the reference's.  Both distances, their
+      ratio and the error as a fraction of the logits' range go into the table; a pass that meets the plain bar never takes this path.
+The table goes to gpurun_out/ (copied to profiles/r04_parity_sweep.tsv): per pass max abs / rel logit error, pixels under 1e-3
 margin, flips, largest flipped margin, and for re-judged passes the reference's and the engine's distance from fp64."""
 import os
 
@@ -31,6 +29,8 @@ BASE_SEED = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}
 FRAMES = [((720, 1280), 101, True), ((720, 1280), 102, False), ((360, 640), 103, True), ((360, 640), 104, False),
           ((1080, 1920), 105, True), ((1080, 1920), 106, False), ((720, 1280), 107, True), ((487, 651), 108, False)]
 ROWS = []
+JUDGED = []
+K64 = 4.0   # fp16x3's unit round-off (2^-22) over fp32's (2^-24): see the module docstring
 
 
 def _decode(kind, logits):
@@ -58,6 +58,7 @@ def test_parity_sweep_fp16x3(kind, wseed):
         eng.set_decode_mode(mode)
     rgb = kind == "egolanes"
     eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB if rgb else lib.VP_PLANES_BGR)
+    fails = []
     try:
         for (h, w), fseed, smooth in FRAMES:
             frame = pre_post.synthetic_frame(h, w, fseed, smooth=smooth)
@@ -79,22 +80,24 @@ def test_parity_sweep_fp16x3(kind, wseed):
             nflip = int(flips.sum())
             worst = float(margin[flips].max()) if nflip else 0.0
             ref64_note = ""
-            if err_rel > 1e-3:
+            if err_rel > 1e-3:           # misses the plain bar: judged against fp64, always (see the module docstring)
                 scale = float(np.abs(ref).max())
-                if err_abs <= 1e-3 * max(1.0, scale / 16.0):
-                    ref64_note = f"ill-scaled: |logits| up to {scale:.0f}, error = {err_abs / scale:.1e} of the range"
-                else:                    # below the fp32 reference's own rounding noise?  judge both against fp64
-                    sd64 = {k: v.double() for k, v in sdt.items()}
-                    r64 = nets.forward(kind, sd64, torch.from_numpy(x).double())[0].numpy()
-                    rel64 = lambda a: float((np.abs(a - r64) / np.maximum(1.0, np.abs(r64))).max())
-                    e_ref, e_got = rel64(ref.astype(np.float64)), rel64(got.astype(np.float64))
-                    ref64_note = f"ill-conditioned: fp32 reference {e_ref:.3e} / engine {e_got:.3e} from fp64 (|logits| up to {scale:.0f})"
-                    assert e_got <= 4.0 * e_ref, f"{kind} seed {wseed} frame {fseed}: logits rel err {err_rel:.3e}; vs fp64: engine {e_got:.3e}, reference {e_ref:.3e}"
+                sd64 = {k: v.double() for k, v in sdt.items()}
+                r64 = nets.forward(kind, sd64, torch.from_numpy(x).double())[0].numpy()
+                rel64 = lambda a: float((np.abs(a - r64) / np.maximum(1.0, np.abs(r64))).max())
+                e_ref, e_got = rel64(ref.astype(np.float64)), rel64(got.astype(np.float64))
+                ref64_note = (f"fp64-judged: fp32 reference {e_ref:.3e} / engine {e_got:.3e} from fp64 = {e_got / max(e_ref, 1e-30):.2f}x "
+                              f"(|logits| up to {scale:.0f}: error = {err_abs / scale:.1e} of the range)")
+                JUDGED.append((kind, BASE_SEED[kind] + wseed, fseed, e_ref, e_got))
+                if not e_got <= K64 * e_ref:   # collected: the remaining frames still go into the table
+                    fails.append(f"{kind} seed {wseed} frame {fseed}: logits rel err {err_rel:.3e}; vs fp64: engine {e_got:.3e}, reference {e_ref:.3e}")
             ROWS.append((kind, BASE_SEED[kind] + wseed, f"{h}x{w}", fseed, int(smooth), err_abs, err_rel, int((margin < 1e-3).sum()), nflip, worst, ref64_note))
             if kind != "scene3d":        # Scene3D's output is a depth map: no class decision to flip
-                assert nflip == 0 or worst <= 2.0 * err_abs, f"{kind} seed {wseed} frame {fseed}: {nflip} flips, largest oracle margin {worst:.3e} vs max logit error {err_abs:.3e}"
+                if not (nflip == 0 or worst <= 2.0 * err_abs):
+                    fails.append(f"{kind} seed {wseed} frame {fseed}: {nflip} flips, largest oracle margin {worst:.3e} vs max logit error {err_abs:.3e}")
     finally:
         eng.close()
+    assert not fails, fails
 
 
 def test_parity_sweep_report():
@@ -114,5 +117,6 @@ def test_parity_sweep_report():
         base = [r for r in ROWS if r[1] == BASE_SEED[r[0]]]
         assert base and all(r[6] <= 1e-3 and not r[10] for r in base), [r for r in base if r[6] > 1e-3]
         f.write(f"# base weight seeds: {len(base)} passes, all inside the plain 1e-3 bar (worst {max(r[6] for r in base):.3e}), {sum(r[8] for r in base)} ties\n")
-        f.write(f"# {len(ROWS)} passes, {tot} class flips in total, worst rel err {max(r[6] for r in ROWS):.3e}, {sum(1 for r in ROWS if r[10])} judged by scale (see the notes)\n")
+        f.write(f"# {len(ROWS)} passes, {tot} class flips in total, worst rel err vs the fp32 reference {max(r[6] for r in ROWS):.3e}, {len(JUDGED)} passes miss the plain bar "
+                f"and are judged against fp64 (engine_vs_fp64 <= {K64:g} x fp32ref_vs_fp64): worst ratio {max([j[4] / max(j[3], 1e-30) for j in JUDGED] or [0.0]):.2f}\n")
     print(f"parity sweep: {len(ROWS)} passes, {sum(r[8] for r in ROWS)} flips, worst rel err {max(r[6] for r in ROWS):.3e}")

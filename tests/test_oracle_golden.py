@@ -239,3 +239,43 @@ def test_autospeed_stages_against_the_reference_binarys_outputs():
         h, w = (int(v) for v in g[f"pre{i}_hw"])
         scale, new_w, new_h, px, py = autospeed.letterbox_geometry(h, w)
         assert (float(scale), px, py) == tuple(float(v) if j == 0 else int(v) for j, v in enumerate(g[f"pre{i}_geom"]))
+
+
+def test_normalisation_forms_against_c_float_arithmetic(tmp_path):
+    """oracle/pre_post.py normalize_planes in both spellings against the C++ front-ends' arithmetic compiled by gcc: the reference's
+    expressions are float multiplications / subtractions / divisions in C (cv::Mat::convertTo(CV_32FC3, 1.0 / 255.0) = `q * (float)(1.0 /
+    255.0)`, onnx_runtime_backend.cpp:45; `(x - MEAN[c]) / STD[c]`, onnxruntime_engine.cpp:98), so a ten-line C program evaluating them
+    with contraction off IS that arithmetic; torchvision's to_tensor is `q / 255.0f`.  All 256 x 3 values, bit for bit."""
+    import shutil
+    import subprocess
+
+    from oracle import pre_post
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not found")
+    src = tmp_path / "norm.c"
+    src.write_text(r"""
+#include <stdio.h>
+int main(void) {
+  static const float MEAN[3] = {0.485f, 0.456f, 0.406f}, STD[3] = {0.229f, 0.224f, 0.225f};
+  const float inv = (float)(1.0 / 255.0);
+  for (int c = 0; c < 3; ++c)
+    for (int q = 0; q < 256; ++q) {
+      volatile float a = (float)q * inv;   /* convertTo(CV_32FC3, 1.0 / 255.0) */
+      volatile float b = (float)q / 255.0f; /* to_tensor */
+      volatile float ya = (a - MEAN[c]) / STD[c], yb = (b - MEAN[c]) / STD[c];
+      printf("%a %a\n", ya, yb);
+    }
+  return 0;
+}
+""")
+    exe = tmp_path / "norm"
+    subprocess.check_call([gcc, "-O0", "-ffp-contract=off", "-o", str(exe), str(src)])
+    vals = np.array([[float.fromhex(t) for t in line.split()] for line in subprocess.check_output([str(exe)], text=True).splitlines()], dtype=np.float32)
+    img = np.zeros((16, 16, 3), np.uint8)
+    img[...] = np.arange(256, dtype=np.uint8).reshape(16, 16, 1)
+    for col, form in ((0, "opencv"), (1, "torchvision")):
+        got = pre_post.normalize_planes(img, input_is_bgr=False, planes_rgb=True, norm_form=form).reshape(3, 256)
+        assert np.array_equal(got, vals[:, col].reshape(3, 256)), form
+    assert int((vals[:, 0] != vals[:, 1]).sum()) == 322

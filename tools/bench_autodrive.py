@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 from autoware_vision_pilot_amd import lib, synthetic, weights as vw
+lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--precision", default="fp16")

@@ -13,6 +13,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401,E402
 from autoware_vision_pilot_amd import lib, synthetic, weights as vw  # noqa: E402
+lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16"
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0

@@ -13,6 +13,7 @@ import numpy as np  # noqa: E402
 
 def child(kind, out):
     from autoware_vision_pilot_amd import lib, weights as vw
+    lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
     from oracle import pre_post, weights
     seeds = {"sceneseg": 0, "scene3d": 1, "egolanes": 2, "domainseg": 3}
     blob = vw.pack_state_dict(weights.make_state_dict(kind, seeds[kind]))

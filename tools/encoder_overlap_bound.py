@@ -14,6 +14,8 @@ import torch  # noqa: F401,E402
 
 from autoware_vision_pilot_amd import lib, synthetic, weights as vw  # noqa: E402
 
+lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
+
 prec = sys.argv[1] if len(sys.argv) > 1 else "fp16x3"
 sd_seg = synthetic.make_state_dict("sceneseg", 0)
 sd_a = synthetic.share_backbone(synthetic.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../autoware_vision_pilot_amd/csrc/kernels_gemm_dma.hip"
+#include "tool_ones.hpp"
 
 using namespace vp;
 namespace vp { hipError_t launch_splitk_finish(const ConvGemmParams&, hipStream_t) { return hipErrorInvalidValue; } }
@@ -43,7 +44,7 @@ static void run_shape(const char* name, int H, int W, int Cin, int Cin2, int Cou
   (void)hipMemset(bias, 0, N * 4);
   ConvGemmParams p{};
   p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.Cin2 = Cin2; p.in2_delta_hi = (long long)in_n; p.in2_delta_lo = (long long)in_n;
-  p.w_hi = w; p.w_lo = wl; p.bias = bias; p.ks = 1; p.Ncols = N; p.CoutW = N; p.store_mode = STORE_SHUFFLE2; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout;
+  p.w_hi = w; p.w_lo = wl; p.bias = bias; p.wscale = tool_dev_ones(N); p.ks = 1; p.Ncols = N; p.CoutW = N; p.store_mode = STORE_SHUFFLE2; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout;
   p.Creal = Cout; p.nsplit = nsplit; p.partial = partial;
   const double gflop = 2.0 * M * (double)N * Kw / 1e9;
   const int it = 30;

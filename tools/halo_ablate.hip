@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../autoware_vision_pilot_amd/csrc/kernels_conv3x3.hip"
+#include "tool_ones.hpp"
 #include "../autoware_vision_pilot_amd/csrc/kernels_conv.hip"
 
 using namespace vp;
@@ -64,6 +65,7 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   p.Cin = Cin;
   p.w_hi = w;
   p.bias = bias;
+  p.wscale = tool_dev_ones(Cout);
   p.ks = 3;
   p.Ncols = Cout;
   p.CoutW = Cout;
@@ -114,7 +116,7 @@ static int run_split(const char* name, int H, int W, int Cin, int Cout, int nspl
   CK(hipMemcpy(w, h.data(), w_n * 2, hipMemcpyHostToDevice));
   CK(hipMemset(bias, 0, Cout * 4));
   ConvGemmParams p{};
-  p.in_hi = in; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.in_hi = in; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.bias = bias; p.wscale = tool_dev_ones(Cout); p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
   p.act = ACT_GELU_F16; p.out_hi = out; p.Cstore = Cout; p.Creal = Cout; p.nsplit = nsplit; p.partial = partial;
   const double gflop = 2.0 * H * W * (double)Cout * Cin * 9 / 1e9;
   const int it = 20;
@@ -171,7 +173,7 @@ static int run_head() {
   CK(hipMemset(w, 0, (size_t)9 * Cout * Cin * 2));
   CK(hipMemset(bias, 0, Cout * 4));
   ConvGemmParams p{};
-  p.in_hi = in; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.in_hi = in; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.bias = bias; p.wscale = tool_dev_ones(Cout); p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
   p.act = ACT_NONE; p.store_mode = STORE_NCHW_F32; p.out_f32 = outf; p.Creal = 3; p.nsplit = 1;
   const int it = 20;
   std::printf("head 64->3 320x640: full %6.1f us | noGlobal %6.1f | noMFMA %6.1f | noLdsRead %6.1f | noBarrier %6.1f | nothing-but-loop %6.1f | nothing, no barrier %6.1f\n",

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch  # noqa: F401
 from autoware_vision_pilot_amd import lib, weights as vw
+lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
 from autoware_vision_pilot_amd import synthetic
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "sceneseg"

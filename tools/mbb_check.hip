@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../autoware_vision_pilot_amd/csrc/kernels_mbconv.hip"
+#include "tool_ones.hpp"
 
 using namespace vp;
 
@@ -71,7 +72,7 @@ static void run(int cexp, int cout, int sq, int H, int W, bool residual, float w
   hipMalloc(&ol, (size_t)M * Cout * 2);
   p.in = ActView{up(xh), up(xl), H, W, C};
   p.se.sums = up(sums); p.se.replicas = replicas; p.se.C = C; p.se.Creal = cexp; p.se.sq = sq; p.se.inv_hw = 1.0f / M; p.se.w1 = up(w1); p.se.b1 = up(b1); p.se.frames = 1;
-  p.w2q = up(w2q); p.b2 = up(b2); p.sqp = sqp; p.w = up(w); p.bias = up(bias);
+  p.w2q = up(w2q); p.b2 = up(b2); p.sqp = sqp; p.w = up(w); p.bias = up(bias); p.wscale = tool_dev_ones(bias.size());
   if (residual) p.res = ActView{up(rh), up(rl), H, W, Cout};
   p.out = ActView{oh, ol, H, W, Cout};
   if (launch_mbconv_back(p, 0) != hipSuccess) { std::printf("launch failed\n"); return; }

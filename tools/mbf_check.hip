@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../autoware_vision_pilot_amd/csrc/kernels_mbconv.hip"
+#include "tool_ones.hpp"
 
 using namespace vp;
 
@@ -30,6 +31,7 @@ static void run(int cin, int cexp, int H, int W) {
   p.w_hi = dev<half_t>((size_t)Cexp * Cin, 0.2f);
   p.w_lo = dev<half_t>((size_t)Cexp * Cin, 0.0001f);
   p.b_exp = dev<float>(Cexp, 0.1f);
+  p.s_exp = tool_dev_ones(Cexp);
   p.w_dw = dev<float>((size_t)K * K * Cexp, 0.3f);
   p.b_dw = dev<float>(Cexp, 0.1f);
   p.out = ActView{dev<half_t>((size_t)OH * OW * Cexp), dev<half_t>((size_t)OH * OW * Cexp), OH, OW, Cexp};

@@ -8,6 +8,7 @@
 
 #include "../autoware_vision_pilot_amd/csrc/kernels_conv3x3.hip"
 #include "../autoware_vision_pilot_amd/csrc/kernels_conv.hip"
+#include "tool_ones.hpp"
 
 using namespace vp;
 
@@ -30,7 +31,7 @@ int main() {
   hipMemset(w, 0, (size_t)9 * C * C * 2);
   hipMemset(bias, 0, C * 4);
   ConvGemmParams p{};
-  p.in_hi = in; p.H = H; p.W = W; p.Cin = C; p.w_hi = w; p.bias = bias; p.ks = 3; p.Ncols = C; p.CoutW = C;
+  p.in_hi = in; p.H = H; p.W = W; p.Cin = C; p.w_hi = w; p.bias = bias; p.wscale = tool_dev_ones(C); p.ks = 3; p.Ncols = C; p.CoutW = C;
   p.act = ACT_GELU_F16; p.out_hi = out; p.Cstore = C; p.Creal = C; p.nsplit = 1;
   int *chain, *sink;
   hipMalloc(&chain, (1 << 20) * 4);

@@ -2,6 +2,7 @@ import os, sys, time, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from autoware_vision_pilot_amd import lib, weights as vw
+lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
 from autoware_vision_pilot_amd import synthetic
 sd_seg = synthetic.make_state_dict("sceneseg", 0)
 sd_3d = synthetic.share_backbone(synthetic.make_state_dict("scene3d", 1), "scene3d", sd_seg, "sceneseg")

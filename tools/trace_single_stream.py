@@ -48,6 +48,8 @@ if __name__ == "__main__":
 
     from autoware_vision_pilot_amd import lib, synthetic, weights as vw
 
+    lib.options_from_env()  # developer tool: VP_* knobs from the environment -> vp_set_option (the library itself never reads the environment)
+
     kind = sys.argv[1] if len(sys.argv) > 1 else "sceneseg"
     prec = sys.argv[2] if len(sys.argv) > 2 else "fp16x3"
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 20

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../autoware_vision_pilot_amd/csrc/kernels_conv3x3_x3.hip"
+#include "tool_ones.hpp"
 
 using namespace vp;
 // the tool's bias vector is all zeros (hipMemset): it doubles as the kernels' zero page
@@ -52,7 +53,7 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   hipMemcpy(wl, h.data(), w_n * 2, hipMemcpyHostToDevice);
   hipMemset(bias, 0, Cout * 4);
   ConvGemmParams p{};
-  p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.wscale = tool_dev_ones(Cout); p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
   p.act = ACT_GELU; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout; p.Creal = Cout; p.nsplit = 1; p.zeros = bias_zero_page(bias);
   const double gflop = 2.0 * H * W * (double)Cout * Cin * 9 / 1e9;
   const int it = 20;
@@ -84,7 +85,7 @@ static void clock_probe(const char* name, int H, int W, int Cin, int Cout) {
   hipMemcpy(inl, h.data(), in_n * 2, hipMemcpyHostToDevice); hipMemcpy(wl, h.data(), w_n * 2, hipMemcpyHostToDevice);
   hipMemset(bias, 0, Cout * 4);
   ConvGemmParams p{};
-  p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
+  p.in_hi = in; p.in_lo = inl; p.H = H; p.W = W; p.Cin = Cin; p.w_hi = w; p.w_lo = wl; p.bias = bias; p.wscale = tool_dev_ones(Cout); p.ks = 3; p.Ncols = Cout; p.CoutW = Cout;
   p.act = ACT_GELU; p.out_hi = out; p.out_lo = outl; p.Cstore = Cout; p.Creal = Cout; p.nsplit = 1; p.partial = reinterpret_cast<float*>(probe); p.zeros = bias_zero_page(bias);
   constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (128 * 64);
   auto k = conv3x3_x3_kernel<128, TH, 2, WPX, HDB, ACT_GELU, ABL>;
