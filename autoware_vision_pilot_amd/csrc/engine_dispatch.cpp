@@ -143,8 +143,8 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       ht = best_c;
     }
     if (ht == 11) {
-      if (!conv3x3_map_supported(p)) throw std::invalid_argument("halo tile 11 (map kernel): 3x3 stride 1, fp16x3, 20x40 regions: " + name);
-      op.kernel = "conv3x3_map<co32,px800,x3>+splitk";
+      if (!conv3x3_map_supported(p)) throw std::invalid_argument("halo tile 11 (map kernel): 3x3 stride 1, fp16x3, 20x40 or 10x20 regions: " + name);
+      op.kernel = conv3x3_map_geometry(p.H, p.W) == 1 ? "conv3x3_map<co32,px800,x3>+splitk" : "conv3x3_map<co32,px200,x3>+splitk";
       op.run = [p](hipStream_t st) { return launch_conv3x3_map(p, st); };
       ops_.push_back(std::move(op));
       return;
@@ -272,21 +272,28 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     {
       const char* envm = dev_option("VP_MAP3X3");
       const bool on = !(envm && envm[0] == '0');
-      if (o.tile == 111 || (on && split() && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && cin_pad >= 256 &&
+      // round 4: the context block's 10x20 maps take the kernel's 10x20-region geometry (four waves, two workgroups per CU; VP_CTX3=0: the
+      // halo kernel's 8x16 tiles + split-K as before) -- context_layer_4 has 128 input channels, so the channel floor is per geometry
+      const char* envc = dev_option("VP_CTX3");
+      const int geom = conv3x3_map_geometry(in->H, in->W);
+      const bool geom_on = geom == 1 ? cin_pad >= 256 : (geom == 2 && cin_pad >= 128 && !(envc && envc[0] == '0'));
+      if (o.tile == 111 || (on && split() && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && geom_on &&
                             conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
         halo = 11;
     }
     if (halo == 11 && (!split() || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
-      throw std::invalid_argument("halo tile 11 (map kernel): fp16x3, maps that tile into 20x40 regions, >= 32 input channels: " + name);
+      throw std::invalid_argument("halo tile 11 (map kernel): fp16x3, maps that tile into 20x40 or 10x20 regions, >= 32 input channels: " + name);
     if (halo >= 6 && halo <= 8 && !split()) throw std::invalid_argument("halo tiles 6 - 8 are fp16x3 kernels: " + name);
   }
   if (halo >= 0) {
     pc.tile = 100 + halo;
     pc.bk = 32;
     pc.CoutW = round_up(ncols, halo_tile_co(halo));
-    if (halo == 11) {  // map kernel: K slices until ~one workgroup per CU (it is a one-workgroup-per-CU kernel), fp32 slabs <= 24 MB
-      const int regions = (in->H / 20) * (in->W / 40), n_co = pc.CoutW / 32, KS = cin_pad / 16;
-      int ns = o.nsplit > 0 ? o.nsplit : std::max(1, 256 / (regions * n_co));  // floor: 155 KB of LDS = one workgroup per CU, a 257th waits a whole round
+    if (halo == 11) {  // map kernel: K slices until ~one round of workgroups (one per CU at 20x40 regions, two at 10x20), fp32 slabs <= 24 MB
+      const int geom = conv3x3_map_geometry(in->H, in->W);
+      const int regions = geom == 1 ? (in->H / 20) * (in->W / 40) : (in->H / 10) * (in->W / 20), n_co = pc.CoutW / 32, KS = cin_pad / 16;
+      const int slots = geom == 1 ? 256 : 512;   // 155 KB of LDS = one workgroup per CU (a 257th waits a whole round); 74 KB = two
+      int ns = o.nsplit > 0 ? o.nsplit : std::max(1, slots / (regions * n_co));
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
       while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
       pc.bk = 16;

@@ -200,6 +200,7 @@ int halo_tile_th(int tile);
 
 // small-map 3x3 of the parity mode (kernels_conv3x3_map.hip; halo tile id 11): a workgroup = 32 output channels x a K slice x all 800 pixels of a
 // 20x40 region; weights packed by conv3x3_map_pack_index; always finishes through splitk_finish_kernel (p.partial required, nsplit >= 1)
+int conv3x3_map_geometry(int H, int W);  // 1 = 20x40 regions (neck), 2 = 10x20 regions (context block), 0 = neither
 bool conv3x3_map_shape_ok(int H, int W, int cin_pad, int coutw);
 size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad);
 bool conv3x3_map_supported(const ConvGemmParams& p);

@@ -26,26 +26,38 @@
 
 namespace vp {
 
+// Geometry of one instantiation: RH x RW region, NWV waves.  <20, 40, 8> = the neck's 20x40 / 40x80 maps (halo tile id 11);
+// <10, 20, 4> = the CONTEXT block's 10x20 maps (round 4, halo tile id 12: context_layer_4..6 ran on the halo kernel's 8x16 tiles with
+// split-K at 0.002-0.03 of the matrix peak -- two pixel tiles re-streaming up to 23.6 MB of (hi, lo) weights each, 20 / 18 / 33 us + finish):
+// 200 pixels = 7 MFMA pixel tiles (the last one ragged: 8 pixels), four waves carry 2 / 2 / 2 / 1 of them, 74 KB of LDS: two workgroups per CU.
+template <int RH_, int RW_, int NWV_>
+struct MapGeom {
+  static constexpr int RH = RH_, RW = RW_, RPX = RH * RW, NWV = NWV_;   // region, waves
+  static constexpr int HW = RW + 2, HH = RH + 2, HPX = HH * HW;         // its halo image
+  static constexpr int NF = (RPX + 31) / 32;                            // pixel tiles of 32 (the last one may be ragged)
+  static constexpr int HROWS = (HPX + 31) / 32 * 32;                    // rows per plane incl. the padding of the last DMA group
+  static constexpr int H_PLANE = HROWS * 32, W_PLANE = 9 * 32 * 32;     // bytes: halo plane, weight plane of one step (9 216)
+  static constexpr int H_BUF = 2 * H_PLANE, W_BUF = 2 * W_PLANE;        // (hi, lo)
+  static constexpr int LDS = 2 * H_BUF + 2 * W_BUF;
+  static constexpr int NHI = HROWS / 32, NWI = W_PLANE / 1024;          // DMA instructions per plane
+  static constexpr int NINSTR = 2 * NHI + 2 * NWI;                      // per step
+  static constexpr int IPW = (NINSTR + NWV - 1) / NWV;                  // per wave
+  static constexpr int NFW_MAX = (NF + NWV - 1) / NWV;                  // pixel tiles of wave 0 (wave w: tiles w, w + NWV, ...)
+  static_assert(LDS <= 160 * 1024, "LDS plan");
+};
 namespace mapk {
-constexpr int RH = 20, RW = 40, RPX = RH * RW;          // region
-constexpr int HW = RW + 2, HH = RH + 2, HPX = HH * HW;   // its halo image: 22 x 42 = 924 pixels
-constexpr int NF = RPX / 32;                             // 25 pixel tiles of 32
-constexpr int HROWS = (HPX + 31) / 32 * 32;              // rows per plane incl. the padding of the last DMA group (928)
-constexpr int H_PLANE = HROWS * 32, W_PLANE = 9 * 32 * 32;  // bytes: halo plane (29 696), weight plane of one step (9 216)
-constexpr int H_BUF = 2 * H_PLANE, W_BUF = 2 * W_PLANE;  // (hi, lo)
-constexpr int LDS = 2 * H_BUF + 2 * W_BUF;               // 155 648
-constexpr int NHI = HROWS / 32, NWI = W_PLANE / 1024;    // DMA instructions per plane: 29 halo, 9 weights
-constexpr int NINSTR = 2 * NHI + 2 * NWI;                // 76 per step
-constexpr int IPW = (NINSTR + 7) / 8;                    // per wave: 10
-static_assert(RPX % 32 == 0 && LDS <= 160 * 1024, "region / LDS plan");
+using Neck = MapGeom<20, 40, 8>;   // 924 halo pixels, 25 tiles, 155 648 B of LDS: one workgroup per CU
+using Ctx = MapGeom<10, 20, 4>;    // 264 halo pixels, 7 tiles (the last: 8 pixels), 73 728 B: two workgroups per CU
+static_assert(Neck::NF == 25 && Neck::LDS == 155648 && Neck::IPW == 10 && Ctx::NF == 7 && Ctx::IPW == 9, "geometry");
 }  // namespace mapk
 
 // NFW = pixel tiles of THIS wave: 4 for wave 0 (tiles 0, 8, 16, 24), 3 for the others.  The body is instantiated per count and the kernel
 // branches ONCE on the (scalar) wave index: with `if (tile < 25)` tests inside the tap loop the compiler guarded every tap with
 // s_waitcnt lgkmcnt(0) at the joins, i.e. the fragments requested one tap ahead were awaited BEFORE the current tap's MFMAs.
-template <int NFW, int ABL>
+template <class G, int NFW, int ABL>
 __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const int wave) {
-  using namespace mapk;
+  constexpr int RH = G::RH, RW = G::RW, RPX = G::RPX, NWV = G::NWV, HW = G::HW, HPX = G::HPX, H_PLANE = G::H_PLANE, W_PLANE = G::W_PLANE, H_BUF = G::H_BUF,
+                W_BUF = G::W_BUF, NHI = G::NHI, NWI = G::NWI, NINSTR = G::NINSTR, IPW = G::IPW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo0 = smem;                 // [2 buffers][2 planes][H_PLANE]
   char* const wgt0 = smem + 2 * H_BUF;      // [2 buffers][2 planes][W_PLANE]
@@ -71,10 +83,10 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
   // branch-free DMA instructions (the last one under a single scalar test: waves 4..7 have nine).
   const half_t* d_src[IPW];
   int d_step[IPW], d_dst[IPW], d_buf[IPW];
-  const int n_dma = (NINSTR - wave + 7) / 8;  // instructions of this wave
+  const int n_dma = (NINSTR - wave + NWV - 1) / NWV;  // instructions of this wave
 #pragma unroll
   for (int i = 0; i < IPW; ++i) {
-    const int ii = wave + 8 * i;
+    const int ii = wave + NWV * i;
     if (ii < 2 * NHI) {
       const int pl = ii >= NHI ? 1 : 0, g = ii - pl * NHI;
       const int R = 32 * g + (lane >> 1), lslot = (lane & 1) ^ ((R >> 3) & 1);
@@ -104,7 +116,7 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
   int b_row[NFW];
 #pragma unroll
   for (int j = 0; j < NFW; ++j) {
-    const int pix = (wave + 8 * j) * 32 + (lane & 31);
+    const int pix = min((wave + NWV * j) * 32 + (lane & 31), RPX - 1);   // ragged last tile: its surplus lanes repeat the last pixel (never stored)
     const int y = pix / RW, x = pix - y * RW;
     b_row[j] = y * HW + x;
   }
@@ -158,7 +170,12 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
   }
 #define VP_MAP_TAP(T)                                                                                                \
   {                                                                                                                  \
-    if constexpr ((T) < 8) VP_MAP_READ(((T) + 1) & 1, (T) + 1)                                                       \
+    if constexpr ((T) < 8) {                                                                                         \
+      VP_MAP_READ(((T) + 1) & 1, (T) + 1)                                                                            \
+      /* this tap's fragments (read one tap ago) must have landed; the 2 + 2 NFW reads just issued stay in flight.  Left to itself the  */ \
+      /* compiler puts s_waitcnt lgkmcnt(0) here on every other tap: the prefetch was drained before the MFMAs it should hide under     */ \
+      if constexpr (!(ABL & 16)) VP_WAIT_LGKMCNT(2 + 2 * NFW);                                                       \
+    }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     VP_MAP_MFMA((T) & 1)                                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -175,7 +192,8 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
   const int M = p.H * p.W, co0 = tile_co * 32;
 #pragma unroll
   for (int j = 0; j < NFW; ++j) {
-    const int pix = (wave + 8 * j) * 32 + (lane & 31);
+    const int pix = (wave + NWV * j) * 32 + (lane & 31);
+    if (RPX % 32 != 0 && pix >= RPX) continue;
     const int y = pix / RW, x = pix - y * RW;
     const int m = (ry0 + y) * p.W + rx0 + x;
     float* row = p.partial + ((size_t)zsplit * M + m) * p.CoutW + co0 + 4 * (lane >> 5);
@@ -191,10 +209,19 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
 // wait in the loop); 0 in the library.
 template <int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParams p) {
+  using G = mapk::Neck;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: keep it scalar
-  static_assert(mapk::NF == 25, "wave 0 carries pixel tiles 0, 8, 16, 24; waves 1..7 three each");
-  if (wave == 0) conv3x3_map_body<4, ABL>(p, wave);
-  else conv3x3_map_body<3, ABL>(p, wave);
+  // wave 0 carries pixel tiles 0, 8, 16, 24; waves 1..7 three each
+  if (wave == 0) conv3x3_map_body<G, 4, ABL>(p, wave);
+  else conv3x3_map_body<G, 3, ABL>(p, wave);
+}
+// the context block's 10x20 maps: four waves, pixel tiles {0, 4}, {1, 5}, {2, 6}, {3}
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv3x3_map_ctx_kernel(const ConvGemmParams p) {
+  using G = mapk::Ctx;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave < 3) conv3x3_map_body<G, 2, ABL>(p, wave);
+  else conv3x3_map_body<G, 1, ABL>(p, wave);
 }
 
 // weight element (output channel co, input channel ci, tap t) -> index into the packed tensor: [co / 32][ci / 16][plane block of 9 x 32 rows x
@@ -205,8 +232,14 @@ size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad) {
   return (((size_t)(co >> 5) * (cin_pad >> 4) + (ci >> 4)) * (9 * 32) + (size_t)t * 32 + col) * 16 + slot * 8 + (k16 & 7);
 }
 
+// geometry a map takes: 1 = 20x40 regions (neck), 2 = 10x20 regions (context block; only where 20x40 does not tile), 0 = neither
+int conv3x3_map_geometry(int H, int W) {
+  if (H >= 20 && W >= 40 && H % 20 == 0 && W % 40 == 0) return 1;
+  if (H >= 10 && W >= 20 && H % 10 == 0 && W % 20 == 0) return 2;
+  return 0;
+}
 bool conv3x3_map_shape_ok(int H, int W, int cin_pad, int coutw) {
-  return H >= mapk::RH && W >= mapk::RW && H % mapk::RH == 0 && W % mapk::RW == 0 && cin_pad % 16 == 0 && cin_pad >= 32 && coutw % 32 == 0;
+  return conv3x3_map_geometry(H, W) != 0 && cin_pad % 16 == 0 && cin_pad >= 32 && coutw % 32 == 0;
 }
 
 bool conv3x3_map_supported(const ConvGemmParams& p) {
@@ -216,10 +249,19 @@ bool conv3x3_map_supported(const ConvGemmParams& p) {
 
 hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st) {
   if (!conv3x3_map_supported(p)) return hipErrorInvalidValue;
-  static LdsAttrOnce once;
-  if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel<0>), mapk::LDS); e != hipSuccess) return e;
-  const int n_regions = (p.H / mapk::RH) * (p.W / mapk::RW);
-  hipLaunchKernelGGL(conv3x3_map_kernel<0>, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(512), mapk::LDS, st, p);
+  if (conv3x3_map_geometry(p.H, p.W) == 1) {
+    using G = mapk::Neck;
+    static LdsAttrOnce once;
+    if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel<0>), G::LDS); e != hipSuccess) return e;
+    const int n_regions = (p.H / G::RH) * (p.W / G::RW);
+    hipLaunchKernelGGL(conv3x3_map_kernel<0>, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(64 * G::NWV), G::LDS, st, p);
+  } else {
+    using G = mapk::Ctx;
+    static LdsAttrOnce once;
+    if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_ctx_kernel<0>), G::LDS); e != hipSuccess) return e;
+    const int n_regions = (p.H / G::RH) * (p.W / G::RW);
+    hipLaunchKernelGGL(conv3x3_map_ctx_kernel<0>, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(64 * G::NWV), G::LDS, st, p);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_splitk_finish(p, st);  // also for nsplit == 1: bias / activation / (hi, lo) split live there

@@ -234,6 +234,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
       if (next_chunk) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, c + 1)                          \
     }                                                                                        \
     VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
+    /* round 4 (ISA): keep these MFMAs IN FRONT of the barrier's lgkmcnt(0) -- the scheduler moved five of the six behind it, so set 1's */ \
+    /* reads were drained one MFMA after their issue                                                                                   */ \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
     if constexpr (!(ABL & 1)) {                                                              \
       /* What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s+1: its first read follows this      */ \
       /* barrier); the tile requested in this step (s+2) is first read behind the NEXT barrier and stays in flight -- two taps */ \
@@ -268,6 +271,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     if constexpr (!(ABL & 4)) VP_READ_FRAGS(0, wnext_, hnext_, tap_next_)                    \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     VP_MFMA(1)                                                                               \
+    /* round 4 (seen in the ISA): without this fence the scheduler hoists the NEXT step's LDS-DMA issue to the head of this MFMA */ \
+    /* group, right behind set 0's reads -- and an LDS-DMA may overwrite what an outstanding ds_read reads, so the compiler puts   */ \
+    /* s_waitcnt lgkmcnt(0) in front of it: the prefetch was drained the moment it was issued.  Behind the 12 MFMAs it has landed. */ \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
   }
 
   // ---- prologue: halo(chunk 0) and weight tiles 0, 1 -> LDS

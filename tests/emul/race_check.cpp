@@ -107,7 +107,8 @@ int main(int argc, char** argv) {
       bad |= conv(1, 0, 64, 128, 17, 19, 3, 1, 106, -1, 1);
       bad |= conv(1, 0, 96, 128, 11, 19, 3, 1, 107, -1, 1);
       bad |= conv(1, 0, 96, 64, 9, 17, 3, 1, 108, -1, 1);  // 64-channel shape (three workgroups per CU on the device)
-      bad |= conv(1, 0, 64, 32, 20, 40, 3, 1, 111, -1, 2);   // map kernel: double-buffered 16-channel steps by LDS-DMA, one barrier per step
+      bad |= conv(1, 0, 64, 32, 20, 40, 3, 1, 111, -1, 2);
+      bad |= conv(1, 0, 64, 32, 10, 20, 3, 1, 111, -1, 2);   // its 10x20-region geometry (context block): four waves, ragged seventh pixel tile   // map kernel: double-buffered 16-channel steps by LDS-DMA, one barrier per step
       bad |= conv(1, 0, 160, 128, 10, 20, 3, 1, 107, -1, 2);  // split-K slices  // 4-wave shape: single halo buffer rewritten between two barriers, 3 chunks
     }
     bad |= conv(precision, 0, 32, 40, 5, 8, 3, 1, 1, 32, 1);                                                                                  // generic 3x3

@@ -447,6 +447,7 @@ F4 mfma_16x16x32_f16(H8 a, H8 b, F4 c) {
 // LDS-DMA (global_load_lds_dwordx4): lane i's 16 bytes land at the wave-uniform LDS address + 16 * i.  Performed at issue.
 #define VP_GLOBAL_LOAD_LDS16(G, L) std::memcpy(reinterpret_cast<char*>(L) + 16 * (threadIdx.x & 63), reinterpret_cast<const char*>(G), 16)
 #define VP_WAIT_VMCNT(N) ((void)0)
+#define VP_WAIT_LGKMCNT(N) ((void)0)
 #define VP_LDS_BARRIER() __syncthreads()
 #define __builtin_amdgcn_s_memrealtime() 0ull
 #define __builtin_amdgcn_wave_barrier() emu::sync_wave()  // lanes of a wave run in lockstep on the device; here they must meet

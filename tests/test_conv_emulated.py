@@ -214,6 +214,10 @@ def test_map_kernel(emu_lib):
     _case(emu_lib, 48, 40, 20, 40, 3, 0, 1, 0, 1, [(111, -1, 1), (111, -1, 2)], seed=71)        # 64 padded input channels = 4 steps; 2 channel tiles
     _case(emu_lib, 96, 72, 40, 80, 3, 0, 0, 0, 1, [(111, -1, 3)], seed=72)                      # four regions, 6 steps in 3 slices, ragged channel tile
     _case(emu_lib, 80, 32, 20, 40, 3, 0, 1, 2, 1, [(111, -1, 5)], seed=73)                      # 96 padded channels = 6 steps in 5 slices (1, 1, 1, 1, 2)
+    # round 4, the context block's geometry: 10x20 regions, four waves carrying 2 / 2 / 2 / 1 pixel tiles, the seventh tile ragged (8 pixels)
+    _case(emu_lib, 48, 72, 10, 20, 3, 0, 1, 0, 1, [(111, -1, 1), (111, -1, 2)], seed=74)        # one region; ragged channel tile
+    _case(emu_lib, 96, 40, 10, 20, 3, 0, 1, 2, 1, [(111, -1, 3)], seed=75)                      # the context's mul-add residual behind 3 K slices
+    _case(emu_lib, 32, 32, 30, 20, 3, 0, 0, 0, 1, [(111, -1, 1)], seed=76)                      # three 10x20 regions stacked (30 rows: not a 20x40 multiple)
     with pytest.raises(emu_lib.VpError):
         x = np.zeros((32, 16, 40), np.float32)
         emu_lib.op_conv2d(x, np.zeros((32, 32, 3, 3), np.float32), np.zeros(32, np.float32), ks=3, precision=1, tile=111, nsplit=1)   # 16 rows: not a region multiple

@@ -11,9 +11,11 @@ down to the oracle's own fp32 rounding, so the bar on the maps is stated in its 
       builder-defined scale rule): the bar |error| <= 1e-3 x max(1, |ref|) is stated against the fp32 CPU reference, and on the ill-scaled
       weight seeds of this sweep (the same generator scales the encoder output up by 15-170x: |activations| to 1800, |logits| 59 ... 773)
       that reference is itself 0.5e-3 ... 3.8e-2 away from fp64 -- a distance from it says as much about the reference as about the
-      engine.  Such a pass must satisfy   engine_vs_fp64 <= K64 x fp32ref_vs_fp64   with K64 = 4: fp16x3 carries 22 significand bits
-      (two fp16 planes, the lo x lo product dropped) against fp32's 24, a unit round-off 4x the reference's.  Both distances, their
-      ratio and the error as a fraction of the logits' range go into the table; a pass that meets the plain bar never takes this path.
+      engine.  Such a pass must satisfy   engine_vs_fp64 <= K64 x fp32ref_vs_fp64   with K64 = 3 -- below the ratio of the unit round-offs
+      (fp16x3 carries 22 significand bits, two fp16 planes with the lo x lo product dropped, against fp32's 24: 4x).  Measured with the
+      weight prescale of round 4: 9 of the 96 passes take this path (19 missed the plain bar in round 3), the engine is CLOSER to fp64
+      than the fp32 reference in 6 of them, worst ratio 1.86.  Both distances, their ratio and the error as a fraction of the logits'
+      range go into the table; a pass that meets the plain bar never takes this path.
 The table goes to gpurun_out/ (copied to profiles/r04_parity_sweep.tsv): per pass max abs / rel logit error, pixels under 1e-3
 margin, flips, largest flipped margin, and for re-judged passes the reference's and the engine's distance from fp64."""
 import os
@@ -30,7 +32,7 @@ FRAMES = [((720, 1280), 101, True), ((720, 1280), 102, False), ((360, 640), 103,
           ((1080, 1920), 105, True), ((1080, 1920), 106, False), ((720, 1280), 107, True), ((487, 651), 108, False)]
 ROWS = []
 JUDGED = []
-K64 = 4.0   # fp16x3's unit round-off (2^-22) over fp32's (2^-24): see the module docstring
+K64 = 3.0   # below the ratio of the unit round-offs (fp16x3 2^-22 : fp32 2^-24 = 4); measured worst 1.86, most passes < 1 (module docstring)
 
 
 def _decode(kind, logits):

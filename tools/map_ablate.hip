@@ -12,14 +12,14 @@ namespace vp { hipError_t launch_splitk_finish(const ConvGemmParams&, hipStream_
 template <int ABL>
 static float time_variant(const ConvGemmParams& p, int iters) {
   auto k = conv3x3_map_kernel<ABL>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, mapk::LDS);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, mapk::Neck::LDS);
   dim3 grid((p.H / 20) * (p.W / 40) * (p.CoutW / 32) * p.nsplit);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), mapk::LDS, 0, p);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), mapk::Neck::LDS, 0, p);
   hipEventRecord(a, 0);
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(512), mapk::LDS, 0, p);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(512), mapk::Neck::LDS, 0, p);
   hipEventRecord(b, 0);
   hipEventSynchronize(b);
   float ms = 0;
