@@ -369,10 +369,10 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
       const int cin = bi == 0 ? S.cin : S.cout, stride = bi == 0 ? S.s : 1, cexp = cin * S.e;
       int j = 0;
       const Act* y = x;
-      // parity mode, one frame per pass: expand 1x1 -> depthwise (+ pool) as ONE launch, the expanded tensor never leaves the CU
+      // one frame per pass (both precisions since round 4): expand 1x1 -> depthwise (+ pool) as ONE launch, the expanded tensor never leaves the CU
       // (kernels_mbconv.hip).  VP_MBCONV_FUSE=0 (developer knob, A/B timing): the two launches.
       const char* env_mb = dev_option("VP_MBCONV_FUSE");
-      const bool fuse_front = S.e != 1 && split() && N == 1 && !(env_mb && env_mb[0] == '0');
+      const bool fuse_front = S.e != 1 && N == 1 && !(env_mb && env_mb[0] == '0');   // both precisions since round 4 (fp16: one plane, one MFMA per product)
       Folded f_exp;
       if (fuse_front) {
         f_exp = fold_conv_bn(blob, bp + std::to_string(j));
@@ -436,7 +436,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           MbFrontParams mp{};
           mp.in = x->view();
           mp.w_hi = dupload(wh);
-          mp.w_lo = dupload(wlo);
+          mp.w_lo = split() ? dupload(wlo) : nullptr;
           mp.b_exp = dupload(be);
           mp.s_exp = dupload(rs.post);
           mp.w_dw = dupload(wk);
@@ -453,8 +453,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           Op op;
           op.name = bp + "0+" + std::to_string(j);   // expand + depthwise
           op.flops = 2.0 * cexp * cin * x->H * x->W + 2.0 * kk * cexp * z->H * z->W;
-          op.bytes = 4.0 * (x->elems() + z->elems());
-          op.kernel = std::string("mbconv_front<k") + std::to_string(S.k) + ",s" + std::to_string(stride) + ">";
+          op.bytes = (split() ? 4.0 : 2.0) * (x->elems() + z->elems());
+          op.kernel = std::string("mbconv_front<k") + std::to_string(S.k) + ",s" + std::to_string(stride) + (split() ? ">" : ",x1>");
           op.run = [mp](hipStream_t st) { return launch_mbconv_front(mp, st); };
           ops_.push_back(std::move(op));
           ++j;
@@ -481,10 +481,10 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         }
       }
       // squeeze-excite -> per-frame scaled projection weights
-      // parity mode, one frame per pass: squeeze-excite tail + projection (+ residual) as ONE launch (kernels_mbconv.hip, back half).
+      // one frame per pass (both precisions since round 4): squeeze-excite tail + projection (+ residual) as ONE launch (kernels_mbconv.hip, back half).
       // VP_MBCONV_BACK=0 (developer knob, A/B timing): se_gate_scale + the projection GEMM (+ its split-K finish).
       const char* env_mbb = dev_option("VP_MBCONV_BACK");
-      const bool fuse_back = split() && N == 1 && !(env_mbb && env_mbb[0] == '0');
+      const bool fuse_back = N == 1 && !(env_mbb && env_mbb[0] == '0');   // both precisions since round 4
       SeParams se{};
       const float *se_w2 = nullptr, *se_b2 = nullptr;
       std::vector<float> se_w2_host;  // [C][sq]
@@ -554,8 +554,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         Op op;
         op.name = bp + std::to_string(j - 1) + "+" + std::to_string(j);   // squeeze-excite + projection
         op.flops = 2.0 * cexp * S.cout * z->H * z->W + 4.0 * sq * cexp;
-        op.bytes = 4.0 * (z->elems() + out->elems() + (residual ? x->elems() : 0)) + 4.0 * wf.size();
-        op.kernel = std::string("mbconv_back<wm") + (z->H * z->W >= 12800 ? "4" : "1") + ">";
+        op.bytes = (split() ? 4.0 : 2.0) * (z->elems() + out->elems() + (residual ? x->elems() : 0)) + 4.0 * wf.size();
+        op.kernel = std::string("mbconv_back<wm") + (z->H * z->W >= 12800 ? "4" : "1") + (split() ? ">" : ",x1>");
         op.run = [mb](hipStream_t st) { return launch_mbconv_back(mb, st); };
         ops_.push_back(std::move(op));
         x = out;

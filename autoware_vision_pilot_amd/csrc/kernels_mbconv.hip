@@ -47,7 +47,9 @@ struct MbTile {
 // ran strictly one after the other (1.05 us per chunk, profiles/r03_mbf_check.txt); two waves per SIMD interleave their halves of it.
 // ABL (tools/mbf_check.hip only): 1 = no expand loop, 2 = no depthwise taps, 4 = no pool atomics (LDS and global), 8 = no SiLU,
 // 16 = expand loop without its global loads after chunk 0, 32 = expand loop without LDS staging / fragment reads / MFMAs (loads only)
-template <int K, int S, int NW, int ABL = 0>
+// X3: the parity mode's (hi, lo) planes and three MFMAs per product; false (round 4: the VP_FP16 engines, until then on the two-launch path):
+// one plane in, one MFMA per product, one plane out -- the lo staging buffers stay unused, the layout is the same.
+template <int K, int S, int NW, int ABL = 0, bool X3 = true>
 __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontParams p) {
   using T = MbTile<K, S>;
   constexpr int NT = 64 * NW;
@@ -107,18 +109,21 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
   }
   const int w_row = tid >> 2, w_part = tid & 3;
   const size_t w_off0 = (size_t)(c0 + (w_row & 31)) * Cin + w_part * 8;
-  u32x4 rx_hi[PCS], rx_lo[PCS], rw_hi = zero4, rw_lo = zero4;
+  u32x4 rx_hi[PCS], rx_lo[X3 ? PCS : 1], rw_hi = zero4, rw_lo = zero4;
 #define VP_MB_LOAD(C)                                                                                  \
   {                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < PCS; ++i) {                                                  \
       const int o_ = (x_off[i] >= 0 ? x_off[i] : 0) + (C) * 32;                                        \
-      const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in.hi + o_), vl_ = *reinterpret_cast<const u32x4*>(p.in.lo + o_); \
+      const u32x4 vh_ = *reinterpret_cast<const u32x4*>(p.in.hi + o_);                                 \
       rx_hi[i] = x_off[i] >= 0 ? vh_ : zero4;                                                          \
-      rx_lo[i] = x_off[i] >= 0 ? vl_ : zero4;                                                          \
+      if constexpr (X3) {                                                                              \
+        const u32x4 vl_ = *reinterpret_cast<const u32x4*>(p.in.lo + o_);                               \
+        rx_lo[i] = x_off[i] >= 0 ? vl_ : zero4;                                                        \
+      }                                                                                                \
     }                                                                                                  \
     if (tid < 128) {                                                                                   \
       rw_hi = *reinterpret_cast<const u32x4*>(p.w_hi + w_off0 + (C) * 32);                             \
-      rw_lo = *reinterpret_cast<const u32x4*>(p.w_lo + w_off0 + (C) * 32);                             \
+      if constexpr (X3) rw_lo = *reinterpret_cast<const u32x4*>(p.w_lo + w_off0 + (C) * 32);           \
     }                                                                                                  \
   }
   VP_MB_LOAD(0)
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
     if constexpr ((ABL & 32) != 0) {  // loads only: fold the pieces into one accumulator element so that they stay
       u32x4 t_ = rw_hi ^ rw_lo;
 #pragma unroll
-      for (int i = 0; i < PCS; ++i) t_ ^= rx_hi[i] ^ rx_lo[i];
+      for (int i = 0; i < PCS; ++i) t_ ^= X3 ? (rx_hi[i] ^ rx_lo[X3 ? i : 0]) : rx_hi[i];
       acc[0][0] += __uint_as_float((t_[0] ^ t_[1] ^ t_[2] ^ t_[3]) & 0x3f800000u);
       if (c + 1 < KC) VP_MB_LOAD(c + 1)
       continue;
@@ -136,12 +141,12 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
       const int q = tid + NT * i;
       if (q < NF * 32 * 4) {
         *reinterpret_cast<u32x4*>(xs_hi + (q >> 2) * XP + (q & 3) * 16) = rx_hi[i];
-        *reinterpret_cast<u32x4*>(xs_lo + (q >> 2) * XP + (q & 3) * 16) = rx_lo[i];
+        if constexpr (X3) *reinterpret_cast<u32x4*>(xs_lo + (q >> 2) * XP + (q & 3) * 16) = rx_lo[X3 ? i : 0];
       }
     }
     if (tid < 128) {  // 32 rows x 4 pieces per plane
       *reinterpret_cast<u32x4*>(ws_hi + w_row * XP + w_part * 16) = rw_hi;
-      *reinterpret_cast<u32x4*>(ws_lo + w_row * XP + w_part * 16) = rw_lo;
+      if constexpr (X3) *reinterpret_cast<u32x4*>(ws_lo + w_row * XP + w_part * 16) = rw_lo;
     }
     __syncthreads();
     if constexpr ((ABL & 16) == 0) {
@@ -150,14 +155,19 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       const int fo = (lane & 31) * XP + ss * 32 + (lane >> 5) * 16;
-      const h8_t a_hi = *reinterpret_cast<const h8_t*>(ws_hi + fo), a_lo = *reinterpret_cast<const h8_t*>(ws_lo + fo);
+      const h8_t a_hi = *reinterpret_cast<const h8_t*>(ws_hi + fo);
+      h8_t a_lo;
+      if constexpr (X3) a_lo = *reinterpret_cast<const h8_t*>(ws_lo + fo);
 #pragma unroll
       for (int j = 0; j < NFW; ++j) {
         const int f = wave + NW * j;
         if (f < NF) {
-          const h8_t b_hi = *reinterpret_cast<const h8_t*>(xs_hi + f * 32 * XP + fo), b_lo = *reinterpret_cast<const h8_t*>(xs_lo + f * 32 * XP + fo);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
+          const h8_t b_hi = *reinterpret_cast<const h8_t*>(xs_hi + f * 32 * XP + fo);
+          if constexpr (X3) {
+            const h8_t b_lo = *reinterpret_cast<const h8_t*>(xs_lo + f * 32 * XP + fo);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
+          }
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[j], 0, 0, 0);
         }
       }
@@ -260,17 +270,18 @@ __global__ __launch_bounds__(64 * NW) void mbconv_front_kernel(const MbFrontPara
 }
 
 bool mbconv_front_supported(const MbFrontParams& p) {
-  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && p.w_hi && p.w_lo && p.b_exp && p.s_exp && p.w_dw && p.b_dw && (p.sums || (p.w1 && p.zsums)) && (p.k == 3 || p.k == 5) &&
+  const bool x3 = p.in.lo != nullptr;   // one plane everywhere (VP_FP16) or two everywhere (VP_FP16X3)
+  return p.in.hi && p.out.hi && p.w_hi && (x3 ? (p.out.lo && p.w_lo) : (!p.out.lo && !p.w_lo)) && p.b_exp && p.s_exp && p.w_dw && p.b_dw && (p.sums || (p.w1 && p.zsums)) && (p.k == 3 || p.k == 5) &&
          (p.stride == 1 || p.stride == 2) && (!p.w1 || (p.zsums && p.sq >= 1 && p.sq <= 64)) && (p.in.C & 31) == 0 && (p.out.C & 31) == 0 && p.replicas >= 1 && (p.replicas & (p.replicas - 1)) == 0 &&
          p.out.H == p.in.H / p.stride && p.out.W == p.in.W / p.stride && p.in.H % p.stride == 0 && p.in.W % p.stride == 0;
 }
 
-template <int K, int S, int NW, int ABL = 0>
+template <int K, int S, int NW, int ABL = 0, bool X3 = true>
 static hipError_t launch_mb_nw(const MbFrontParams& p, hipStream_t st) {
   using T = MbTile<K, S>;
   static_assert(T::LDS <= 160 * 1024, "LDS budget");
   static LdsAttrOnce once;
-  auto k = mbconv_front_kernel<K, S, NW, ABL>;
+  auto k = mbconv_front_kernel<K, S, NW, ABL, X3>;
   if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(k), T::LDS); e != hipSuccess) return e;
   const dim3 grid(((p.out.H + T::TH - 1) / T::TH) * ((p.out.W + T::TW - 1) / T::TW), p.out.C / 32);
   hipLaunchKernelGGL(k, grid, dim3(64 * NW), T::LDS, st, p);
@@ -279,6 +290,7 @@ static hipError_t launch_mb_nw(const MbFrontParams& p, hipStream_t st) {
 template <int K, int S, int ABL = 0>
 static hipError_t launch_mb(const MbFrontParams& p, hipStream_t st) {
   // maps up to 40x80 (<= 200 workgroups: one per CU): eight waves; the big maps keep four (three workgroups per CU)
+  if (p.in.lo == nullptr) return p.out.H * p.out.W <= 3200 ? launch_mb_nw<K, S, 8, ABL, false>(p, st) : launch_mb_nw<K, S, 4, ABL, false>(p, st);
   return p.out.H * p.out.W <= 3200 ? launch_mb_nw<K, S, 8, ABL>(p, st) : launch_mb_nw<K, S, 4, ABL>(p, st);
 }
 
@@ -321,7 +333,7 @@ struct MbBack {
 };
 
 // ABL (tools/mbb_check.hip only): 1 = no gate phases (gate = 0.5), 2 = no projection loop, 4 = no means, 8 = no squeeze FC, 16 = no excite FC
-template <int WM, int NW, int ABL = 0>
+template <int WM, int NW, int ABL = 0, bool X3 = true>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4 ? 3 : 2))) void mbconv_back_kernel(const MbBackParams p) {
   using T = MbBack<WM, NW>;
   constexpr int U = 3;                  // K steps per batch in flight
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
       nxt[u].w0 = *reinterpret_cast<const f32x4_t*>(wrow + k_);                       \
       nxt[u].w1 = *reinterpret_cast<const f32x4_t*>(wrow + k_ + 4);                   \
       nxt[u].xh = *reinterpret_cast<const h8_t*>(p.in.hi + xoff + k_);                \
-      nxt[u].xl = *reinterpret_cast<const h8_t*>(p.in.lo + xoff + k_);                \
+      if constexpr (X3) nxt[u].xl = *reinterpret_cast<const h8_t*>(p.in.lo + xoff + k_); \
     }                                                                                 \
   }
   VP_MBB_LOAD(0)
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
     r_hi[t] = r_lo[t] = h4_t{0, 0, 0, 0};
     if (p.res.hi && it < T::ITEMS && px < M) {
       r_hi[t] = *reinterpret_cast<const h4_t*>(p.res.hi + (size_t)px * Cout + ec);
-      r_lo[t] = *reinterpret_cast<const h4_t*>(p.res.lo + (size_t)px * Cout + ec);
+      if constexpr (X3) r_lo[t] = *reinterpret_cast<const h4_t*>(p.res.lo + (size_t)px * Cout + ec);
     }
   }
   const f32x4_t bias4 = *reinterpret_cast<const f32x4_t*>(p.bias + ec);
@@ -503,10 +515,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
           // 2^12 disagree by one fp16 ulp (1e-4 of a layer's output, tools/mbb_check.hip).  The empty asm pins v in a register.
           asm volatile("" : "+v"(v));
           a_hi[i] = (half_t)v;
-          a_lo[i] = (half_t)(v - (float)a_hi[i]);
+          if constexpr (X3) a_lo[i] = (half_t)(v - (float)a_hi[i]);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, cur[u].xh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, cur[u].xl, acc, 0, 0, 0);
+        if constexpr (X3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, cur[u].xh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, cur[u].xl, acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, cur[u].xh, acc, 0, 0, 0);
       }
     }
@@ -540,27 +554,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WM == 4
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float y = fmaf(v[r], ws4[r], bias4[r]);
-      if (p.res.hi) y += (float)r_hi[t][r] + (float)r_lo[t][r];
+      if (p.res.hi) y += X3 ? (float)r_hi[t][r] + (float)r_lo[t][r] : (float)r_hi[t][r];
       o_hi[r] = (half_t)y;
-      o_lo[r] = (half_t)(y - (float)o_hi[r]);
+      if constexpr (X3) o_lo[r] = (half_t)(y - (float)o_hi[r]);
     }
     *reinterpret_cast<h4_t*>(p.out.hi + (size_t)px * Cout + ec) = o_hi;
-    *reinterpret_cast<h4_t*>(p.out.lo + (size_t)px * Cout + ec) = o_lo;
+    if constexpr (X3) *reinterpret_cast<h4_t*>(p.out.lo + (size_t)px * Cout + ec) = o_lo;
   }
 }
 
 bool mbconv_back_supported(const MbBackParams& p) {
   const SeParams& se = p.se;
-  return p.in.hi && p.in.lo && p.out.hi && p.out.lo && se.sums && se.w1 && se.b1 && p.w2q && p.b2 && p.w && p.bias && p.wscale && se.frames <= 1 &&
+  const bool x3 = p.in.lo != nullptr;   // one plane everywhere (VP_FP16) or two everywhere (VP_FP16X3)
+  return p.in.hi && p.out.hi && (x3 ? p.out.lo != nullptr : p.out.lo == nullptr) && se.sums && se.w1 && se.b1 && p.w2q && p.b2 && p.w && p.bias && p.wscale && se.frames <= 1 &&
          se.C == p.in.C && (se.C & 31) == 0 && se.C >= 32 && (p.out.C & 31) == 0 && se.sq >= 1 && se.sq <= 64 && p.sqp >= se.sq && (p.sqp & 3) == 0 && p.sqp <= 64 &&
          se.replicas >= 1 && p.out.H == p.in.H && p.out.W == p.in.W && p.in.H * p.in.W >= 1 &&
-         (!p.res.hi || (p.res.lo && p.res.C == p.out.C && p.res.H == p.out.H && p.res.W == p.out.W));
+         (!p.res.hi || ((x3 ? p.res.lo != nullptr : p.res.lo == nullptr) && p.res.C == p.out.C && p.res.H == p.out.H && p.res.W == p.out.W));
 }
 
 template <int WM, int NW, int ABL = 0>
 static hipError_t launch_mbb(const MbBackParams& p, hipStream_t st) {
   using T = MbBack<WM, NW>;
   const int M = p.in.H * p.in.W;
+  if (p.in.lo == nullptr) {
+    hipLaunchKernelGGL((mbconv_back_kernel<WM, NW, ABL, false>), dim3((M + 32 * WM - 1) / (32 * WM), p.out.C / 32), dim3(T::NT), T::lds(p.se.C), st, p);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((mbconv_back_kernel<WM, NW, ABL>), dim3((M + 32 * WM - 1) / (32 * WM), p.out.C / 32), dim3(T::NT), T::lds(p.se.C), st, p);
   return hipGetLastError();
 }

@@ -298,6 +298,19 @@ def test_mbconv_front_kernel(emu, cin, cexp, k, stride, H, W):
     assert emu.emu_mbconv_front(ptr(xh), ptr(xl), H, W, cinp, ptr(wh), ptr(wlo), ptr(bep), ptr(wk), ptr(bdp), ptr(oh2), ptr(ol2), cexpp, k, stride,
                                 None, replicas, ptr(w1), sq, ptr(zs2)) == 0
     assert np.array_equal(oh2, oh) and np.array_equal(ol2, ol) and np.array_equal(zs2.sum(axis=0), zsums.sum(axis=0))
+    # round 4, the VP_FP16 engines' instantiation: ONE plane in / out and one MFMA per product (no lo pointers anywhere): the hi planes as operands,
+    # the result rounded to fp16 once
+    e16 = F.silu(F.conv2d(torch.from_numpy(xh.astype(np.float32).transpose(2, 0, 1)[:cin])[None].double(), torch.from_numpy(wh.astype(np.float32)[:cexp, :cin])[:, :, None, None].double(),
+                          torch.from_numpy(be).double()))
+    want16 = F.silu(F.conv2d(e16, torch.from_numpy(wd).double(), torch.from_numpy(bd).double(), stride=stride, padding=k // 2, groups=cexp))[0].float().numpy()
+    oh3, zs3 = np.full((OH, OW, cexpp), 7, np.float16), np.zeros_like(zsums)
+    assert emu.emu_mbconv_front(ptr(xh), None, H, W, cinp, ptr(wh), None, ptr(bep), ptr(wk), ptr(bdp), ptr(oh3), None, cexpp, k, stride,
+                                None, replicas, ptr(w1), sq, ptr(zs3)) == 0
+    got3 = oh3.astype(np.float32).transpose(2, 0, 1)
+    assert _rel(got3[:cexp], want16) <= 1.5e-3 and not got3[cexp:].any()
+    z3 = zs3.view(np.int64).sum(axis=0).astype(np.float64) / 2.0 ** 24
+    want_z3 = w1.astype(np.float64) @ got3.astype(np.float64).sum(axis=(1, 2))       # pool sums of what the kernel stored ...
+    assert np.abs(z3[:sq] - want_z3).max() <= 2e-3 * max(1.0, np.abs(want_z3).max())   # ... up to the fp16 rounding of the stored values (the sums are taken in fp32)
 
 
 @pytest.mark.parametrize("cexp,cout,sq,H,W,residual", [(1152, 192, 48, 10, 20, True), (144, 40, 6, 9, 13, False), (240, 40, 10, 40, 80, True),
@@ -362,6 +375,15 @@ def test_mbconv_back_kernel(emu, cexp, cout, sq, H, W, residual):
                                ptr(bias), ptr(rh) if residual else None, ptr(rl) if residual else None, ptr(oh2), ptr(ol2), Cout, ptr(zs.view(np.uint64))) == 0
     got2 = oh2.astype(np.float64) + ol2.astype(np.float64)
     assert np.abs(got2 - want).max() <= 3e-6 * np.abs(want).max()
+    # round 4, the VP_FP16 engines' instantiation: one plane in / out (no lo pointers), one MFMA per product, the gated weights rounded to fp16
+    want16 = (xh.astype(np.float64) * gate[None, :]) @ w.astype(np.float64).T + bias
+    if residual:
+        want16 = want16 + rh.astype(np.float64)
+    oh3 = np.full((M, Cout), 7, np.float16)
+    assert emu.emu_mbconv_back(ptr(xh), None, H, W, C, cexp, ptr(sums.view(np.uint64)), replicas, sq, ptr(w1), ptr(b1), ptr(w2q), ptr(b2), sqp, ptr(w),
+                               ptr(bias), ptr(rh) if residual else None, None, ptr(oh3), None, Cout, ptr(zs.view(np.uint64))) == 0
+    got3 = oh3.astype(np.float64)
+    assert np.abs(got3 - want16).max() <= 3e-3 * np.abs(want16).max() and not got3[:, cout:].any()
 
 
 def test_squeeze_excite_kernel(emu):
