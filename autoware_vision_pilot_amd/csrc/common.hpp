@@ -43,6 +43,11 @@ struct ConvGemmParams {
   // [2^13, 2^14): neither fp16 plane of a weight is subnormal -- engine_internal.hpp prescale_exp); every epilogue evaluates
   // fmaf(acc, wscale[co], bias[co]): the product is exact (power of two), so the result is that of un-scaled weights carried exactly
   const float* wscale;
+  // VP_WEIGHTS_FP8, real storage (round 4): when non-null the weights are OCP e4m3 BYTES in the kernel's own weight layout (one byte per
+  // element where w_hi has a half), w_hi / w_lo are null, wscale[co] is the row's quantisation scale (not a power of two), and the weight
+  // staging converts 8 codes -> 8 fp16 values on their way to LDS (exact: every e4m3 value is an fp16 value; the lo plane is zero).
+  // Honoured by conv_gemm_kernel and conv3x3_halo_kernel (register-staged weights) -- every matrix layer of AutoDrive.
+  const uint8_t* w8;
   int ks;              // 1 or 3 (stride 1, pad ks/2)
   int Ncols;           // GEMM columns to store (multiple of 32): Cout_pad, or 4*Cout_pad for STORE_SHUFFLE2
   int CoutW;           // weight rows allocated (multiple of the CO tile)
@@ -89,6 +94,25 @@ __device__ __forceinline__ float gelu_exact(float x) {
   const float P = poly * t * __expf(-u * u);  // = 1 - erf(u)
   const float hx = 0.5f * x;
   return x >= 0.0f ? fmaf(-hx, P, x) : hx * P;
+}
+// OCP e4m3 (sign, 4 exponent bits with bias 7, 3 mantissa bits; no infinities, 0x7f / 0xff = NaN never produced by the quantiser) -> fp32, exactly,
+// in integer arithmetic (no dependence on the fp16 denormal mode): normal codes are re-biased into the fp32 exponent, the seven subnormal
+// codes are m * 2^-9.
+__host__ __device__ __forceinline__ float e4m3_to_float(unsigned b) {
+  const unsigned e = (b >> 3) & 15u, m = b & 7u;
+  union { unsigned u; float f; } v;
+  v.u = ((e + 120u) << 23) | (m << 20);
+  const float mag = e ? v.f : (float)m * 0.001953125f;
+  return (b & 0x80u) ? -mag : mag;
+}
+// 8 e4m3 codes (two dwords, element i in byte i) -> 8 fp16 values packed as a 16-byte piece (what the fp16 weight layout holds there)
+typedef unsigned int vp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int vp_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vp_u32x4 e4m3x8_to_half8(unsigned lo, unsigned hi) {
+  union { h8_t h; vp_u32x4 u; } r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.h[i] = (half_t)e4m3_to_float(((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xffu);
+  return r.u;
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }

@@ -100,6 +100,27 @@ void split_half(float v, float pre, half_t* hi, half_t* lo) {
   *lo = (half_t)(x - (float)h);
 }
 
+uint8_t e4m3_encode(float q) {
+  const uint8_t sign = std::signbit(q) ? 0x80 : 0x00;
+  const float mag = std::fabs(q);
+  if (!(mag > 0.0f)) return sign;
+  if (mag >= 448.0f) return sign | 0x7E;                       // largest finite code (0x7F is NaN)
+  int e = 0;
+  std::frexp(mag, &e);                                         // mag = f * 2^e, f in [0.5, 1)  ->  exponent of the leading bit: e - 1
+  int E = e - 1;
+  if (E < -6) {                                                // subnormal range: multiples of 2^-9
+    const int m = (int)std::nearbyint(std::ldexp(mag, 9));     // 0 .. 8
+    return sign | (uint8_t)(m >= 8 ? 0x08 : m);                // 8 * 2^-9 = 2^-6: the smallest normal
+  }
+  int m = (int)std::nearbyint(std::ldexp(mag, 3 - E)) - 8;     // mantissa 0 .. 8
+  if (m == 8) {
+    m = 0;
+    ++E;
+  }
+  const int code = ((E + 7) << 3) | m;
+  return sign | (uint8_t)(code > 0x7E ? 0x7E : code);
+}
+
 int prescale_exp(float amax) {
   if (!(amax > 0.0f) || !std::isfinite(amax)) return 0;
   int e = 0;
@@ -270,6 +291,26 @@ void Engine::dfree(void* p) {
   if (it != allocs_.end()) allocs_.erase(it);
   hipFree(p);
 }
+void Engine::upload_fc_weights(FcParams* fp, const std::vector<float>& w, int N, int K, const std::vector<float>* row_amax) {
+  if (w.size() != (size_t)N * K) throw std::runtime_error("FC weight size mismatch");
+  if (!fp8_weights() || (K & 3) != 0) {
+    fp->w = dupload(w);
+    wbytes_[2] += 4 * w.size();
+    return;
+  }
+  std::vector<uint8_t> codes((size_t)N * K);
+  std::vector<float> scale(N);
+  for (int n = 0; n < N; ++n) {
+    float amax = row_amax ? (*row_amax)[n] : 0.0f;
+    if (!row_amax)
+      for (int k = 0; k < K; ++k) amax = std::max(amax, std::fabs(w[(size_t)n * K + k]));
+    scale[n] = fp8_row_scale(amax);
+    for (int k = 0; k < K; ++k) codes[(size_t)n * K + k] = e4m3_encode(w[(size_t)n * K + k] / scale[n]);
+  }
+  fp->w8 = dupload(codes);
+  fp->wscale8 = dupload(scale);
+  wbytes_[0] += codes.size();
+}
 const void* Engine::zero_page() {
   if (!d_zero_) d_zero_ = dalloc(256, true);
   return d_zero_;
@@ -437,6 +478,8 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
           mp.in = x->view();
           mp.w_hi = dupload(wh);
           mp.w_lo = split() ? dupload(wlo) : nullptr;
+          wbytes_[1] += 2 * wh.size() * (split() ? 2 : 1);
+          wbytes_[2] += 4 * wk.size();
           mp.b_exp = dupload(be);
           mp.s_exp = dupload(rs.post);
           mp.w_dw = dupload(wk);
@@ -546,6 +589,7 @@ std::vector<Act*> Engine::build_backbone(const WeightBlob& blob, const std::stri
         mb.b2 = se_b2;
         mb.sqp = sqp;
         mb.w = dupload(wf);
+        wbytes_[2] += 4 * (wf.size() + w2q.size());
         mb.bias = dupload(bias);
         mb.wscale = dupload(rs.post);
         if (residual) mb.res = x->view();
@@ -648,7 +692,7 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
     if (w.shape[0] != widths[i] || w.shape[1] != K) throw std::runtime_error("context MLP shape mismatch: " + lp);
     FcParams fp{};
     fp.x = x;
-    fp.w = dupload(w.data);
+    upload_fc_weights(&fp, w.data, widths[i], K);
     fp.b = dupload(b.data);
     fp.N = widths[i];
     fp.K = K;
@@ -663,7 +707,7 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
     Op op;
     op.name = lp;
     op.flops = 2.0 * widths[i] * K;
-    op.bytes = 4.0 * widths[i] * K;
+    op.bytes = (fp.w8 ? 1.0 : 4.0) * widths[i] * K;
     op.run = [fp](hipStream_t st) { return launch_fc(fp, st); };
     ops_.push_back(std::move(op));
     x = fp.out;
@@ -943,11 +987,14 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     const HostTensor& ew = T(cp + ".exp0.weight");
     const HostTensor& eb = T(cp + ".exp0.bias");
     if (ew.shape.size() != 3 || ew.shape[0] != HW || ew.shape[1] != C || ew.shape[2] != 3) throw std::runtime_error("exp0 shape mismatch: " + cp);
-    std::vector<float> wm((size_t)HW * a->C, 0.0f);
+    std::vector<float> wm((size_t)HW * a->C, 0.0f), row_amax(HW, 0.0f);
     for (int n = 0; n < HW; ++n)
-      for (int c = 0; c < C; ++c) wm[(size_t)n * a->C + c] = ew.data[((size_t)n * C + c) * 3 + 1];
+      for (int c = 0; c < C; ++c) {
+        wm[(size_t)n * a->C + c] = ew.data[((size_t)n * C + c) * 3 + 1];
+        for (int t = 0; t < 3; ++t) row_amax[n] = std::max(row_amax[n], std::fabs(ew.data[((size_t)n * C + c) * 3 + t]));   // the quantiser's row: all three taps
+      }
     FcParams fp{};
-    fp.w = dupload(wm);
+    upload_fc_weights(&fp, wm, HW, a->C, &row_amax);
     fp.b = dupload(eb.data);
     fp.N = HW;
     fp.K = a->C;
@@ -957,7 +1004,7 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     fp.nslab = nslab;
     fp.Kstride = a->C;
     fp.inv_hw = 1.0f / (float)HW;
-    push(cp + ".exp0", "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, 4.0 * HW * C);
+    push(cp + ".exp0", "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, (fp.w8 ? 1.0 : 4.0) * HW * C);
     // ctx0: conv3x3 1 -> C/2 + SiLU (:216-217)
     const HostTensor& w0 = T(cp + ".ctx0.weight");
     const HostTensor& b0 = T(cp + ".ctx0.bias");
@@ -1097,13 +1144,13 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     if (w.shape[1] != K) throw std::runtime_error("linear shape mismatch: " + name);
     FcParams fp{};
     fp.x = in;
-    fp.w = dupload(w.data);
+    upload_fc_weights(&fp, w.data, w.shape[0], K);
     fp.b = dupload(b.data);
     fp.N = w.shape[0];
     fp.K = K;
     fp.act = act;
     fp.out = out ? out : static_cast<float*>(dalloc((size_t)w.shape[0] * sizeof(float)));
-    push(name, "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * fp.N * K, 4.0 * fp.N * K);
+    push(name, "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * fp.N * K, (fp.w8 ? 1.0 : 4.0) * fp.N * K);
     return fp.out;
   };
   const float* f1 = fc("head.fc1.0", v0, flat, ACT_SILU, nullptr);

@@ -183,6 +183,8 @@ class Engine {
   bool split() const { return (precision_ & 15) == 1; }
   bool fp8_weights() const { return (precision_ & 16) != 0; }
   int shared_level() const { return shared_level_; }  // 0 own network, 1 backbone shared, 2 backbone + context + neck shared
+  // device bytes of the network's WEIGHT tensors by storage class (bias / scale vectors and tables not counted): [0] e4m3 codes, [1] fp16 planes, [2] fp32
+  const unsigned long long* weight_bytes() const { return wbytes_; }
 
   std::string last_error;
 
@@ -191,7 +193,8 @@ class Engine {
     half_t* w_hi = nullptr;
     half_t* w_lo = nullptr;
     float* bias = nullptr;
-    float* wscale = nullptr;  // [CoutW] 2^-prescale of the weight rows (engine_internal.hpp prescale_exp)
+    float* wscale = nullptr;  // [CoutW] 2^-prescale of the weight rows (engine_internal.hpp prescale_exp), or the fp8 row scales
+    uint8_t* w8 = nullptr;    // VP_WEIGHTS_FP8 on a kernel that stages weights through registers: e4m3 codes in that kernel's layout (w_hi / w_lo null)
     int CoutW = 0, tile = 0, bk = 32, nsplit = 1;
   };
   void construct(int kind, const WeightBlob* blob, int precision, int gpu_id, Engine* base);
@@ -203,6 +206,9 @@ class Engine {
   const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)
   template <class T>
   T* dupload(const std::vector<T>& v);
+  // FC matrix [N][K] -> fp32 rows, or (VP_WEIGHTS_FP8) e4m3 codes + row scales.  row_amax: per-row maximum the quantiser saw when it is not the
+  // maximum of the K values handed in (AutoDrive's exp0: a row's three Conv1d taps share one scale, only the centre tap is used), else null
+  void upload_fc_weights(FcParams* fp, const std::vector<float>& w, int N, int K, const std::vector<float>* row_amax = nullptr);
   int gemm_dma_nsplit(int M, int ncols, int kw) const;
   bool gemm_dma_wanted(int H, int W, int ncols, int cin_pad, int cin2_pad, int cstore) const;
   void choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc);
@@ -231,6 +237,7 @@ class Engine {
   size_t ad_shift_op_ = 0, ad_place_op_ = 0;  // AutoDrive: ops_[shift] moves curr->prev features, ops_[place] stores the new ones
   bool ad_primed_ = false;
   std::vector<void*> allocs_;
+  unsigned long long wbytes_[3] = {0, 0, 0};
   std::vector<std::unique_ptr<Act>> acts_;
   std::vector<Op> ops_;
   size_t first_net_op_ = 0;  // ops_[0] is the preprocess op (skipped for vp_infer_tensor)

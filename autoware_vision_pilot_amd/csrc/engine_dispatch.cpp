@@ -61,6 +61,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.w_lo = pc.w_lo;
   p.bias = pc.bias;
   p.wscale = pc.wscale;
+  p.w8 = pc.w8;
   p.ks = ks;
   p.Ncols = ncols;
   p.CoutW = pc.CoutW;
@@ -96,8 +97,8 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   op.name = name;
   op.flops = 2.0 * M * (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks;
   const double esz = sp ? 4.0 : 2.0;
-  op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real +
-                    (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
+  op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real) +
+             (pc.w8 ? 1.0 : esz) * ((double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks);
   if (o.in2) {  // fused skip-link: extra K columns read at every OUTPUT pixel
     op.flops += 2.0 * M * 4.0 * cout_real * o.in2->Creal;
     op.bytes += esz * ((double)M * 4.0 * o.in2->Creal + (double)cout_real * o.in2->Creal);
@@ -352,8 +353,20 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   } else {
     choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
   }
-  std::vector<half_t> hi((size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
-  const RowScale rs = row_prescale(w.data(), cout, (size_t)cin * taps, pc.CoutW);
+  // VP_WEIGHTS_FP8: real e4m3 storage where the layer's kernel stages its weights through registers (the generic GEMM kernel and the halo
+  // kernel's tiles 0-5: every matrix layer of AutoDrive); the LDS-DMA / register-stationary kernels copy weight images verbatim and keep
+  // de-quantised fp16 planes
+  const bool w8 = fp8_weights() && (halo < 0 || halo <= 5);
+  std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo((split() && !w8) ? hi.size() : 0, (half_t)0.0f);
+  std::vector<uint8_t> codes(w8 ? (size_t)taps * pc.CoutW * cin_pad : 0, (uint8_t)0);
+  RowScale rs = row_prescale(w.data(), cout, (size_t)cin * taps, pc.CoutW);
+  if (w8)   // the rows' quantisation scales instead of the power-of-two prescale (e4m3 values need none: |q| in [2^-9, 448] are normal fp16 numbers)
+    for (int co = 0; co < cout; ++co) {
+      float amax = 0.0f;
+      for (size_t i = 0; i < (size_t)cin * taps; ++i) amax = std::max(amax, std::fabs(w[(size_t)co * cin * taps + i]));
+      rs.post[co] = fp8_row_scale(amax);
+      rs.pre[co] = 1.0f / rs.post[co];
+    }
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int t = 0; t < taps; ++t) {
@@ -365,6 +378,11 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         const size_t d = halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)
                          : halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
+        if (w8) {
+          if (!(std::fabs(v) <= 65504.0f)) throw RangeError("weight " + std::to_string(v) + " is outside the fp16 range the matrix pipe carries (|w| <= 65504): re-scale the checkpoint");
+          codes[d] = e4m3_encode(v / rs.post[co]);   // v / S is on the e4m3 grid up to the fold's float rounding: the nearest code IS the quantiser's
+          continue;
+        }
         half_t h, l;
         split_half(v, rs.pre[co], &h, &l);
         hi[d] = h;
@@ -372,8 +390,14 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       }
   std::vector<float> bias(pc.CoutW, 0.0f);
   for (int co = 0; co < cout; ++co) bias[co] = b[co];
-  pc.w_hi = dupload(hi);
-  pc.w_lo = split() ? dupload(lo) : nullptr;
+  if (w8) {
+    pc.w8 = dupload(codes);
+    wbytes_[0] += codes.size();
+  } else {
+    pc.w_hi = dupload(hi);
+    pc.w_lo = split() ? dupload(lo) : nullptr;
+    wbytes_[1] += 2 * (hi.size() + lo.size());
+  }
   pc.bias = dupload(bias);
   pc.wscale = dupload(rs.post);
   Act* out = nullptr;
@@ -458,6 +482,7 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
     }
   pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
+  wbytes_[1] += 2 * (hi.size() + lo.size());
   pc.bias = dupload(bias);
   pc.wscale = dupload(post);
   push_conv_op(name, in, pc, 1, ncols, o, out, STORE_SHUFFLE2, cout);
@@ -529,6 +554,7 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
     }
  pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
+  wbytes_[1] += 2 * (hi.size() + lo.size());
   pc.bias = dupload(bias);
   pc.wscale = dupload(post);
   push_conv_op(up_name + "+" + skip_name.substr(skip_name.rfind('.') == std::string::npos ? 0 : skip_name.rfind('.') + 1), in, pc, 1, ncols, o,

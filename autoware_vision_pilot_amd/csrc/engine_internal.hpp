@@ -40,6 +40,14 @@ struct RowScale {
 // rows x per (contiguous rows) -> scales; rows_alloc >= rows entries in `post`
 RowScale row_prescale(const float* w, size_t rows, size_t per, size_t rows_alloc);
 
+// ---- VP_WEIGHTS_FP8, real storage (round 4).  WeightBlob::quantize_fp8_e4m3 leaves every conv / linear weight as v = q * S with q on the OCP
+// e4m3 grid and |q| <= 448 per output row.  Whatever per-row factor has been applied since (BatchNorm folding), the row's scale is recovered
+// from its maximum -- the maximum element is +-448 by construction -- and each element's code by rounding v / S to the nearest grid value:
+// the float rounding of the fold is ~1e-7 against a grid spacing of >= 6 %, so the recovery is exact.  The kernels then carry the CODES
+// (one byte per weight in HBM) and multiply the fp32 accumulator by S in the epilogue (ConvGemmParams::wscale).
+uint8_t e4m3_encode(float q);                                  // nearest OCP e4m3 code of q (|q| <= 448)
+inline float fp8_row_scale(float amax) { return amax > 0.0f ? amax / 448.0f : 1.0f; }
+
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));

@@ -159,6 +159,10 @@ constexpr int kDetectMaxBoxes = 16384;
 struct FcParams {
   const float* x;
   const float* w;  // [N][K]
+  // VP_WEIGHTS_FP8, real storage (round 4): when non-null the matrix is OCP e4m3 CODES [N][K] (one byte per weight; w is null) and
+  // wscale8[n] the row's quantisation scale: out[n] = act(b[n] + wscale8[n] * sum_k q[n][k] x[k])
+  const uint8_t* w8;
+  const float* wscale8;
   const float* b;
   float* out;
   int N, K, act;

@@ -295,16 +295,26 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   for (int r = 0; r < 2; ++r) {
     const int n = blockIdx.x * 8 + wave * 2 + r;
     if (n >= p.N) continue;
-    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w + (size_t)n * p.K);
     float s = 0.f;
+    if (p.w8) {   // fp8 storage: four codes per lane and step (a quarter of the fp32 row's bytes), the row scale applied once at the end
+      const unsigned* wr8 = reinterpret_cast<const unsigned*>(p.w8 + (size_t)n * p.K);
 #pragma unroll 6
-    for (int k = lane; k < K4; k += 64) {
-      const f32x4_t a = wr[k], m = x4[k];
-      s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+      for (int k = lane; k < K4; k += 64) {
+        const unsigned c4 = wr8[k];
+        const f32x4_t m = x4[k];
+        s += (e4m3_to_float(c4 & 0xffu) * m[0] + e4m3_to_float((c4 >> 8) & 0xffu) * m[1]) + (e4m3_to_float((c4 >> 16) & 0xffu) * m[2] + e4m3_to_float(c4 >> 24) * m[3]);
+      }
+    } else {
+      const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w + (size_t)n * p.K);
+#pragma unroll 6
+      for (int k = lane; k < K4; k += 64) {
+        const f32x4_t a = wr[k], m = x4[k];
+        s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) p.out[n] = apply_act(s + p.b[n], p.act);
+    if (lane == 0) p.out[n] = apply_act((p.w8 ? s * p.wscale8[n] : s) + p.b[n], p.act);
   }
 }
 

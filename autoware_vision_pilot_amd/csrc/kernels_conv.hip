@@ -130,8 +130,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     if constexpr (K1) { /* 1x1 / ConvTranspose GEMM: no tap arithmetic, 32-bit offsets, one add per load */   \
       const int c0_ = s_ * BK;                                                                                \
       _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
-        ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + (a_off32[i] + c0_));                        \
-        if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + (a_off32[i] + c0_));   \
+        if (__builtin_expect(p.w8 != nullptr, 0)) { /* fp8 storage: 8 bytes, converted at the LDS store (wave-uniform branch) */ \
+          const vp_u32x2 r8_ = *reinterpret_cast<const vp_u32x2*>(p.w8 + (a_off32[i] + c0_));                       \
+          ra_hi[SLOT][i] = u32x4{r8_[0], r8_[1], 0u, 0u};                                                       \
+        } else {                                                                                              \
+          ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + (a_off32[i] + c0_));                      \
+          if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + (a_off32[i] + c0_)); \
+        }                                                                                                     \
       }                                                                                                       \
       const bool sec_ = c0_ >= p.Cin; /* wave-uniform: this K step reads the extension tensor */              \
       _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) {                                                   \
@@ -153,8 +158,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     const int dy_ = ky_ - half_k, dx_ = (tap_ - ky_ * p.ks) - half_k;                                         \
     const size_t wbase_ = (size_t)tap_ * p.CoutW * p.Cin + c0_;                                               \
     _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
-      ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + wbase_ + a_off[i]);                           \
-      if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + wbase_ + a_off[i]);      \
+      if (__builtin_expect(p.w8 != nullptr, 0)) {                                                             \
+        const vp_u32x2 r8_ = *reinterpret_cast<const vp_u32x2*>(p.w8 + wbase_ + a_off[i]);                          \
+        ra_hi[SLOT][i] = u32x4{r8_[0], r8_[1], 0u, 0u};                                                         \
+      } else {                                                                                                \
+        ra_hi[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_hi + wbase_ + a_off[i]);                         \
+        if constexpr (SPLIT) ra_lo[SLOT][i] = *reinterpret_cast<const u32x4*>(p.w_lo + wbase_ + a_off[i]);    \
+      }                                                                                                       \
     }                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) {                                                     \
       const int yy_ = b_y[i] * cstride + dy_, xx_ = b_x[i] * cstride + dx_;                                   \
@@ -173,8 +183,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   {                                                                                                           \
     char* st_ = smem + (BUF) * STAGE;                                                                         \
     _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
-      *reinterpret_cast<u32x4*>(st_ + OFF_AHI + a_lds[i]) = ra_hi[SLOT][i];                                   \
-      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st_ + OFF_ALO + a_lds[i]) = ra_lo[SLOT][i];              \
+      if (__builtin_expect(p.w8 != nullptr, 0)) {                                                             \
+        *reinterpret_cast<u32x4*>(st_ + OFF_AHI + a_lds[i]) = e4m3x8_to_half8(ra_hi[SLOT][i][0], ra_hi[SLOT][i][1]); \
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st_ + OFF_ALO + a_lds[i]) = zero4;                     \
+      } else {                                                                                                \
+        *reinterpret_cast<u32x4*>(st_ + OFF_AHI + a_lds[i]) = ra_hi[SLOT][i];                                 \
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st_ + OFF_ALO + a_lds[i]) = ra_lo[SLOT][i];            \
+      }                                                                                                       \
     }                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < B_ITERS; ++i) if (B_CHUNKS % 256 == 0 || tid + 256 * i < B_CHUNKS) { \
       *reinterpret_cast<u32x4*>(st_ + OFF_BHI + b_lds[i]) = rb_hi[SLOT][i];                                   \

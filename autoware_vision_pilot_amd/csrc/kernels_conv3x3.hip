@@ -140,16 +140,26 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
     const int si_ = (SIDX) < s_last ? (SIDX) : s_last; /* clamped: loads stay unconditional */         \
     const size_t base_ = (size_t)si_ * w_step;                                                        \
     _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
-      rw_hi[SLOT][pc] = *reinterpret_cast<const u32x4*>(p.w_hi + base_ + w_goff[pc]);                 \
-      if constexpr (SPLIT) rw_lo[SLOT][pc] = *reinterpret_cast<const u32x4*>(p.w_lo + base_ + w_goff[pc]); \
+      if (__builtin_expect(p.w8 != nullptr, 0)) { /* fp8 storage: 8 bytes instead of 16, converted at the LDS store (wave-uniform branch) */ \
+        const vp_u32x2 r8_ = *reinterpret_cast<const vp_u32x2*>(p.w8 + base_ + w_goff[pc]);                 \
+        rw_hi[SLOT][pc] = u32x4{r8_[0], r8_[1], 0u, 0u};                                                \
+      } else {                                                                                        \
+        rw_hi[SLOT][pc] = *reinterpret_cast<const u32x4*>(p.w_hi + base_ + w_goff[pc]);               \
+        if constexpr (SPLIT) rw_lo[SLOT][pc] = *reinterpret_cast<const u32x4*>(p.w_lo + base_ + w_goff[pc]); \
+      }                                                                                               \
     }                                                                                                 \
   }
 #define VP_STORE_W(SLOT, BUF)                                                                         \
   {                                                                                                   \
     char* dst_ = w_base + (BUF) * NPL * W_BYTES;                                                      \
     _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
-      *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = rw_hi[SLOT][pc];                                  \
-      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = rw_lo[SLOT][pc];   \
+      if (__builtin_expect(p.w8 != nullptr, 0)) {                                                     \
+        *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = e4m3x8_to_half8(rw_hi[SLOT][pc][0], rw_hi[SLOT][pc][1]); \
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = zero4;           \
+      } else {                                                                                        \
+        *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = rw_hi[SLOT][pc];                                \
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = rw_lo[SLOT][pc]; \
+      }                                                                                               \
     }                                                                                                 \
   }
   // out-of-image halo pixels: load from offset 0 (always valid) and zero the value, so the access stays a plain

@@ -226,7 +226,7 @@ int convt_rs_shape_case(int H, int W, int cin_pad, int cin2_pad, int ncols, int 
   return 0;
 }
 
-bool convt_rs_supported(const ConvGemmParams& p, bool split) { return split == (p.in_lo != nullptr) && split == (p.out_lo != nullptr) && rs_case(p) != 0; }
+bool convt_rs_supported(const ConvGemmParams& p, bool split) { return p.w_hi != nullptr && split == (p.in_lo != nullptr) && split == (p.out_lo != nullptr) && rs_case(p) != 0; }
 
 hipError_t launch_convt_rs(const ConvGemmParams& p, hipStream_t st) {
   const bool split = p.in_lo != nullptr;

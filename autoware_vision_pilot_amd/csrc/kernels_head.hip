@@ -192,7 +192,8 @@ hipError_t launch_head_cfg(const ConvGemmParams& p, const half_t* zeros, hipStre
 
 bool head_conv_supported(const ConvGemmParams& p) {
   return p.ks == 3 && p.stride <= 1 && p.store_mode == STORE_NCHW_F32 && p.act == ACT_NONE && p.res_mode == RES_NONE && p.post_act == ACT_NONE &&
-         p.nsplit == 1 && p.Cin2 == 0 && (p.Cin == 64 || p.Cin == 128) && p.Creal >= 1 && p.Creal <= 4 && p.CoutW >= 16 && p.out_f32 != nullptr;
+         p.nsplit == 1 && p.Cin2 == 0 && (p.Cin == 64 || p.Cin == 128) && p.Creal >= 1 && p.Creal <= 4 && p.CoutW >= 16 && p.out_f32 != nullptr &&
+         p.w_hi != nullptr;   // fp16 planes (an fp8-storage layer stays on the halo kernel)
 }
 
 // zeros: >= 16 bytes of zeros in device memory (the engine's zero page)

@@ -478,6 +478,14 @@ unsigned long long vp_plan_hash(const vp_engine* e) {
   }
   return h ? h : 1;
 }
+int vp_weight_bytes(const vp_engine* e, unsigned long long* fp8_bytes, unsigned long long* fp16_bytes, unsigned long long* fp32_bytes) {
+  if (!e || !e->impl) return VP_ERR_ARG;
+  const unsigned long long* w = e->impl->weight_bytes();
+  if (fp8_bytes) *fp8_bytes = w[0];
+  if (fp16_bytes) *fp16_bytes = w[1];
+  if (fp32_bytes) *fp32_bytes = w[2];
+  return VP_OK;
+}
 // host only: the (hi, lo) fp16 planes and the per-row 2^-s the engine makes of a weight matrix (engine.cpp row_prescale + split_half)
 int vp_split_weight_rows(const float* w, int rows, int per_row, uint16_t* hi, uint16_t* lo, float* post_scale) {
   if (!w || rows < 1 || per_row < 1 || !hi || !lo || !post_scale) return VP_ERR_ARG;

@@ -102,6 +102,7 @@ _SIGS = {
     "vp_get_option": (C.c_char_p, [C.c_char_p]),
     "vp_clear_options": (None, []),
     "vp_plan_hash": (C.c_ulonglong, [_P]),
+    "vp_weight_bytes": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "vp_split_weight_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
@@ -305,6 +306,12 @@ class Engine:
 
     def plan_hash(self):
         return int(self._lib.vp_plan_hash(self._h))
+
+    def weight_bytes(self):
+        """Device bytes of the weight tensors by storage class: {'fp8': e4m3 codes, 'fp16': fp16 planes, 'fp32': fp32 rows} (vp_weight_bytes)."""
+        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+        self._ck(self._lib.vp_weight_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"fp8": a.value, "fp16": b.value, "fp32": c.value}
 
     def input_hw(self):
         h, w = C.c_int(), C.c_int()

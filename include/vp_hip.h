@@ -57,9 +57,15 @@ enum vp_model_kind { VP_SCENESEG = 0, VP_SCENE3D = 1, VP_DOMAINSEG = 2, VP_EGOLA
  * VP_FP16X3: fp32-class accuracy on the fp16 matrix pipe: every tensor is a (hi, lo) fp16 pair and every
  *            product is three MFMAs (hi*hi + hi*lo + lo*hi), fp32 accumulate -- the parity mode (1e-3). */
 enum vp_precision { VP_FP16 = 0, VP_FP16X3 = 1,
-                    /* OR-able flag: every conv / linear weight is quantised at load to per-output-channel OCP e4m3 (fp8) and
-                     * de-quantised for the fp16 / fp16x3 matrix pipe (BASELINE configs[4] "fp8 weights"; the reference's
-                     * PTQ flow: Models/exports/quantization/PTQ/AutoDrive) */
+                    /* OR-able flag: every conv / linear weight is quantised at load to per-output-row OCP e4m3 (fp8) (BASELINE
+                     * configs[4] "fp8 weights"; the reference's PTQ flow: Models/exports/quantization/PTQ/AutoDrive).  Round 4: it is
+                     * STORAGE, not only numerics -- on the kernels that stage weights through registers (the generic GEMM kernel, the
+                     * 3x3 halo kernel, the FC kernel: every matrix / FC layer of VP_AUTODRIVE) HBM holds one e4m3 byte per weight plus
+                     * a per-row fp32 scale; the staging path converts 8 codes -> 8 fp16 values on their way to LDS (exact: every e4m3
+                     * value is an fp16 value) and the epilogue applies the scale to the fp32 accumulator.  The arithmetic stays the
+                     * fp16 matrix pipe with fp16 / (hi, lo) activations (fp8 MFMA would quantise the ACTIVATIONS to 3 mantissa bits:
+                     * outside the 1e-3 bar).  Layers on the LDS-DMA / register-stationary kernels of the scene networks keep
+                     * de-quantised fp16 planes.  vp_weight_bytes reports the split. */
                     VP_WEIGHTS_FP8 = 16 };
 
 enum vp_pixel_format { VP_BGR8 = 0, VP_RGB8 = 1 };
@@ -319,6 +325,10 @@ int vp_set_option(const char* key, const char* value);
 const char* vp_get_option(const char* key);       /* NULL when unset */
 void vp_clear_options(void);
 unsigned long long vp_plan_hash(const vp_engine* e);
+/* Device bytes of an engine's matrix / FC WEIGHT tensors by storage class: OCP e4m3 codes (VP_WEIGHTS_FP8 on the kernels that convert on
+ * the fly), fp16 planes ((hi, lo) pairs in the parity mode), fp32 (FC rows, the fused MBConv projection / depthwise filters).  Bias and
+ * scale vectors, tables and activations are not counted.  Any pointer may be NULL. */
+int vp_weight_bytes(const vp_engine* e, unsigned long long* fp8_bytes, unsigned long long* fp16_bytes, unsigned long long* fp32_bytes);
 /* host only (tests / external checks): the (hi, lo) fp16 planes the engine makes of a weight matrix [rows][per_row] and the per-row
  * 2^-s of its power-of-two prescale: fp32(hi) + fp32(lo) = w * 2^s with the row maximum in [2^13, 2^14), post_scale[r] = 2^-s.
  * VP_ERR_RANGE for a weight beyond the fp16 range, as vp_create*. */

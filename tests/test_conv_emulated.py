@@ -221,3 +221,36 @@ def test_map_kernel(emu_lib):
     with pytest.raises(emu_lib.VpError):
         x = np.zeros((32, 16, 40), np.float32)
         emu_lib.op_conv2d(x, np.zeros((32, 32, 3, 3), np.float32), np.zeros(32, np.float32), ks=3, precision=1, tile=111, nsplit=1)   # 16 rows: not a region multiple
+
+
+def _q_e4m3(w):
+    """oracle/autodrive.py quantize_fp8_e4m3 on one weight tensor: per-output-row symmetric OCP e4m3, returned de-quantised (fp32)."""
+    from oracle import autodrive
+
+    return autodrive.quantize_fp8_e4m3({"x.weight": w})["x.weight"]
+
+
+@pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])
+def test_fp8_weight_storage(emu_lib, precision):
+    """VP_WEIGHTS_FP8 as STORAGE (round 4): on the kernels that stage weights through registers (generic GEMM kernel, halo kernel) the engine keeps
+    one e4m3 BYTE per weight + a row scale in HBM and converts on the way to LDS.  The codes and scales are recovered from the de-quantised blob
+    values, so the result must equal a convolution with exactly those values: against torch on the quantised weights, at the tolerance of
+    un-quantised weights (fp16x3: 2e-5 -- a single wrong code would show at 6e-2 of a weight) -- 3x3 (halo tiles, split-K), 1x1, strided 3x3,
+    ragged channels, rows scaled after quantisation as a BatchNorm fold does, and a row of tiny values (subnormal codes)."""
+    rng = np.random.default_rng(700 + precision)
+    tol = 2e-5 if precision == 1 else 3e-3
+    q = (lambda a: a) if precision == 1 else _h
+    for ks, cin, cout, h, w, tile, nsplit in ((3, 48, 72, 11, 21, -1, -1), (3, 96, 40, 16, 16, 103, 2), (1, 80, 200, 9, 15, -1, -1), (3, 32, 32, 8, 16, 104, 1)):
+        wt = (rng.standard_normal((cout, cin, ks, ks)) * np.sqrt(2.0 / (cin * ks * ks))).astype(np.float32)
+        wt[1] *= np.float32(1e-4)                                                 # a row whose codes are mostly e4m3 subnormals after scaling? no: scaled per row -- kept as a plain small row
+        wq = _q_e4m3(wt)
+        fold = (0.5 + rng.random(cout)).astype(np.float32) * np.where(rng.random(cout) < 0.3, -1.0, 1.0).astype(np.float32)
+        wq = (wq * fold[:, None, None, None]).astype(np.float32)                   # what BatchNorm folding does to a quantised row (incl. a sign flip)
+        b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        x = rng.standard_normal((cin, h, w)).astype(np.float32)
+        ref = F.conv2d(torch.from_numpy(q(x)).double()[None], torch.from_numpy(wq).double(), torch.from_numpy(b).double(), padding=ks // 2)[0].float().numpy()
+        got = emu_lib.op_conv2d(x, wq, b, ks=ks, precision=precision | 16, tile=tile, nsplit=nsplit)
+        err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+        assert got.shape == ref.shape and err <= tol, (ks, cin, cout, err)
+        plain = emu_lib.op_conv2d(x, wq, b, ks=ks, precision=precision, tile=tile, nsplit=nsplit)   # the same values as (hi, lo) fp16 planes
+        assert float((np.abs(got - plain) / np.maximum(1.0, np.abs(plain))).max()) <= (2e-5 if precision == 1 else 2e-3)

@@ -55,6 +55,26 @@ def test_autodrive_engine_end_to_end_on_cpu(emu_lib):
         eng.close()
 
 
+def test_autodrive_fp8_storage_parity_mode_on_cpu(emu_lib):
+    """BASELINE configs[4] with the fp8 weights as REAL storage (round 4): every conv / linear weight of the plan is one e4m3 byte + a row scale in
+    HBM (conv_gemm / halo kernels and the FC kernel convert on the fly), activations in the parity mode -- against the reference module's outputs on
+    the same fp8-dequantised weights, at the parity bar (the GPU test's contract, tests/test_gpu_autodrive.py)."""
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+
+    g = np.load(GOLDEN)
+    frames = [synthetic.synthetic_frame(1080, 1920, int(s)) for s in g["frame_seeds"]]
+    eng = emu_lib.Engine("autodrive", vw.pack_state_dict(synthetic.make_autodrive_state_dict(int(g["weight_seed"]))), precision="fp16x3", weights_fp8=True)
+    try:
+        eng.infer_pair(frames[0], frames[1])
+        got = eng.logits().reshape(3)
+        assert np.abs(got - g["fp8_out"]).max() <= 1e-3, (got, g["fp8_out"])
+        wb = eng.weight_bytes()
+        # every matrix / FC weight of the plan is e4m3 bytes: 6.6 MB (exp0's Conv1d keeps only the centre tap of its three), no fp16 plane, no fp32 row
+        assert wb["fp8"] > 6e6 and wb["fp16"] == 0 and wb["fp32"] == 0, wb
+    finally:
+        eng.close()
+
+
 def test_autodrive_from_onnx_path_fp8_fp16_on_cpu(emu_lib, tmp_path):
     """vp_create on a `*.onnx` model_path (native reader, exporter-folded Conv+BN form), VP_WEIGHTS_FP8, the fp16 engine and
     the streaming vp_infer form -- BASELINE configs[4] as deployed -- against the reference-pinned fp8 golden outputs."""

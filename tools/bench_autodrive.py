@@ -36,6 +36,8 @@ for _ in range(50):
     t1 = time.perf_counter(); engs[0].enqueue(); engs[0].sync(); lat.append((time.perf_counter() - t1) * 1e3)
 fps = a.steps / dt
 print(json.dumps({"metric": "frames/sec, AutoDrive 1920x1080 streaming (BASELINE configs[4])", "value": round(fps, 1), "unit": "frames/s",
-                  "precision": a.precision, "weights": "fp32" if a.no_fp8 else "fp8-e4m3 per channel (dequantised at load)",
+                  "precision": a.precision,
+                  "weights": "fp32 checkpoint -> fp16 planes" if a.no_fp8 else "fp8: one OCP e4m3 byte per weight + per-row fp32 scale in HBM, converted in the weight-staging path (round 4)",
+                  "weight_bytes": engs[0].weight_bytes(), "library": lib.version(), "plan_hash": f"{engs[0].plan_hash():016x}",
                   "frames_in_flight": a.streams, "p50_ms": round(float(np.percentile(lat, 50)), 3),
                   "gflop_per_frame": 8.1, "launches_per_frame": len(engs[0].layers())}))
