@@ -293,7 +293,7 @@ void Engine::dfree(void* p) {
 }
 void Engine::upload_fc_weights(FcParams* fp, const std::vector<float>& w, int N, int K, const std::vector<float>* row_amax) {
   if (w.size() != (size_t)N * K) throw std::runtime_error("FC weight size mismatch");
-  if (!fp8_weights() || (K & 3) != 0) {
+  if (!fp8_storage() || (K & 3) != 0) {
     fp->w = dupload(w);
     wbytes_[2] += 4 * w.size();
     return;

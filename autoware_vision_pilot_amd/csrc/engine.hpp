@@ -182,6 +182,9 @@ class Engine {
   bool host_logits_current() const { return host_logits_valid_; }  // the pinned host logits belong to the LAST pass
   bool split() const { return (precision_ & 15) == 1; }
   bool fp8_weights() const { return (precision_ & 16) != 0; }
+  // ... kept as e4m3 BYTES in HBM (round 4): AutoDrive engines (BASELINE configs[4]) and the operator entry; a scene network with the flag keeps
+  // de-quantised fp16 planes on its LDS-DMA / register-stationary kernels
+  bool fp8_storage() const { return fp8_weights() && (kind_ == 4 || kind_ < 0); }
   int shared_level() const { return shared_level_; }  // 0 own network, 1 backbone shared, 2 backbone + context + neck shared
   // device bytes of the network's WEIGHT tensors by storage class (bias / scale vectors and tables not counted): [0] e4m3 codes, [1] fp16 planes, [2] fp32
   const unsigned long long* weight_bytes() const { return wbytes_; }

@@ -171,9 +171,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       return;
     }
     // ",regepi": the register-GELU single-pass epilogue instantiation (same condition as launch_halo_cfg)
-    const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1;
+    const bool regepi = !sp && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1 && !p.w8;
     op.kernel = "conv3x3_halo<co" + std::to_string(halo_tile_co(ht)) + ",px" + std::to_string(halo_tile_px(ht)) + (sp ? ",x3" : ",x1") +
-                (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
+                (p.w8 ? ",w8" : "") + (regepi ? ",regepi>" : ">") + (pc.nsplit > 1 ? "+splitk" : "");
     if (fuse_decode) {
       op.kernel += "+decode";
       op.run = [this, p, ht, sp](hipStream_t st) {
@@ -195,9 +195,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
     op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
   } else {
-    const int epi = (ks == 1 && !sp) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
+    const int epi = (ks == 1 && !sp && !p.w8) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
     op.kernel = "conv_gemm<bk" + std::to_string(bk) + ",co" + std::to_string(conv_tile_co(tile)) + ",px" +
-                std::to_string(conv_tile_px(tile)) + (sp ? ",x3" : ",x1") + (epi ? ",regepi" + std::to_string(epi) + ">" : ">") +
+                std::to_string(conv_tile_px(tile)) + (sp ? ",x3" : ",x1") + (p.w8 ? ",w8" : "") + (epi ? ",regepi" + std::to_string(epi) + ">" : ">") +
                 (pc.nsplit > 1 ? "+splitk" : "");
     if (fuse_decode) {
       op.kernel += "+decode";
@@ -282,6 +282,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
                             conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
         halo = 11;
     }
+    // VP_WEIGHTS_FP8 as storage (AutoDrive engines and the operator entry): the halo kernel's 8x16-pixel tiles of 64 / 32 channels are the ones
+    // instantiated with the byte-weight staging path (kernels_conv3x3.hip W8)
+    if (fp8_storage() && o.tile < 0 && halo >= 0) halo = ncols <= 32 ? 4 : 3;
     if (halo == 11 && (!split() || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
       throw std::invalid_argument("halo tile 11 (map kernel): fp16x3, maps that tile into 20x40 or 10x20 regions, >= 32 input channels: " + name);
     if (halo >= 6 && halo <= 8 && !split()) throw std::invalid_argument("halo tiles 6 - 8 are fp16x3 kernels: " + name);
@@ -351,12 +354,14 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     }
     }
   } else {
-    choose_conv_cfg(M, ncols, cin_pad, ks, o, &pc);
+    ConvOpts og = o;
+    if (fp8_storage() && og.tile < 0) og.tile = 2;   // the generic kernel's 64 x 64 tile carries the byte-weight staging path (kernels_conv.hip W8)
+    choose_conv_cfg(M, ncols, cin_pad, ks, og, &pc);
   }
   // VP_WEIGHTS_FP8: real e4m3 storage where the layer's kernel stages its weights through registers (the generic GEMM kernel and the halo
   // kernel's tiles 0-5: every matrix layer of AutoDrive); the LDS-DMA / register-stationary kernels copy weight images verbatim and keep
   // de-quantised fp16 planes
-  const bool w8 = fp8_weights() && (halo < 0 || halo <= 5);
+  const bool w8 = fp8_storage() && ((halo < 0 && pc.tile == 2) || halo == 3 || halo == 4);
   std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo((split() && !w8) ? hi.size() : 0, (half_t)0.0f);
   std::vector<uint8_t> codes(w8 ? (size_t)taps * pc.CoutW * cin_pad : 0, (uint8_t)0);
   RowScale rs = row_prescale(w.data(), cout, (size_t)cin * taps, pc.CoutW);

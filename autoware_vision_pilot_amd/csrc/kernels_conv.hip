@@ -25,7 +25,8 @@ namespace vp {
 // K1: kernel size 1 (1x1 conv / ConvTranspose-as-GEMM) -- the tap/bounds arithmetic of the general path cost ~190
 // instructions per K step against 8 MFMAs; the K1 path is one 32-bit add per load.
 // EPI: 0 = generic fp32-staged epilogue; 1..4 = register epilogue case (conv_epilogue.hpp regepi_case)
-template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH, bool K1, int EPI = 0>
+// W8: the weights are OCP e4m3 bytes (ConvGemmParams::w8); compile-time for the reason given at conv3x3_halo_kernel, instantiated for the 64 x 64 tile only
+template <int BK, int CO_TILE, int PX_TILE, int WCO, int WPX, bool SPLIT, int DEPTH, bool K1, int EPI = 0, bool W8 = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves per workgroup");
   constexpr int ROWB = BK * 2 + 16;   // LDS row pitch in bytes
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     if constexpr (K1) { /* 1x1 / ConvTranspose GEMM: no tap arithmetic, 32-bit offsets, one add per load */   \
       const int c0_ = s_ * BK;                                                                                \
       _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
-        if (__builtin_expect(p.w8 != nullptr, 0)) { /* fp8 storage: 8 bytes, converted at the LDS store (wave-uniform branch) */ \
+        if constexpr (W8) { /* fp8 storage: 8 bytes, converted at the LDS store */                            \
           const vp_u32x2 r8_ = *reinterpret_cast<const vp_u32x2*>(p.w8 + (a_off32[i] + c0_));                       \
           ra_hi[SLOT][i] = u32x4{r8_[0], r8_[1], 0u, 0u};                                                       \
         } else {                                                                                              \
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     const int dy_ = ky_ - half_k, dx_ = (tap_ - ky_ * p.ks) - half_k;                                         \
     const size_t wbase_ = (size_t)tap_ * p.CoutW * p.Cin + c0_;                                               \
     _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
-      if (__builtin_expect(p.w8 != nullptr, 0)) {                                                             \
+      if constexpr (W8) {                                                                                     \
         const vp_u32x2 r8_ = *reinterpret_cast<const vp_u32x2*>(p.w8 + wbase_ + a_off[i]);                          \
         ra_hi[SLOT][i] = u32x4{r8_[0], r8_[1], 0u, 0u};                                                         \
       } else {                                                                                                \
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
   {                                                                                                           \
     char* st_ = smem + (BUF) * STAGE;                                                                         \
     _Pragma("unroll") for (int i = 0; i < A_ITERS; ++i) if (A_CHUNKS % 256 == 0 || tid + 256 * i < A_CHUNKS) { \
-      if (__builtin_expect(p.w8 != nullptr, 0)) {                                                             \
+      if constexpr (W8) {                                                                                     \
         *reinterpret_cast<u32x4*>(st_ + OFF_AHI + a_lds[i]) = e4m3x8_to_half8(ra_hi[SLOT][i][0], ra_hi[SLOT][i][1]); \
         if constexpr (SPLIT) *reinterpret_cast<u32x4*>(st_ + OFF_ALO + a_lds[i]) = zero4;                     \
       } else {                                                                                                \
@@ -315,16 +316,20 @@ static hipError_t launch_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int DEPTH = chunks <= 4 ? 4 : (chunks <= 8 ? 3 : 2);
   const bool k1 = p.ks == 1;
   // register epilogue (fp16 engines, K1 GEMMs only: that is where the epilogue dominates); see regepi_case
-  const int epi = (k1 && !SPLIT) ? regepi_case(p, CO, SPLIT) : 0;
+  const int epi = (k1 && !SPLIT && p.w8 == nullptr) ? regepi_case(p, CO, SPLIT) : 0;
   void (*k)(const ConvGemmParams) = k1 ? conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, true, 0> : conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, false, 0>;
+  if (p.w8 != nullptr) {   // fp8 weight storage: the 64 x 64 tile only (the engine selects nothing else for such a layer)
+    if constexpr (CO == 64 && PX == 64) k = k1 ? conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, true, 0, true> : conv_gemm_kernel<BK, CO, PX, WCO, WPX, SPLIT, DEPTH, false, 0, true>;
+    else return hipErrorInvalidValue;
+  }
   if constexpr (!SPLIT) {
     if (epi == 1) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 1>;
     if (epi == 2) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 2>;
     if (epi == 3) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 3>;
     if (epi == 4) k = conv_gemm_kernel<BK, CO, PX, WCO, WPX, false, DEPTH, true, 4>;
   }
-  static LdsAttrOnce attr_once[2][5];
-  if (hipError_t e = set_max_dynamic_lds(attr_once[k1][epi], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  static LdsAttrOnce attr_once[2][6];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[k1][p.w8 ? 5 : epi], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   const int M = p.H * p.W;
   dim3 grid(((M + PX - 1) / PX) * (p.CoutW / CO) * p.nsplit);  // decoded in the kernel (XCD-aware)
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);

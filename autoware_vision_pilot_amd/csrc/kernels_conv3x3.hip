@@ -24,7 +24,10 @@ namespace vp {
 // with `p.ks - 3` x s_sleep(127), the tool passes the count in ks -- DESIGN.md "Tried and dropped"); always 0 in the library.
 // FASTEPI: single-pass register GELU + fp16-staged epilogue (conv_epilogue.hpp epilogue_regs_fp16); the launcher
 // selects it when the layer is bias + ACT_GELU_F16 (VP_FP16 engines), no residual, NHWC, no split-K.
-template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0, bool FASTEPI = false>
+// W8: the weights are OCP e4m3 BYTES (ConvGemmParams::w8, VP_WEIGHTS_FP8 as storage): 8 bytes per piece instead of 16, converted to fp16 on their way to
+// LDS.  A COMPILE-TIME flag: as a run-time branch in the tap macros it cost the fp16 engines' big layers 12-47 % (the compiler waits at the joins;
+// measured, round 4) -- instantiated for the tiles an fp8 engine uses (64- and 32-channel 8x16 tiles), the library's other kernels are untouched.
+template <int CO_TILE, int TH, int TW, int WCO, int WPX, bool SPLIT, int ABL = 0, bool FASTEPI = false, bool W8 = false>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams p) {
   static_assert(WCO * WPX == 4, "4 waves");
   constexpr int ROWB = 80, CH = 4;  // 32 channels = 64 B + 16 B pad
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
     const int si_ = (SIDX) < s_last ? (SIDX) : s_last; /* clamped: loads stay unconditional */         \
     const size_t base_ = (size_t)si_ * w_step;                                                        \
     _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
-      if (__builtin_expect(p.w8 != nullptr, 0)) { /* fp8 storage: 8 bytes instead of 16, converted at the LDS store (wave-uniform branch) */ \
+      if constexpr (W8) { /* fp8 storage: 8 bytes instead of 16, converted at the LDS store */        \
         const vp_u32x2 r8_ = *reinterpret_cast<const vp_u32x2*>(p.w8 + base_ + w_goff[pc]);                 \
         rw_hi[SLOT][pc] = u32x4{r8_[0], r8_[1], 0u, 0u};                                                \
       } else {                                                                                        \
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
   {                                                                                                   \
     char* dst_ = w_base + (BUF) * NPL * W_BYTES;                                                      \
     _Pragma("unroll") for (int pc = 0; pc < WP; ++pc) if (WCHUNKS % 256 == 0 || w_goff[pc] >= 0) {    \
-      if (__builtin_expect(p.w8 != nullptr, 0)) {                                                     \
+      if constexpr (W8) {                                                                             \
         *reinterpret_cast<u32x4*>(dst_ + w_lds[pc]) = e4m3x8_to_half8(rw_hi[SLOT][pc][0], rw_hi[SLOT][pc][1]); \
         if constexpr (SPLIT) *reinterpret_cast<u32x4*>(dst_ + W_BYTES + w_lds[pc]) = zero4;           \
       } else {                                                                                        \
@@ -271,10 +274,14 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds = lds_a > epilogue_fp16_stage_bytes<TH * TW, CO>() ? lds_a : epilogue_fp16_stage_bytes<TH * TW, CO>();
   static_assert(lds <= 160 * 1024, "LDS budget");
   const bool fast = !SPLIT && p.act == ACT_GELU_F16 && p.res_mode == RES_NONE && p.store_mode == STORE_NHWC && p.nsplit == 1 &&
-                    p.out_lo == nullptr;
+                    p.out_lo == nullptr && p.w8 == nullptr;
   auto k = fast ? conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, !SPLIT> : conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, false>;
-  static LdsAttrOnce attr_once[2];
-  if (hipError_t e = set_max_dynamic_lds(attr_once[fast], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
+  if (p.w8 != nullptr) {   // fp8 weight storage: the 8x16-pixel tiles of 64 and 32 channels only (halo_w8_tile_ok; the engine selects nothing else)
+    if constexpr (TH == 8 && CO <= 64) k = conv3x3_halo_kernel<CO, TH, TW, WCO, WPX, SPLIT, 0, false, true>;
+    else return hipErrorInvalidValue;
+  }
+  static LdsAttrOnce attr_once[3];
+  if (hipError_t e = set_max_dynamic_lds(attr_once[p.w8 ? 2 : fast], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW) * (p.CoutW / CO) * p.nsplit);  // decoded in the kernel (XCD-aware)
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   hipError_t e = hipGetLastError();

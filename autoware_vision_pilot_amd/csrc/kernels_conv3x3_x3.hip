@@ -46,7 +46,7 @@ namespace vp {
 // fragment reads in the loop, 8 = no barrier in the loop, 16 = no epilogue arithmetic / stores, 32 = clock probe: workgroup 0
 // writes {shader-clock ticks, 100 MHz wall ticks} of its K loop to p.partial[0..1] as raw 64-bit counters, 64 = no halo staging
 // in the loop (weights still stream), 128 = no weight DMA in the loop (halo still streams), 256 = __syncthreads() instead of
-// VP_LDS_BARRIER in the loop: every barrier drains vmcnt(0), lds_dma.hpp); always 0 in the library.
+// VP_LDS_BARRIER in the loop: every barrier drains vmcnt(0), lds_dma.hpp), 512 / 1024 / 2048 = ConvTranspose-fusion estimate (below); always 0 in the library.
 // Measured with them (profiles/r02_x3_clock_probe.txt): either stream alone is free (255 k cycles of the 8-wave K loop on
 // decode_layer_4 = 87 % matrix-pipe busy), both together cost 290 k (76 %): s_waitcnt vmcnt retires in issue order, so a wait
 // for a weight tile (L2 hit) also waits for the older halo loads (HBM).  Splitting the roles between waves (waves 0-3 DMA,
@@ -125,6 +125,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     const bool ok = hidx < HCHUNKS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     h_goff[pc] = ok ? (gy * p.W + gx) * p.Cin + ch * 8 : -1;
+    // ABL 512 (tools/x3_ablate.hip, the ConvTranspose -> 3x3 fusion estimate of VERDICT round 3 item 5): the halo comes from a QUARTER-RESOLUTION
+    // tensor, as it would if the up-sampling ran inside this kernel (timing only: the values are meaningless)
+    if constexpr ((ABL & 512) != 0) h_goff[pc] = ok ? ((gy >> 1) * (p.W >> 1) + (gx >> 1)) * p.Cin + ch * 8 : -1;
   }
   // weight tiles by LDS-DMA: a (chunk, tap) tile plane is CO_TILE x 64 B = W_BYTES contiguous bytes in global memory, already
   // in LDS image order; wave v copies the 1 KiB pieces v, v + NW, ... of both planes
@@ -271,6 +274,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     if constexpr (!(ABL & 4)) VP_READ_FRAGS(0, wnext_, hnext_, tap_next_)                    \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     VP_MFMA(1)                                                                               \
+    /* ABL 1024 / 2048 (same estimate): one / two extra taps' worth of MFMAs per chunk = +11 % / +22 % matrix work, the price of the  */ \
+    /* in-kernel up-sampling GEMM (+17 % on these layers)                                                                             */ \
+    if constexpr (((ABL & 1024) != 0 && (T) == 4) || ((ABL & 2048) != 0 && (T) == 7)) { VP_MFMA(0) VP_MFMA(1) } \
     /* round 4 (seen in the ISA): without this fence the scheduler hoists the NEXT step's LDS-DMA issue to the head of this MFMA */ \
     /* group, right behind set 0's reads -- and an LDS-DMA may overwrite what an outstanding ds_read reads, so the compiler puts   */ \
     /* s_waitcnt lgkmcnt(0) in front of it: the prefetch was drained the moment it was issued.  Behind the 12 MFMAs it has landed. */ \

@@ -123,6 +123,20 @@ int main(int argc, char** argv) {
     clock_probe<8, 2, false, 32 | 1 | 4 | 8 | 16>("w4 dec8 MFMA + loop only", 320, 640, 128, 128);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'f') {  // ConvTranspose -> 3x3 prologue fusion, estimated BEFORE building it: the consumer layers of
+    // upsample_layer_4 (-> decode_layer_8, 4-wave shape) and upsample_layer_3 + skip (-> decode_layer_6, 8-wave shape) with their halo read from a
+    // quarter-resolution tensor (bit 512) and one / two extra taps' worth of MFMAs per chunk (bits 1024 / 2048: +11 % / +22 %; the in-kernel
+    // up-sampling GEMM is +17 %).  What the fusion could save at best = the up-sampling launch (39.4 / 36.6 us) minus the growth of this launch.
+    clock_probe<8, 2, false, 32>("w4 dec8 as shipped", 320, 640, 128, 128);
+    clock_probe<8, 2, false, 32 | 512>("w4 dec8 halo from quarter-resolution tensor", 320, 640, 128, 128);
+    clock_probe<8, 2, false, 32 | 512 | 1024>("w4 dec8 quarter-res halo, +11 % MFMAs", 320, 640, 128, 128);
+    clock_probe<8, 2, false, 32 | 512 | 1024 | 2048>("w4 dec8 quarter-res halo, +22 % MFMAs", 320, 640, 128, 128);
+    clock_probe<16, 4, true, 32>("w8 dec6 as shipped", 160, 320, 256, 256);
+    clock_probe<16, 4, true, 32 | 512>("w8 dec6 halo from quarter-resolution tensor", 160, 320, 256, 256);
+    clock_probe<16, 4, true, 32 | 512 | 1024>("w8 dec6 quarter-res halo, +11 % MFMAs", 160, 320, 256, 256);
+    clock_probe<16, 4, true, 32 | 512 | 1024 | 2048>("w8 dec6 quarter-res halo, +22 % MFMAs", 160, 320, 256, 256);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'b') {  // barrier A/B: VP_LDS_BARRIER (library) vs __syncthreads() (drains vmcnt(0) at every tap, ABL bit 256)
     clock_probe<16, 4, true, 32>("w8 dec4 lds barrier", 80, 160, 512, 512);
     clock_probe<16, 4, true, 32 | 256>("w8 dec4 __syncthreads", 80, 160, 512, 512);
