@@ -82,6 +82,28 @@ public:
       throw std::runtime_error("Inference has not been run yet. Call inference() first.");
     return {shape[0], shape[1], shape[2], shape[3]};
   }
+  // AutoSteer hand-over (main.cpp:472-534): the raw logits of the last two inference() calls, concatenated [t-1 | t] = {1, 6, 80, 160}, kept on
+  // the DEVICE by the engine (vp_set_lane_ring) instead of the app's circular buffer of host copies + two memcpys per frame.
+  //   engine.enableAutoSteerInput();                                   // once, after construction
+  //   if (engine.autoSteerInput(autosteer_input_buffer))              // false until two frames are in (the reference's `buffer.full()` test, :521)
+  //     steering = autosteer_engine->inference(autosteer_input_buffer);
+  // autoSteerInputDevice() hands a device-resident AutoSteer runtime the same 6 x 80 x 160 floats without the D2H.
+  void enableAutoSteerInput()
+  {
+    if (vp_set_lane_ring(engine_, 1) != VP_OK) throw std::runtime_error(std::string("[hip_engine] ") + vp_last_error(engine_));
+  }
+  bool autoSteerInput(std::vector<float> & buffer)
+  {
+    int frames = 0;
+    buffer.resize(static_cast<size_t>(6) * out_h_ * out_w_);
+    if (vp_lane_ring_fetch(engine_, buffer.data(), &frames) != VP_OK) return false;
+    return frames >= 2;
+  }
+  const float * autoSteerInputDevice(int * frames_valid = nullptr) const
+  {
+    void * p = nullptr;
+    return vp_lane_ring_device(engine_, &p, frames_valid) == VP_OK ? static_cast<const float *>(p) : nullptr;
+  }
   int getInputWidth() const { return in_w_; }
   int getInputHeight() const { return in_h_; }
   int getOutputWidth() const { return out_w_; }

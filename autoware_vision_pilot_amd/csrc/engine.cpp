@@ -1201,6 +1201,19 @@ void Engine::finish_plan() {
       return launch_finite_probe(d_logits_, (size_t)out_c_ * out_h_ * out_w_, d_status_, st);
     };
     ops_.push_back(std::move(probe));
+    if (kind_ == 3) {   // EgoLanes: the AutoSteer hand-over ring, when enabled (two device-to-device copy nodes behind the pass)
+      Op ring;
+      ring.name = "lane_ring";
+      ring.kernel = "lane_ring";
+      ring.bytes = 3.0 * 4.0 * out_c_ * out_h_ * out_w_;
+      ring.run = [this](hipStream_t st) -> hipError_t {
+        if (!lane_ring_) return hipSuccess;
+        const size_t n = (size_t)out_c_ * out_h_ * out_w_;
+        if (hipError_t e = hipMemcpyAsync(d_lane_ring_, d_lane_ring_ + n, n * sizeof(float), hipMemcpyDeviceToDevice, st); e != hipSuccess) return e;   // t-1 := t
+        return hipMemcpyAsync(d_lane_ring_ + n, d_logits_, n * sizeof(float), hipMemcpyDeviceToDevice, st);                                                 // t := this pass
+      };
+      ops_.push_back(std::move(ring));
+    }
   }
   // kernel tags of the non-GEMM launches (the conv ops set theirs in push_conv_op)
   auto ends_with = [](const std::string& s, const char* suf) {

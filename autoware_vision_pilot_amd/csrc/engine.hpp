@@ -99,6 +99,13 @@ class Engine {
   // (cv::Mat::convertTo(CV_32FC3, 1.0 / 255.0): the C++ front-ends, onnx_runtime_backend.cpp:45, onnxruntime_engine.cpp:85)
   void set_norm_form(int form);
   int norm_form() const { return norm_form_; }
+  // AutoSteer hand-over: the raw EgoLanes logits of the last TWO passes, [t-1 | t] = fp32 {1, 6, 80, 160}, kept on the device and
+  // updated behind every pass (production_release main.cpp:472-534 builds the same buffer on the host with a circular buffer and two memcpys)
+  void set_lane_ring(bool on);
+  bool lane_ring() const { return lane_ring_; }
+  float* dev_lane_ring() const { return d_lane_ring_; }
+  int lane_ring_frames() const { return ring_frames_; }   // 0, 1, 2: the reference runs AutoSteer only once two frames are in
+  void fetch_lane_ring(float* dst);                        // D2H of the 6 x 80 x 160 floats + sync
   // frame resize ahead of the network: 0 = the integer bilinear modelled on cv::resize INTER_LINEAR (the C++ nodes; default of the scene
   // networks), 1 / 2 = Pillow's antialiased BILINEAR / BICUBIC (the Python scripts' Image.resize; 1 is AutoDrive's default)
   void set_resize_mode(int mode);
@@ -276,6 +283,10 @@ class Engine {
   bool decode_fused_ = false;  // the logits convolution writes d_mask_ in its epilogue: no separate decode launch
   int outputs_ = 3;  // vp_set_outputs: bit 0 logits, bit 1 mask copied to the host by vp_infer*
   bool host_logits_valid_ = false, host_mask_valid_ = false;
+  float* d_lane_ring_ = nullptr;  // [6][out_h][out_w] fp32: previous | current EgoLanes logits (vp_set_lane_ring)
+  bool lane_ring_ = false;
+  int ring_frames_ = 0;
+  void note_pass() { if (lane_ring_ && ring_frames_ < 2) ++ring_frames_; }
   unsigned* d_status_ = nullptr;  // sticky non-finite flag written by the probe kernel
   unsigned* h_status_ = nullptr;  // pinned copy, fetched with the outputs
   bool finite_check_ = true, status_pending_ = false;

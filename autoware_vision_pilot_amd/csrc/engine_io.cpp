@@ -17,6 +17,25 @@ void Engine::set_norm_form(int form) {
   if (form != norm_form_) { graph_valid_ = false; ++plan_epoch_; }
   norm_form_ = form;
 }
+void Engine::set_lane_ring(bool on) {
+  if (kind_ != 3) throw std::invalid_argument("lane ring: VP_EGOLANES engines only (the AutoSteer hand-over of the EgoLanes logits)");
+  if (on == lane_ring_) return;
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (on && !d_lane_ring_) d_lane_ring_ = static_cast<float*>(dalloc((size_t)2 * out_c_ * out_h_ * out_w_ * sizeof(float), true));
+  if (on) VP_HIP_CHECK(hipMemset(d_lane_ring_, 0, (size_t)2 * out_c_ * out_h_ * out_w_ * sizeof(float)));
+  lane_ring_ = on;
+  ring_frames_ = 0;
+  graph_valid_ = false;
+  ++plan_epoch_;
+}
+void Engine::fetch_lane_ring(float* dst) {
+  if (!lane_ring_ || !d_lane_ring_) throw std::runtime_error("lane ring is not enabled (vp_set_lane_ring)");
+  if (!dst) throw std::invalid_argument("null destination");
+  VP_HIP_CHECK(hipSetDevice(gpu_));
+  VP_HIP_CHECK(hipMemcpyAsync(dst, d_lane_ring_, (size_t)2 * out_c_ * out_h_ * out_w_ * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  VP_HIP_CHECK(hipStreamSynchronize(stream_));
+}
 void Engine::set_decode_mode(int mode) {
   if (mode < 0 || mode > 2) throw std::invalid_argument("bad decode mode");
   if (mode != decode_mode_) { graph_valid_ = false; ++plan_epoch_; }
@@ -305,9 +324,11 @@ void Engine::enqueue_multi(const std::vector<Engine*>& heads) {
   VP_HIP_CHECK(hipGraphLaunch(multi_exec_, stream_));
   have_outputs_ = true;
   host_logits_valid_ = host_mask_valid_ = false;
+  note_pass();
   for (Engine* h : heads) {
     h->have_outputs_ = true;
     h->host_logits_valid_ = h->host_mask_valid_ = false;
+    h->note_pass();
   }
 }
 
@@ -348,7 +369,10 @@ void Engine::enqueue() {
     warmed_ = true;
     have_outputs_ = true;
     host_logits_valid_ = host_mask_valid_ = false;
-    if (!use_graph_ || kind_ == 4) return;  // AutoDrive carries state (feature shift): a frame must run exactly once
+    if (!use_graph_ || kind_ == 4 || lane_ring_) {  // AutoDrive (feature shift) and the lane ring carry state: a frame must run exactly once
+      note_pass();
+      return;
+    }
   }
   if (use_graph_) {
     if (!graph_valid_) capture_graph();
@@ -358,6 +382,7 @@ void Engine::enqueue() {
   }
   have_outputs_ = true;
   host_logits_valid_ = host_mask_valid_ = false;
+  note_pass();
 }
 
 void Engine::sync() {

@@ -273,6 +273,20 @@ int vp_set_norm_form(vp_engine* e, int form) {
   return guarded(e, [&](vp::Engine& g) { g.set_norm_form(form); });
 }
 int vp_get_norm_form(const vp_engine* e) { return (e && e->impl) ? e->impl->norm_form() : VP_ERR_ARG; }
+int vp_set_lane_ring(vp_engine* e, int enable) {
+  return guarded(e, [&](vp::Engine& g) { g.set_lane_ring(enable != 0); });
+}
+int vp_lane_ring_device(const vp_engine* e, void** dev_f32, int* frames_valid) {
+  if (!e || !e->impl || !e->impl->lane_ring()) return VP_ERR_STATE;
+  if (dev_f32) *dev_f32 = e->impl->dev_lane_ring();
+  if (frames_valid) *frames_valid = e->impl->lane_ring_frames();
+  return VP_OK;
+}
+int vp_lane_ring_fetch(vp_engine* e, float* dst_host, int* frames_valid) {
+  const int rc = guarded(e, [&](vp::Engine& g) { g.fetch_lane_ring(dst_host); });
+  if (rc == VP_OK && frames_valid) *frames_valid = e->impl->lane_ring_frames();
+  return rc;
+}
 int vp_get_resize_mode(const vp_engine* e) { return (e && e->impl) ? e->impl->resize_mode() : VP_ERR_ARG; }
 int vp_device_count(void) {
   int n = 0;

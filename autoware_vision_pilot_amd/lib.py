@@ -96,6 +96,9 @@ _SIGS = {
     "vp_detect_set_letterbox": (C.c_int, [_P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vp_detect_postprocess": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, C.c_int, C.POINTER(C.c_int)]),
     "vp_version": (C.c_char_p, []),
+    "vp_set_lane_ring": (C.c_int, [_P, C.c_int]),
+    "vp_lane_ring_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
+    "vp_lane_ring_fetch": (C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     "vp_set_norm_form": (C.c_int, [_P, C.c_int]),
     "vp_get_norm_form": (C.c_int, [_P]),
     "vp_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
@@ -306,6 +309,17 @@ class Engine:
 
     def plan_hash(self):
         return int(self._lib.vp_plan_hash(self._h))
+
+    def set_lane_ring(self, on=True):
+        """AutoSteer hand-over on an EgoLanes engine: keep [t-1 | t] of the raw logits (fp32 6 x 80 x 160) on the device (vp_set_lane_ring)."""
+        self._ck(self._lib.vp_set_lane_ring(self._h, 1 if on else 0))
+
+    def lane_ring(self):
+        """(6 x 80 x 160 fp32 host copy of the ring, frames_valid)  -- frames_valid < 2: the reference skips AutoSteer (main.cpp:521)."""
+        buf = np.empty((6, 80, 160), np.float32)
+        n = C.c_int()
+        self._ck(self._lib.vp_lane_ring_fetch(self._h, _ptr(buf), C.byref(n)))
+        return buf, n.value
 
     def weight_bytes(self):
         """Device bytes of the weight tensors by storage class: {'fp8': e4m3 codes, 'fp16': fp16 planes, 'fp32': fp32 rows} (vp_weight_bytes)."""

@@ -224,6 +224,18 @@ int vp_frame_hw(const vp_engine* e, int* h, int* w);                           /
 int vp_visualize_depth_bgr8(vp_engine* e, uint8_t* dst_bgr8, int h, int w);
 int vp_input_tensor(vp_engine* e, float* dst_1x3x320x640);                     /* the post-resize network input */
 
+/* ---- AutoSteer hand-over (VisionPilot/production_release/main.cpp:472-534) ---------------------------
+ * The production app feeds its AutoSteer head the raw EgoLanes logits of the last TWO frames, concatenated [t-1 | t] = fp32 {1, 6, 80, 160}:
+ * a boost::circular_buffer of host copies plus two memcpys per frame (main.cpp:508-530), handed to AutoSteerOnnxEngine::inference
+ * (src/inference/autosteer_engine.cpp:104-195).  With vp_set_lane_ring(e, 1) a VP_EGOLANES engine keeps that buffer ON THE DEVICE: two
+ * device-to-device copies behind every pass (inside the replayed graph), no host round trip -- a device-resident AutoSteer runtime reads
+ * vp_lane_ring_device, the reference's host-side engine reads vp_lane_ring_fetch.  *frames_valid = passes since enabling, capped at 2: the
+ * reference runs AutoSteer only once two frames are in (main.cpp:521).  The AutoSteer GRAPH itself is not in the reference tree (ONNX only,
+ * production_release/README.md:112): the head is not built, its input is.  VP_ERR_ARG on other model kinds, VP_ERR_STATE while disabled. */
+int vp_set_lane_ring(vp_engine* e, int enable);
+int vp_lane_ring_device(const vp_engine* e, void** dev_f32_6x80x160, int* frames_valid);
+int vp_lane_ring_fetch(vp_engine* e, float* dst_host_6x80x160, int* frames_valid);
+
 /* ---- asynchronous / device-resident path (bench, multi-GPU) ---------------------------------------------- */
 int vp_upload_frame(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes); /* H2D, frame stays in HBM */
 int vp_enqueue(vp_engine* e);                                                  /* one pass over the resident frame */

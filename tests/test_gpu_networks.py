@@ -294,3 +294,39 @@ def test_config1_640x360_rgb_class_map(engines, state_dicts):
     finally:
         eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
         eng.set_decode_mode(lib.VP_DECODE_SEG_MASK)
+
+
+def test_egolanes_autosteer_handover_ring(engines, frame720):
+    """vp_set_lane_ring (production_release main.cpp:472-534): the raw EgoLanes logits of the last two frames, [t-1 | t] = fp32
+    {1, 6, 80, 160}, kept on the device behind every pass -- eager first pass, graph capture, graph replays -- bit for bit the engine's own logits
+    of those frames; one valid frame after the first pass (the reference skips AutoSteer then), two from the second on; switching the ring off and on
+    again starts over; other model kinds refuse."""
+    from autoware_vision_pilot_amd import lib
+    from oracle import pre_post
+
+    eng = engines("egolanes", "fp16x3")
+    eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB)
+    eng.set_lane_ring(True)
+    try:
+        frames = [frame720] + [pre_post.synthetic_frame(360, 640, 40 + i) for i in range(4)]
+        prev = None
+        for i, f in enumerate(frames):
+            eng.infer(f)
+            cur = eng.logits().copy()
+            ring, nvalid = eng.lane_ring()
+            assert nvalid == min(i + 1, 2)
+            assert np.array_equal(ring[3:], cur), i
+            assert np.array_equal(ring[:3], prev) if prev is not None else not ring[:3].any()
+            prev = cur
+        eng.set_lane_ring(False)
+        with pytest.raises(lib.VpError):
+            eng.lane_ring()
+        eng.set_lane_ring(True)
+        eng.infer(frames[1])
+        ring, nvalid = eng.lane_ring()
+        assert nvalid == 1 and not ring[:3].any() and np.array_equal(ring[3:], eng.logits())
+        with pytest.raises(ValueError):
+            engines("sceneseg", "fp16x3").set_lane_ring(True)
+    finally:
+        eng.set_lane_ring(False)
+        eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_BGR)
