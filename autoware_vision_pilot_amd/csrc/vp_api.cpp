@@ -519,6 +519,17 @@ int vp_split_weight_rows(const float* w, int rows, int per_row, uint16_t* hi, ui
   }
   return VP_OK;
 }
+// host only: the e4m3 codes and row scales VP_WEIGHTS_FP8 storage makes of a (quantised, possibly re-scaled) weight matrix
+int vp_fp8_encode_rows(const float* w, int rows, int per_row, uint8_t* codes, float* row_scale) {
+  if (!w || rows < 1 || per_row < 1 || !codes || !row_scale) return VP_ERR_ARG;
+  for (int r = 0; r < rows; ++r) {
+    float amax = 0.0f;
+    for (int i = 0; i < per_row; ++i) amax = std::max(amax, std::fabs(w[(size_t)r * per_row + i]));
+    row_scale[r] = vp::fp8_row_scale(amax);
+    for (int i = 0; i < per_row; ++i) codes[(size_t)r * per_row + i] = vp::e4m3_encode(w[(size_t)r * per_row + i] / row_scale[r]);
+  }
+  return VP_OK;
+}
 int vp_copy_outputs_device(vp_engine* e, void* logits_dst, void* mask_dst) {
   return guarded(e, [&](vp::Engine& g) { g.copy_outputs_device(logits_dst, mask_dst); });
 }

@@ -107,6 +107,7 @@ _SIGS = {
     "vp_plan_hash": (C.c_ulonglong, [_P]),
     "vp_weight_bytes": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "vp_split_weight_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
+    "vp_fp8_encode_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "vp_convert_onnx": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
 }
 # multi-camera exchange (csrc/vp_comm.cpp): part of libvp_hip.so, absent from the CPU-emulated test build
@@ -196,6 +197,17 @@ def options_from_env(environ=None):
 
 def version():
     return load().vp_version().decode()
+
+
+def fp8_encode_rows(w):
+    """vp_fp8_encode_rows (host only): fp32 [rows][per_row] -> (uint8 e4m3 codes, fp32 row scales)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    rows, per = w.shape
+    codes = np.empty((rows, per), np.uint8)
+    scale = np.empty(rows, np.float32)
+    if load().vp_fp8_encode_rows(_ptr(w), rows, per, _ptr(codes), _ptr(scale)) != 0:
+        raise ValueError("vp_fp8_encode_rows failed")
+    return codes, scale
 
 
 def split_weight_rows(w):

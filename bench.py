@@ -149,8 +149,10 @@ class Camera:
     fork_all = False  # --fork-all: forked graphs in the throughput legs too (experiment)
 
     def __init__(self, lib, kinds, blobs, precision, gpu, frame):
+        t0 = time.perf_counter()
         self.base = lib.Engine(kinds[0], blobs[0], precision=precision, gpu_id=gpu)
         self.heads = [lib.Engine(k, b, precision=precision, gpu_id=gpu, base=self.base) for k, b in zip(kinds[1:], blobs[1:])]
+        self.create_s = time.perf_counter() - t0   # vp_create + vp_create_shared: blob parse, BN fold, prescale + (hi, lo) split, per-kernel packing, uploads
         self.frame = frame
         # no forked graph (hence no side stream) unless a latency leg asks for it: HIP streams are dealt round-robin onto a few
         # hardware queues (4 by default), and a side stream created between two cameras' streams made two cameras share a queue
@@ -571,6 +573,9 @@ def main():
             "rccl_world": world if (args.gather or world > 1) else 0,
             "rccl_use": ("per-frame all-gather of the class maps (vp_gather) + " if args.gather else "") + ("barrier / max-over-ranks timing" if world > 1 else ("none" if not args.gather else "world 1")),
             "library": lib.version(),
+            "engine_create_s": round(float(np.median([c.create_s for c in cams])), 3),
+            "engine_create_note": "wall time of vp_create (SceneSeg) + vp_create_shared (Scene3D) from the in-memory VPW1 blobs: the packing a TensorRT-style "
+                                  "engine cache would save (tensorrt_backend.cpp:40-54); median over the in-flight slots",
             "plan_hash": {e.kind: f"{e.plan_hash():016x}" for e in engs},
         }
         if fps_timer is not None:

@@ -345,6 +345,10 @@ int vp_weight_bytes(const vp_engine* e, unsigned long long* fp8_bytes, unsigned 
  * 2^-s of its power-of-two prescale: fp32(hi) + fp32(lo) = w * 2^s with the row maximum in [2^13, 2^14), post_scale[r] = 2^-s.
  * VP_ERR_RANGE for a weight beyond the fp16 range, as vp_create*. */
 int vp_split_weight_rows(const float* w, int rows, int per_row, uint16_t* hi, uint16_t* lo, float* post_scale);
+/* host only (tests): what VP_WEIGHTS_FP8 storage keeps of a weight matrix -- one OCP e4m3 code per element and the per-row scale
+ * (row maximum / 448); for rows that came out of the per-row quantiser (possibly re-scaled since, as BatchNorm folding does)
+ * code x scale reproduces the value to fp32 rounding. */
+int vp_fp8_encode_rows(const float* w, int rows, int per_row, uint8_t* codes, float* row_scale);
 
 const char* vp_version(void);
 

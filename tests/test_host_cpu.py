@@ -351,3 +351,35 @@ def test_library_ignores_a_hostile_environment():
         del os.environ["VP_MAP3X3"]
         lib.clear_options()
     assert lib.get_option("VP_MAP3X3") is None and "options: none" in lib.version()
+
+
+def test_fp8_codes_reproduce_the_quantised_weights():
+    """VP_WEIGHTS_FP8 storage, host side (vp_fp8_encode_rows = engine_internal.hpp e4m3_encode + fp8_row_scale): every one of the 254 finite OCP e4m3
+    codes survives decode -> encode; rows that came out of the per-row quantiser (oracle/autodrive.py quantize_fp8_e4m3) and were re-scaled
+    afterwards as BatchNorm folding does (incl. a sign flip) come back as code x scale to fp32 rounding, with no code off by one."""
+    from autoware_vision_pilot_amd import lib
+    from oracle import autodrive
+
+    def decode(c):
+        c = np.asarray(c, np.int64)
+        e, m = (c >> 3) & 15, c & 7
+        mag = np.where(e > 0, (1.0 + m / 8.0) * np.exp2(e.astype(np.float64) - 7.0), m * 2.0 ** -9)
+        return np.where(c & 0x80, -mag, mag)
+
+    finite = np.array([c for c in range(256) if (c & 0x7F) != 0x7F], np.uint8)
+    vals = decode(finite).astype(np.float32)
+    row = np.concatenate([vals, np.array([448.0], np.float32)])[None]          # the row maximum 448 pins the scale to 1
+    codes, scale = lib.fp8_encode_rows(row)
+    assert scale[0] == 1.0
+    back = decode(codes[0][:-1])
+    assert np.array_equal(back, vals.astype(np.float64))                      # (+0 and -0 both decode to 0)
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((64, 1152)) * 0.03).astype(np.float32)
+    w[3] *= np.float32(1e-4)
+    wq = autodrive.quantize_fp8_e4m3({"x.weight": w})["x.weight"]
+    fold = ((0.3 + rng.random(64)) * np.where(rng.random(64) < 0.3, -1.0, 1.0)).astype(np.float32)
+    wf = (wq * fold[:, None]).astype(np.float32)
+    codes, scale = lib.fp8_encode_rows(wf)
+    rec = decode(codes) * scale.astype(np.float64)[:, None]
+    assert np.abs(rec - wf).max() <= 4e-7 * np.abs(wf).max()
+    assert (np.abs(decode(codes)).max(axis=1) == 448.0).all()                 # every row's maximum is the largest code, as the quantiser made it
