@@ -977,7 +977,9 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     const std::string cp = sn + ".1";
     const int HW = a->H * a->W, C = a->Creal;
     // mean over H, W (:206) as slab partial sums
-    const int nslab = std::max(1, std::min(64, HW / 512));
+    // 64 pixels per slab (round 4; it was 512): on the 16x32 map of p5 ONE workgroup walked the 512 pixels, 16 dependent round trips = 23 us of a
+    // 0.66 ms frame; the FC behind it sums the slabs in their fixed order either way
+    const int nslab = std::max(1, std::min(64, HW / 64));
     float* partial = static_cast<float*>(dalloc((size_t)nslab * a->C * sizeof(float)));
     {
       PoolParams pp{a->view(), partial, nslab};
@@ -1043,9 +1045,14 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     const int c_ = c1->Creal;
     Act* cat = new_act(sp + ".cat", 4 * c_, x->H, x->W);
     const ActView cv = cat->view(), c1v = c1->view();
-    push(sp + ".cat0", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(c1v, 0, cv, 0, c_, st); });
-    for (int i = 0; i < 3; ++i)
-      push(sp + ".maxpool" + std::to_string(i), "maxpool5", [=](hipStream_t st) { return launch_maxpool5(cv, i * c_, cv, (i + 1) * c_, c_, st); });
+    // cat((x, mp5(x), mp5(mp5(x)), mp5^3(x))) in one launch (round 4: a slice copy + three chained max-pool launches before; kernels_autodrive.hip)
+    if (sppf_pool_ok(c1v, cv, c_)) {
+      push(sp + ".pyramid", "sppf_pool", [=](hipStream_t st) { return launch_sppf_pool(c1v, cv, c_, st); });
+    } else {   // maps above 512 pixels (other input sizes): the slice copy and the three chained 5x5 max-pools
+      push(sp + ".cat0", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(c1v, 0, cv, 0, c_, st); });
+      for (int i = 0; i < 3; ++i)
+        push(sp + ".maxpool" + std::to_string(i), "maxpool5", [=](hipStream_t st) { return launch_maxpool5(cv, i * c_, cv, (i + 1) * c_, c_, st); });
+    }
     x = conv_bn(sp + ".cv2", cat, 1, 1, ACT_SILU);
   }
   // ---- C2PSA (common_layers.py:246-257) with one PSABlock (:107-118) and its Attention (:78-104)
@@ -1070,7 +1077,12 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     ap.dv = dv;
     ap.scale = 1.0f / std::sqrt((float)dk);
     const int Tn = t->H * t->W;
-    push(mb + ".conv1.attention", "attention", [ap](hipStream_t st) { return launch_attention(ap, st); }, 2.0 * heads * Tn * (double)Tn * (dk + dv));
+    {  // round 4: four query tokens per workgroup (kernels_autodrive.hip attention_block_kernel); VP_ATTN_BLOCK=0 (developer knob, A/B timing): one per workgroup
+      const char* ab = dev_option("VP_ATTN_BLOCK");
+      ap.qblock = (attention_block_ok(ap) && !(ab && ab[0] == '0')) ? 4 : 0;
+    }
+    push(mb + ".conv1.attention", ap.qblock ? "attention<q4>" : "attention", [ap](hipStream_t st) { return launch_attention(ap, st); },
+         2.0 * heads * Tn * (double)Tn * (dk + dv));
     // + depthwise 3x3 positional conv of v (BN folded, identity activation)
     Act* pe = new_act(mb + ".conv1.pe", c_, t->H, t->W);
     {
@@ -1155,9 +1167,30 @@ void Engine::build_autodrive(const WeightBlob& blob) {
   };
   const float* f1 = fc("head.fc1.0", v0, flat, ACT_SILU, nullptr);
   const float* f2 = fc("head.fc2.0", f1, 768, ACT_SILU, nullptr);
-  fc("head.distance_head.0", f2, 512, ACT_RELU, d_logits_ + 0);
-  fc("head.curvature_head.0", f2, 512, ACT_TANH, d_logits_ + 1);
-  fc("head.flag_head", f2, 512, ACT_NONE, d_logits_ + 2);
+  {  // the three scalar heads (autodrive_head.py:60-66: ReLU / tanh / none on one row each) as ONE stacked [3][512] matrix with per-row activations
+     // (round 4: three launches before); row arithmetic is the single-row kernel's
+    const char* names[3] = {"head.distance_head.0", "head.curvature_head.0", "head.flag_head"};
+    const int acts[3] = {ACT_RELU, ACT_TANH, ACT_NONE};
+    std::vector<float> w3, b3;
+    FcParams fp{};
+    for (int r = 0; r < 3; ++r) {
+      const HostTensor& w = T(std::string(names[r]) + ".weight");
+      const HostTensor& b = T(std::string(names[r]) + ".bias");
+      if (w.shape.size() != 2 || w.shape[0] != 1 || w.shape[1] != 512 || b.data.size() != 1) throw std::runtime_error(std::string("linear shape mismatch: ") + names[r]);
+      w3.insert(w3.end(), w.data.begin(), w.data.end());
+      b3.push_back(b.data[0]);
+      fp.act_rows |= (unsigned)acts[r] << (8 * r);
+    }
+    fp.act_rows |= 0x80000000u;   // non-zero even if every row's code were 0 (byte 3 is never a row: N = 3)
+    fp.x = f2;
+    upload_fc_weights(&fp, w3, 3, 512);
+    fp.b = dupload(b3);
+    fp.N = 3;
+    fp.K = 512;
+    fp.act = ACT_NONE;
+    fp.out = d_logits_;
+    push("head.distance+curvature+flag", "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * 3 * 512, (fp.w8 ? 1.0 : 4.0) * 3 * 512);
+  }
   decode_mode_ = 0;
 }
 

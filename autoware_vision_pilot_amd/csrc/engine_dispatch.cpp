@@ -151,8 +151,9 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       return;
     }
     if (ht >= 6 && ht <= 8) {
-      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 8 (pipelined fp16x3 kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles; any epilogue with split-K (7 / 8): " + name);
-      op.kernel = std::string(ht == 6 ? "conv3x3_x3w8<co128,px256>" : (ht == 7 ? "conv3x3_x3w4<co128,px128>" : "conv3x3_x3w4<co64,px128>")) + (pc.nsplit > 1 ? "+splitk" : "");
+      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 8 (pipelined kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles, fp16: input channels a multiple of 64; any epilogue with split-K (7 / 8): " + name);
+      // fp16 engines ("x1"): the same schedule on 64-channel chunks, the chunk's two halves in the two LDS planes (kernels_conv3x3_x3.hip X1)
+      op.kernel = std::string(sp ? "conv3x3_x3" : "conv3x3_x1") + (ht == 6 ? "w8<co128,px256" : (ht == 7 ? "w4<co128,px128" : "w4<co64,px128")) + (sp ? ">" : ",k64>") + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -258,6 +259,18 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // staging per MFMA)
       const int want = envx ? std::atoi(envx) : (cin_pad <= 128 ? 7 : 6);
       const bool plain = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
+      // round 4: the VP_FP16 engines take the same shapes on 64-channel chunks (X1: the planes are the chunk's halves) for their big layers --
+      // the halo kernel's lone-wave schedule left them at 0.29-0.31 of peak.  VP_F16_BIG=0 (developer knob, A/B timing): the halo kernel.
+      const char* envf = dev_option("VP_F16_BIG");
+      if (!split() && !fp8_storage() && o.tile < 0 && !(envf && envf[0] == '0') && halo >= 0 && halo <= 3 && ncols % 128 == 0 && cin_pad % 64 == 0 && !o.logits_out &&
+          !o.in2 && plain && wgs16 >= 160) {
+        // measured per layer (profiles/r04_layers_sceneseg_fp16_big_ab.tsv): the 8-wave shape wins where ONE round of its workgroups covers the
+        // map and the K loop is long (decode_layer_4: 79.6 -> 68.9 us, decode_layer_7: 45.6 -> 40.9); with two rounds (decode_layer_6: 75.6 ->
+        // 77.2) or two chunks per workgroup (decode_layer_8: 85.8 -> 95.6 / 83.7 on the 4-wave shape) the halo kernel's two workgroups per CU
+        // do as well or better.  VP_F16_BIG=6 / 7 forces a shape on every eligible layer.
+        if (envf) halo = std::atoi(envf) == 6 ? 6 : 7;
+        else if (wgs16 <= 256 && cin_pad >= 256) halo = 6;
+      }
       if (split() && o.tile < 0 && want != 0 && (halo == 1 || halo == 3) && ncols % 128 == 0 && !o.logits_out && !o.in2) {
         // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured
         // on MI355X, the 4-wave shape without split-K took 139 vs 100 us on decode_layer_5 (200 patches) and its split-K form
@@ -287,7 +300,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     if (fp8_storage() && o.tile < 0 && halo >= 0) halo = ncols <= 32 ? 4 : 3;
     if (halo == 11 && (!split() || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
       throw std::invalid_argument("halo tile 11 (map kernel): fp16x3, maps that tile into 20x40 or 10x20 regions, >= 32 input channels: " + name);
-    if (halo >= 6 && halo <= 8 && !split()) throw std::invalid_argument("halo tiles 6 - 8 are fp16x3 kernels: " + name);
+    if (halo >= 6 && halo <= 8 && !split() && cin_pad % 64 != 0) throw std::invalid_argument("halo tiles 6 - 8 in the fp16 engines: input channels a multiple of 64: " + name);
   }
   if (halo >= 0) {
     pc.tile = 100 + halo;
@@ -342,6 +355,16 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     // 48.1 / 82.6 / 60.2 -> 77.9 / 54.6 / 90.2 / 65.6, decode_layer_5 98.6 -> 106.5, decode_layer_9 (128 -> 64 channels on
     // 320x640) 108.0 -> 102.2; 389 -> 381 frames/s with it everywhere.  So: only the short-K big-map case (as for tile 7);
     // VP_X3_C64=1 wherever the epilogue fits (plain, or anything behind split-K), =0 nowhere.
+    if ((halo == 3 || halo == 2) && !split() && !fp8_storage() && o.tile < 0 && cin_pad % 64 == 0 && ncols == 64 && !o.logits_out && !o.in2 && cstride == 1) {
+      // fp16 engines, 64-channel outputs on the big maps (decode_layer_9: 128 -> 64 channels on 320x640): the pipelined 64-channel shape
+      const char* e8 = dev_option("VP_F16_BIG");
+      const bool plain8 = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
+      if (plain8 && e8 && e8[0] != '0' && M >= 65536) {   // measured level with the halo kernel (decode_layer_9: 52.2 -> 52.0 us): only when forced
+        halo = 8;
+        pc.tile = 108;
+        pc.nsplit = 1;
+      }
+    }
     if (halo == 3 && split() && o.tile < 0 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 && cstride == 1) {
       const char* e8 = dev_option("VP_X3_C64");
       const bool plain8 = (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE;
@@ -362,7 +385,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   // kernel's tiles 0-5: every matrix layer of AutoDrive); the LDS-DMA / register-stationary kernels copy weight images verbatim and keep
   // de-quantised fp16 planes
   const bool w8 = fp8_storage() && ((halo < 0 && pc.tile == 2) || halo == 3 || halo == 4);
-  std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad, (half_t)0.0f), lo((split() && !w8) ? hi.size() : 0, (half_t)0.0f);
+  // fp16 engines on the pipelined kernels (halo tiles 6 - 8 without the lo plane): 64-channel chunks, the chunk's halves in two plane arrays
+  const bool k64 = halo >= 6 && halo <= 8 && !split();
+  std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad / (k64 ? 2 : 1), (half_t)0.0f), lo(((split() || k64) && !w8) ? hi.size() : 0, (half_t)0.0f);
   std::vector<uint8_t> codes(w8 ? (size_t)taps * pc.CoutW * cin_pad : 0, (uint8_t)0);
   RowScale rs = row_prescale(w.data(), cout, (size_t)cin * taps, pc.CoutW);
   if (w8)   // the rows' quantisation scales instead of the power-of-two prescale (e4m3 values need none: |q| in [2^-9, 448] are normal fp16 numbers)
@@ -381,6 +406,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
         const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)
+                         : k64     ? ((((size_t)(ci >> 6) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                          : halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
         if (w8) {
@@ -390,6 +416,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         }
         half_t h, l;
         split_half(v, rs.pre[co], &h, &l);
+        if (k64) {
+          ((ci >> 5) & 1 ? lo : hi)[d] = h;
+          continue;
+        }
         hi[d] = h;
         if (split()) lo[d] = l;
       }
@@ -400,7 +430,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     wbytes_[0] += codes.size();
   } else {
     pc.w_hi = dupload(hi);
-    pc.w_lo = split() ? dupload(lo) : nullptr;
+    pc.w_lo = (split() || k64) ? dupload(lo) : nullptr;
     wbytes_[1] += 2 * (hi.size() + lo.size());
   }
   pc.bias = dupload(bias);

@@ -166,6 +166,8 @@ struct FcParams {
   const float* b;
   float* out;
   int N, K, act;
+  // per-row activations of a small stacked matrix (N <= 4): byte n = ActFn of row n; 0 = `act` for every row (AutoDrive's three scalar heads in one launch)
+  unsigned act_rows;
   const float* partial;  // optional: x = mean over nslab partial sums (avg-pool input, scene_context.py:27)
   int nslab, Kstride;
   float inv_hw;
@@ -260,13 +262,18 @@ hipError_t launch_act_to_nchw(const ActView& a, int Creal, float* dst, hipStream
 hipError_t launch_chan_copy(const ActView& src, int src_off, const ActView& dst, int dst_off, int nch, hipStream_t st);
 // MaxPool2d(5, stride 1, pad 2) on a channel slice (SPPF, common_layers.py:236-243)
 hipError_t launch_maxpool5(const ActView& src, int src_off, const ActView& dst, int dst_off, int nch, hipStream_t st);
+// SPPF's pyramid in one launch: dst slice 0 = src[0, nch), slices 1..3 = the 5x5 / 9x9 / 13x13 clipped window maxima (= three chained MaxPool2d(5, 1, 2))
+bool sppf_pool_ok(const ActView& src, const ActView& dst, int nch);   // maps of at most 512 pixels (one workgroup holds an octet's map)
+hipError_t launch_sppf_pool(const ActView& src, const ActView& dst, int nch, hipStream_t st);
 struct AttnParams {
   ActView qkv;   // [HW][heads * (2*dk + dv)]: per head q(dk) | k(dk) | v(dv)   (Attention.forward, common_layers.py:95-99)
   ActView out;   // [HW][heads * dv] = v @ softmax(q^T k * scale)^T
   ActView vout;  // [HW][heads * dv] copy of v (input of the depthwise positional conv)
   int heads, dk, dv;
   float scale;
+  int qblock;    // 4: four query tokens per workgroup (attention_block_kernel: dk = 32, dv = 64, <= 2048 tokens); 0: one workgroup per query token
 };
+bool attention_block_ok(const AttnParams& p);
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);
 struct DwPlainParams {
   ActView in, out;   // out = add + dwconv3x3(in) (BN folded, no activation), common_layers.py:103

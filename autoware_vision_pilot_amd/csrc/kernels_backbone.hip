@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) p.out[n] = apply_act((p.w8 ? s * p.wscale8[n] : s) + p.b[n], p.act);
+    if (lane == 0) p.out[n] = apply_act((p.w8 ? s * p.wscale8[n] : s) + p.b[n], p.act_rows ? (int)((p.act_rows >> (8 * (n & 3))) & 0xffu) : p.act);
   }
 }
 
@@ -364,6 +364,7 @@ hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipS
   VP_LAUNCH(se_gate_scale_kernel<false>, dim3(sw.C / 32), dim3(256), lds, st, se, sw);
 }
 hipError_t launch_fc(const FcParams& p, hipStream_t st) {
+  if (p.act_rows && p.N > 4) return hipErrorInvalidValue;
   VP_LAUNCH(fc_kernel, dim3((p.N + 7) / 8), dim3(256), p.K * sizeof(float), st, p);
 }
 

@@ -296,7 +296,7 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st) {
 #define VP_HCASE(T, CO, TH, TW, WCO, WPX) \
   if (tile == T) return split ? launch_halo_cfg<CO, TH, TW, WCO, WPX, true>(p, st) : launch_halo_cfg<CO, TH, TW, WCO, WPX, false>(p, st);
-  if (tile >= 6 && tile <= 8) return split ? launch_conv3x3_x3(p, tile, st) : hipErrorInvalidValue;  // pipelined parity-mode kernels (kernels_conv3x3_x3.hip)
+  if (tile >= 6 && tile <= 8) return launch_conv3x3_x3(p, tile, st);  // pipelined kernels (kernels_conv3x3_x3.hip): fp16x3, or fp16 on 64-channel chunks (its own weight layout)
   if (tile == 3 && !split) return launch_halo_cfg<64, 8, 16, 1, 4, false>(p, st);
   VP_HCASE(1, 128, 8, 16, 2, 2)
   VP_HCASE(3, 64, 8, 16, 2, 2)

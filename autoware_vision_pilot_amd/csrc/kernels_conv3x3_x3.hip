@@ -59,7 +59,12 @@ namespace vp {
 // owner) was built, verified on the MI355X and measured in round 3: it removes the tile-quantisation tail (200 / 400 / 1600 tiles on 256 /
 // 512 slots) and changes nothing in the layer times (profiles/r03_streamk_layers.tsv) -- the big layers are bound chip-wide, not per
 // workgroup.  Kept out of the library: tools/dropped/kernels_conv3x3_x3_streamk.hip, DESIGN.md "tried and dropped".
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false>
+// X1 (round 4): the VP_FP16 engines' form of the same schedule.  One fp16 plane per tensor and ONE MFMA per product would leave a third of the
+// matrix work per barrier / staging step (measured slower than the halo kernel in round 2); instead a step covers SIXTY-FOUR input channels and
+// the two "planes" of every LDS image are the two 32-channel halves of that chunk: plane 0 = channels [64c, 64c + 32), plane 1 = [64c + 32,
+// 64c + 64) of the one fp16 tensor (weights packed likewise by the engine: w_hi / w_lo carry the two halves).  Same LDS plan, same DMA and
+// halo traffic per step, two MFMAs per fragment pair instead of three -- two thirds of the parity kernel's matrix work per barrier.
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool X1 = false>
 __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
@@ -80,7 +85,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   const int tiles_x = (p.W + TW - 1) / TW;
   const int n_px_tiles = tiles_x * ((p.H + TH - 1) / TH);
   const int n_co_tiles = p.CoutW / CO_TILE;
-  const int KC_all = p.Cin >> 5;
+  constexpr int CSTEP = X1 ? 64 : 32;  // input channels per chunk
+  const int KC_all = p.Cin / CSTEP;
+  const half_t* const in_p1 = X1 ? p.in_hi + 32 : p.in_lo;  // second plane of the halo image
   int vid;  // XCD-aware workgroup -> tile map (see kernels_conv3x3.hip)
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
@@ -163,9 +170,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 #define VP_LOAD_H(SLOT, PC, C)                                                               \
   {                                                                                          \
     const int g_ = h_goff[PC];                                                               \
-    const int o_ = (g_ >= 0 ? g_ : 0) + (c_first + (C)) * 32;                                \
+    const int o_ = (g_ >= 0 ? g_ : 0) + (c_first + (C)) * CSTEP;                             \
     const u32x4 v_ = *reinterpret_cast<const u32x4*>(p.in_hi + o_);                          \
-    const u32x4 l_ = *reinterpret_cast<const u32x4*>(p.in_lo + o_);                          \
+    const u32x4 l_ = *reinterpret_cast<const u32x4*>(in_p1 + o_);                            \
     rh_hi[SLOT] = g_ >= 0 ? v_ : zero4;                                                      \
     rh_lo[SLOT] = g_ >= 0 ? l_ : zero4;                                                      \
   }
@@ -193,6 +200,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
     const int i = q_ / NT, j = q_ % NT;                                                      \
     if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[SET][i][1] + (float)fb[SET][j][2] + (float)fbl[SET][j][3]; continue; } \
+    if constexpr (X1) { /* the planes are K halves: a0 . b0 + a1 . b1 */                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
+      continue;                                                                              \
+    }                                                                                        \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);  \
@@ -379,10 +391,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
         for (int r = 0; r < 4; ++r) {
           const float x = apply_act(fmaf(acc[i][j][4 * g + r], sc[g][r], b[g][r]), ACT);
           h[r] = (half_t)x;
-          l[r] = (half_t)(x - (float)h[r]);
+          if constexpr (!X1) l[r] = (half_t)(x - (float)h[r]);
         }
         *reinterpret_cast<h4_t*>(row + g * 16) = h;
-        *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
+        if constexpr (!X1) *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
       }
     }
   }
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
     if (m < 0) continue;
     const size_t o = (size_t)m * p.Cstore + co;
     *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
-    *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+    if constexpr (!X1) *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
   }
 }
 
@@ -407,19 +419,22 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 // factor as the halo kernel's 64-channel tile (halo tile 3), the pipelined schedule instead of its lone-wave one.
 bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
   const int co_tile = shape == 8 ? 64 : 128;
-  if (!(p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % 32 == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
-  const bool plain = p.out_lo && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && (p.act == ACT_GELU || p.act == ACT_NONE);
-  if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= (p.Cin >> 5);  // any epilogue: the finish kernel applies it
+  const bool x1 = p.in_lo == nullptr;  // VP_FP16 engines: the two planes are the halves of a 64-channel chunk (template parameter X1)
+  if (!(p.ks == 3 && p.stride <= 1 && p.in_hi && p.w_hi && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % (x1 ? 64 : 32) == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
+  const bool act_ok = x1 ? (p.act == ACT_GELU_F16 || p.act == ACT_NONE) : (p.act == ACT_GELU || p.act == ACT_NONE);
+  const bool plain = p.out_hi && (x1 ? p.out_lo == nullptr : p.out_lo != nullptr) && p.store_mode == STORE_NHWC && p.res_mode == RES_NONE && p.post_act == ACT_NONE && act_ok;
+  if (p.nsplit > 1) return p.partial != nullptr && p.nsplit <= p.Cin / (x1 ? 64 : 32);  // any epilogue: the finish kernel applies it
   return plain;
 }
 
-template <int CO, int TH, int WPX, bool HDB>
+template <int CO, int TH, int WPX, bool HDB, bool X1>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (CO * 64);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  const bool gelu = p.act == ACT_GELU, sk = p.nsplit > 1;
-  auto k = sk ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, 0, true>
-              : (gelu ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_GELU> : conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE>);
+  constexpr int GELU = X1 ? ACT_GELU_F16 : ACT_GELU;
+  const bool gelu = p.act == GELU, sk = p.nsplit > 1;
+  auto k = sk ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, 0, true, X1>
+              : (gelu ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, GELU, 0, false, X1> : conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, 0, false, X1>);
   static LdsAttrOnce attr_once[3];
   if (hipError_t e = set_max_dynamic_lds(attr_once[sk ? 2 : gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / CO) * p.nsplit);
@@ -433,9 +448,15 @@ static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
 // shape 8: shape 7 on 64-channel tiles
 hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st) {
   if (!conv3x3_x3_supported(p, shape)) return hipErrorInvalidValue;
-  if (shape == 6) return launch_x3_cfg<128, 16, 4, true>(p, st);
-  if (shape == 7) return launch_x3_cfg<128, 8, 2, false>(p, st);
-  if (shape == 8) return launch_x3_cfg<64, 8, 2, false>(p, st);
+  if (p.in_lo == nullptr) {  // VP_FP16 engines
+    if (shape == 6) return launch_x3_cfg<128, 16, 4, true, true>(p, st);
+    if (shape == 7) return launch_x3_cfg<128, 8, 2, false, true>(p, st);
+    if (shape == 8) return launch_x3_cfg<64, 8, 2, false, true>(p, st);
+    return hipErrorInvalidValue;
+  }
+  if (shape == 6) return launch_x3_cfg<128, 16, 4, true, false>(p, st);
+  if (shape == 7) return launch_x3_cfg<128, 8, 2, false, false>(p, st);
+  if (shape == 8) return launch_x3_cfg<64, 8, 2, false, false>(p, st);
   return hipErrorInvalidValue;
 }
 

@@ -157,8 +157,11 @@ int emu_fc(const float* x, const float* w, const float* b, float* out, int N, in
 int emu_maxpool5(void* src_hi, int H, int W, int C, int src_off, void* dst_hi, int dstC, int dst_off, int nch) {
   return launch_maxpool5(view(src_hi, nullptr, H, W, C), src_off, view(dst_hi, nullptr, H, W, dstC), dst_off, nch, nullptr);
 }
-int emu_attention(void* qkv_hi, void* qkv_lo, int H, int W, int heads, int dk, int dv, float scale, void* out_hi, void* out_lo, void* v_hi, void* v_lo) {
-  AttnParams p{view(qkv_hi, qkv_lo, H, W, heads * (2 * dk + dv)), view(out_hi, out_lo, H, W, heads * dv), view(v_hi, v_lo, H, W, heads * dv), heads, dk, dv, scale};
+int emu_sppf_pool(void* src_hi, void* src_lo, int H, int W, int C, void* dst_hi, void* dst_lo, int dstC, int nch) {
+  return launch_sppf_pool(view(src_hi, src_lo, H, W, C), view(dst_hi, dst_lo, H, W, dstC), nch, nullptr);
+}
+int emu_attention(void* qkv_hi, void* qkv_lo, int H, int W, int heads, int dk, int dv, float scale, void* out_hi, void* out_lo, void* v_hi, void* v_lo, int qblock) {
+  AttnParams p{view(qkv_hi, qkv_lo, H, W, heads * (2 * dk + dv)), view(out_hi, out_lo, H, W, heads * dv), view(v_hi, v_lo, H, W, heads * dv), heads, dk, dv, scale, qblock};
   return launch_attention(p, nullptr);
 }
 int emu_pool_partial(void* hi, void* lo, int H, int W, int C, float* partial, int nslab) {

@@ -28,7 +28,8 @@ int emu_mbconv_back(void*, void*, int, int, int, int, const unsigned long long*,
 int emu_fc(const float*, const float*, const float*, float*, int, int, int);
 int emu_detect(const float*, int, int, float, float, float, int, int, int, int, float*, int*, void*, int, int*);
 int emu_pool_partial(void*, void*, int, int, int, float*, int);
-int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*);
+int emu_attention(void*, void*, int, int, int, int, int, float, void*, void*, void*, void*, int);
+int emu_sppf_pool(void*, void*, int, int, int, void*, void*, int, int);
 int emu_depth_viz(const float*, size_t, const uint8_t*, uint8_t*);
 int emu_maxpool5(void*, int, int, int, int, void*, int, int, int);
 }
@@ -102,6 +103,10 @@ int main(int argc, char** argv) {
     for (int tile : {0, 1, 2, 3}) {  // K1 GEMM
       if (quick && tile != 1) continue;
       bad |= conv(precision, 0, 96, 40, 7, 13, 1, 2, tile, tile == 2 ? 64 : 32, tile == 1 ? 2 : 1);
+    }
+    if (precision == 0) {  // the fp16 engines' form of the pipelined kernels: 64-channel chunks, the chunk's halves as the two LDS planes
+      bad |= conv(0, 0, 128, 128, 17, 19, 3, 1, 106, -1, 1);
+      if (!quick) bad |= conv(0, 0, 192, 128, 11, 19, 3, 1, 107, -1, 1);
     }
     if (precision == 1 || quick) {  // 8-wave fp16x3 kernel: 3 weight buffers, cross-tap fragment prefetch, 2 chunks
       bad |= conv(1, 0, 64, 128, 17, 19, 3, 1, 106, -1, 1);
@@ -187,7 +192,16 @@ int main(int argc, char** argv) {
   {  // AutoDrive attention, SPPF pool; depth visualisation
     const int heads = 2, dk = 8, dv = 16, Hq = 6, Wq = 7, T = Hq * Wq, per = 2 * dk + dv;
     std::vector<half_t> qh = rnd16((size_t)T * heads * per), ql = rnd16(qh.size()), oh((size_t)T * heads * dv), ol(oh.size()), vh(oh.size()), vl(oh.size());
-    bad |= emu_attention(qh.data(), ql.data(), Hq, Wq, heads, dk, dv, 0.35f, oh.data(), ol.data(), vh.data(), vl.data());
+    bad |= emu_attention(qh.data(), ql.data(), Hq, Wq, heads, dk, dv, 0.35f, oh.data(), ol.data(), vh.data(), vl.data(), 0);
+    {  // four query tokens per workgroup (dk = 32, dv = 64): LDS scores, two block reductions, value partials of 32 token slices meeting in LDS
+      const int dk2 = 32, dv2 = 64, per2 = 2 * dk2 + dv2;
+      std::vector<half_t> q2 = rnd16((size_t)T * heads * per2), q2l = rnd16(q2.size()), o2((size_t)T * heads * dv2), o2l(o2.size()), v2(o2.size()), v2l(o2.size());
+      bad |= emu_attention(q2.data(), q2l.data(), Hq, Wq, heads, dk2, dv2, 0.18f, o2.data(), o2l.data(), v2.data(), v2l.data(), 4);
+    }
+    {  // SPPF pyramid: the octet's map and its three row-maximum images in LDS, two barriers
+      std::vector<half_t> s2 = rnd16(11 * 14 * 32), s2l = rnd16(s2.size()), d2(11 * 14 * 64), d2l(d2.size());
+      bad |= emu_sppf_pool(s2.data(), s2l.data(), 11, 14, 32, d2.data(), d2l.data(), 64, 16);
+    }
     std::vector<half_t> src = rnd16(9 * 12 * 32), dst(9 * 12 * 64);
     bad |= emu_maxpool5(src.data(), 9, 12, 32, 8, dst.data(), 64, 32, 16);
     std::vector<float> depth = rnd(37 * 53);

@@ -78,7 +78,7 @@ def test_halo_3x3_kernel_every_tile(emu_lib, precision):
 
 
 def test_x3w8_kernel(emu_lib):
-    """kernels_conv3x3_x3.hip (halo tiles 6 and 7): the pipelined fp16x3 kernels -- fragment prefetch across tap (and, tile 6,
+    """kernels_conv3x3_x3.hip (halo tiles 6 - 8): the pipelined fp16x3 kernels -- fragment prefetch across tap (and, tile 6,
     chunk) boundaries, three weight buffers, single-buffered halo with the two-barrier chunk hand-over (tile 7), register
     epilogue with both planes; one and several 32-channel chunks, GELU and no activation, an image that is not a multiple of
     the patch, two output-channel tiles; bit-identical to halo tile 1 (same K order)."""
@@ -97,10 +97,22 @@ def test_x3w8_kernel(emu_lib):
     # split-K slices of the 4-wave shape (fp32 partials + finish kernel), incl. a mul-add residual (context_layer_6's epilogue)
     _case(emu_lib, 160, 128, 10, 20, 3, 0, 1, 0, 1, [(107, -1, 2), (107, -1, 5)], seed=24)
     _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3), (108, -1, 3)], seed=25)
+
+
+def test_x1_k64_kernel(emu_lib):
+    """The VP_FP16 engines' form of the pipelined kernels (kernels_conv3x3_x3.hip, template parameter X1; halo tiles 6 - 8 with one fp16 plane
+    per tensor): a step covers a 64-channel chunk, its two 32-channel halves travel as the two LDS planes (weights packed likewise by the
+    engine), two MFMAs per fragment pair.  One and several chunks, GELU and none, ragged maps, two output-channel tiles, split-K slices with
+    a mul-add residual behind the finish kernel; input channels that are not a multiple of 64 are refused."""
+    _case(emu_lib, 64, 128, 16, 32, 3, 0, 1, 0, 0, [(106, -1, 1), (107, -1, 1), (108, -1, 1)], seed=27)     # one chunk
+    _case(emu_lib, 192, 256, 19, 21, 3, 0, 0, 0, 0, [(106, -1, 1), (107, -1, 1), (108, -1, 1)], seed=28)    # three chunks, ragged map, no activation
+    _case(emu_lib, 100, 64, 9, 17, 3, 0, 1, 0, 0, [(108, -1, 1), (108, -1, 2)], seed=29)                    # 100 -> 128 padded channels: two chunks; two K slices
+    _case(emu_lib, 256, 128, 10, 20, 3, 0, 1, 2, 0, [(107, -1, 2), (107, -1, 4)], seed=30)                  # split-K + mul-add residual (finish kernel)
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((96, 16, 16), dtype=np.float32)
+    wt = rng.standard_normal((128, 96, 3, 3), dtype=np.float32) * np.float32(0.05)
     with pytest.raises(emu_lib.VpError):
-        emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=107, nsplit=1)      # fp16 engines have no tile 7
-    with pytest.raises(emu_lib.VpError):
-        emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=0, tile=106, nsplit=1)      # ... nor tile 6 (its single-plane form was measured slower and removed)
+        emu_lib.op_conv2d(x, wt, np.zeros(128, np.float32), ks=3, act=1, precision=0, tile=107, nsplit=1)     # 96 input channels: not a multiple of 64
 
 
 @pytest.mark.parametrize("precision", [0, 1], ids=["fp16", "fp16x3"])

@@ -55,6 +55,37 @@ def test_autodrive_engine_end_to_end_on_cpu(emu_lib):
         eng.close()
 
 
+def test_autodrive_attention_block_kernel_matches_per_query_kernel(emu_lib, vp_opts):
+    """kernels_autodrive.hip: the four-queries-per-workgroup attention (round 4; the plan's default for C2PSA's dk = 32, dv = 64) against the
+    one-query-per-workgroup kernel it replaces (VP_ATTN_BLOCK=0) on the same network and frames: the attention output and the copy of v, both
+    (hi, lo) planes -- same arithmetic order per output except the order of the softmax denominator's sum."""
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+
+    g = np.load(GOLDEN)
+    frames = [synthetic.synthetic_frame(1080, 1920, int(s)) for s in g["frame_seeds"]]
+    blob = vw.pack_state_dict(synthetic.make_autodrive_state_dict(int(g["weight_seed"])))
+
+    def run():
+        eng = emu_lib.Engine("autodrive", blob, precision="fp16x3")
+        try:
+            eng._ck(eng._lib.vp_use_graph(eng._h, 0))
+            eng.infer_pair(frames[0], frames[1])
+            t = {n: eng.tensor_read(i) for i, (n, c, h, w) in enumerate(eng.tensors()) if n.endswith(".conv1.attn") or n.endswith(".conv1.v")}
+            return t, [k for k in _layer_kernels(eng) if k.startswith("attention")], eng.logits().reshape(3).copy()
+        finally:
+            eng.close()
+
+    new, tags_new, out_new = run()
+    vp_opts.setenv("VP_ATTN_BLOCK", "0")
+    old, tags_old, out_old = run()
+    assert tags_new == ["attention<q4>"] and tags_old == ["attention"]
+    assert len(new) == 2 and set(new) == set(old)
+    for n in new:
+        scale = float(np.abs(old[n]).max())
+        assert scale > 0 and float(np.abs(new[n] - old[n]).max()) <= 2e-6 * scale, n
+    assert np.abs(out_new - out_old).max() <= 1e-5
+
+
 def test_autodrive_fp8_storage_parity_mode_on_cpu(emu_lib):
     """BASELINE configs[4] with the fp8 weights as REAL storage (round 4): every conv / linear weight of the plan is one e4m3 byte + a row scale in
     HBM (conv_gemm / halo kernels and the FC kernel convert on the fly), activations in the parity mode -- against the reference module's outputs on

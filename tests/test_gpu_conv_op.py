@@ -101,9 +101,15 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
             sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=ns)
             assert (np.abs(sk - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5
             assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=108, nsplit=ns))   # same slices, same finish kernel
-    for tile in (106, 107):   # parity-mode kernels only (the single-plane form of the 8-wave shape was measured slower and removed)
-        with pytest.raises(lib.VpError):
-            lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=tile, nsplit=1)
+    # VP_FP16 engines: the same shapes on 64-channel chunks (X1: the chunk's halves in the two LDS planes); other channel counts are refused
+    ref16 = _reference(x, wt, b, 3, 0, act, None, 0, fp16=True)
+    for tile in (106, 107, 108):
+        if ((cin + 31) // 32 * 32) % 64 == 0:
+            g16 = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=tile, nsplit=1)
+            assert (np.abs(g16 - ref16) / np.maximum(1.0, np.abs(ref16))).max() <= 1.5e-3, tile
+        else:
+            with pytest.raises(lib.VpError):
+                lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=tile, nsplit=1)
 
 
 def test_conv_op_transpose_detecting():

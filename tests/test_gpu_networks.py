@@ -100,7 +100,7 @@ def test_class_map_parity(engines, oracle_runs, frame720):
     ref_cls = pre_post.argmax_classes(ref_out)
     srt = np.sort(ref_out, axis=0)
     margin = srt[-1] - srt[-2]
-    for precision, band, min_agree in (("fp16x3", 2e-3, 0.9995), ("fp16", 0.25, 0.995)):
+    for precision, band, min_agree in (("fp16x3", None, 1.0), ("fp16", 0.25, 0.995)):
         eng = engines("sceneseg", precision)
         eng.set_decode_mode(lib.VP_DECODE_CLASS_INDEX)
         eng.infer(frame720)
@@ -108,8 +108,14 @@ def test_class_map_parity(engines, oracle_runs, frame720):
         # decode itself is integer work: bit-exact against the oracle decode of the SAME logits
         assert np.array_equal(cls, pre_post.argmax_classes(eng.logits()))
         flips = cls != ref_cls
-        assert flips.mean() <= 1 - min_agree, f"{precision}: {flips.sum()} flips"
-        assert (margin[flips] < band).all(), f"{precision}: flip outside tolerance band, max margin {margin[flips].max():.3e}"
+        if band is None:
+            # parity mode, the sweep's strict rule (tests/test_gpu_parity_sweep.py): ZERO flips except at pixels whose oracle decision margin is at
+            # most twice the MEASURED maximum logit error of this pass -- a tie inside the float tolerance (measured on this frame: 0 flips)
+            band = 2.0 * float(np.abs(eng.logits() - ref_out).max()) + 1e-12
+            assert band <= 2e-3
+        else:
+            assert flips.mean() <= 1 - min_agree, f"{precision}: {flips.sum()} flips"
+        assert (margin[flips] <= band).all(), f"{precision}: {flips.sum()} flips, one outside the tolerance band {band:.3e}: max margin {margin[flips].max():.3e}"
         eng.set_decode_mode(lib.VP_DECODE_SEG_MASK)
         eng.infer(frame720)
         assert np.array_equal(eng.mask(), pre_post.seg_mask_u8(eng.logits()))

@@ -446,23 +446,44 @@ def test_maxpool5_and_attention_kernels(emu):
     assert np.array_equal(dst[..., 32:48].astype(np.float32), want[8:24].transpose(1, 2, 0))
     assert not dst[..., :32].any() and not dst[..., 48:].any()
 
-    heads, dk, dv = 2, 8, 16
-    Hq, Wq = 6, 7
-    T, per = Hq * Wq, 2 * dk + dv
-    qkv = rng.standard_normal((T, heads * per)).astype(np.float32)
-    qh, ql = split16(qkv)
-    q32 = torch.from_numpy(qh.astype(np.float32) + ql.astype(np.float32))
-    oh, ol = np.zeros((T, heads * dv), np.float16), np.zeros((T, heads * dv), np.float16)
-    vh, vl = np.zeros_like(oh), np.zeros_like(ol)
-    scale = dk ** -0.5
-    emu.emu_attention.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 4
-    assert emu.emu_attention(ptr(qh), ptr(ql), Hq, Wq, heads, dk, dv, scale, ptr(oh), ptr(ol), ptr(vh), ptr(vl)) == 0
-    got = oh.astype(np.float32) + ol.astype(np.float32)
-    for h in range(heads):
-        q, k, v = (q32[:, h * per + a:h * per + b] for a, b in ((0, dk), (dk, 2 * dk), (2 * dk, per)))
-        want = torch.softmax(q @ k.T * scale, dim=1) @ v                              # common_layers.py:95-101
-        assert np.abs(got[:, h * dv:(h + 1) * dv] - want.numpy()).max() <= 1e-5
-        assert np.abs((vh.astype(np.float32) + vl.astype(np.float32))[:, h * dv:(h + 1) * dv] - v.numpy()).max() <= 1e-6
+    # SPPF's pyramid in one launch: slice 0 = x, slices 1..3 = three CHAINED 5x5 max-pools, bit for bit, on (hi, lo) planes; 17x20 > the 13x13 window
+    H2, W2, C2, n2 = 17, 20, 32, 24
+    x2 = rng.standard_normal((H2, W2, C2)).astype(np.float32)
+    sh2, sl2 = split16(x2)
+    dh2, dl2 = np.full((H2, W2, 96), 9, np.float16), np.full((H2, W2, 96), 9, np.float16)
+    assert emu.emu_sppf_pool(ptr(sh2), ptr(sl2), H2, W2, C2, ptr(dh2), ptr(dl2), 96, n2) == 0
+    xv = torch.from_numpy((sh2.astype(np.float32) + sl2.astype(np.float32))[..., :n2].transpose(2, 0, 1).copy())[None]
+    got2 = dh2.astype(np.float32) + dl2.astype(np.float32)
+    want2 = [xv]
+    for _ in range(3):
+        want2.append(F.max_pool2d(want2[-1], 5, 1, 2))
+    for i, wv in enumerate(want2):
+        assert np.array_equal(got2[..., i * n2:(i + 1) * n2], wv[0].numpy().transpose(1, 2, 0)), i
+    assert emu.emu_sppf_pool(ptr(sh2), ptr(sl2), H2, W2, C2, ptr(dh2), ptr(dl2), 96, 28) != 0      # 4 x 28 channels do not fit 96 (and 28 is not an octet multiple)
+
+    emu.emu_attention.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float] + [ct.c_void_p] * 4 + [ct.c_int]
+    # one workgroup per query token (any dk, dv); four query tokens per workgroup (C2PSA's dk = 32, dv = 64; 42 tokens: the last block holds two
+    # queries), (hi, lo) planes and a single fp16 plane
+    for heads, dk, dv, qblock, planes in ((2, 8, 16, 0, 2), (2, 32, 64, 4, 2), (1, 32, 64, 4, 1), (2, 32, 64, 0, 2)):
+        Hq, Wq = 6, 7
+        T, per = Hq * Wq, 2 * dk + dv
+        qkv = rng.standard_normal((T, heads * per)).astype(np.float32)
+        qh, ql = split16(qkv)
+        q32 = torch.from_numpy(qh.astype(np.float32) + (ql.astype(np.float32) if planes == 2 else 0.0))
+        oh, ol = np.zeros((T, heads * dv), np.float16), np.zeros((T, heads * dv), np.float16)
+        vh, vl = np.zeros_like(oh), np.zeros_like(ol)
+        scale = dk ** -0.5
+        lo = (lambda a: ptr(a)) if planes == 2 else (lambda a: None)
+        assert emu.emu_attention(ptr(qh), lo(ql), Hq, Wq, heads, dk, dv, scale, ptr(oh), lo(ol), ptr(vh), lo(vl), qblock) == 0
+        got = oh.astype(np.float32) + ol.astype(np.float32)
+        tol = 1e-5 if planes == 2 else 2e-3
+        for h in range(heads):
+            q, k, v = (q32[:, h * per + a:h * per + b] for a, b in ((0, dk), (dk, 2 * dk), (2 * dk, per)))
+            want = torch.softmax(q @ k.T * scale, dim=1) @ v                              # common_layers.py:95-101
+            assert np.abs(got[:, h * dv:(h + 1) * dv] - want.numpy()).max() <= tol, (heads, dk, dv, qblock, planes)
+            assert np.abs((vh.astype(np.float32) + vl.astype(np.float32))[:, h * dv:(h + 1) * dv] - v.numpy()).max() <= 1e-6
+    oh2 = np.zeros((42, 128), np.float16)
+    assert emu.emu_attention(ptr(qh), ptr(ql), 6, 7, 2, 16, 32, 0.25, ptr(oh2), ptr(oh2), ptr(oh2), ptr(oh2), 4) != 0    # the block kernel is dk = 32, dv = 64 only
 
 
 def test_layout_conversion_kernels_roundtrip(emu):
