@@ -397,7 +397,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       rs.post[co] = fp8_row_scale(amax);
       rs.pre[co] = 1.0f / rs.post[co];
     }
-  for (int co = 0; co < cout; ++co)
+  parallel_rows(cout, [&](int co_begin, int co_end) {
+  for (int co = co_begin; co < co_end; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int t = 0; t < taps; ++t) {
         const float v = w[((size_t)co * cin + ci) * taps + t];
@@ -423,6 +424,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         hi[d] = h;
         if (split()) lo[d] = l;
       }
+  });
   std::vector<float> bias(pc.CoutW, 0.0f);
   for (int co = 0; co < cout; ++co) bias[co] = b[co];
   if (w8) {
@@ -497,8 +499,9 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
     throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
   std::vector<half_t> hi((size_t)pc.CoutW * cin_pad, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
   std::vector<float> bias(pc.CoutW, 0.0f), post(pc.CoutW, 1.0f);
-  for (int q = 0; q < 4; ++q)
-    for (int co = 0; co < cout; ++co) {
+  parallel_rows(4 * cout, [&](int r_begin, int r_end) {
+    for (int r = r_begin; r < r_end; ++r) {
+      const int q = r / cout, co = r - q * cout;
       const int n = q * cpad + co;
       bias[n] = b[co];
       float amax = 0.0f;   // prescale per GEMM row n = (quadrant, output channel)
@@ -515,6 +518,7 @@ Act* Engine::add_convT(const std::string& name, const Act* in, const std::vector
         if (split()) lo[d] = l;
       }
     }
+  });
   pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
   wbytes_[1] += 2 * (hi.size() + lo.size());
@@ -568,8 +572,9 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
   const int kw = cin_pad + cs_pad;
   std::vector<half_t> hi((size_t)pc.CoutW * kw, (half_t)0.0f), lo(split() ? hi.size() : 0, (half_t)0.0f);
   std::vector<float> bias(pc.CoutW, 0.0f), post(pc.CoutW, 1.0f);
-  for (int q = 0; q < 4; ++q)
-    for (int co = 0; co < cout; ++co) {
+  parallel_rows(4 * cout, [&](int r_begin, int r_end) {
+    for (int r = r_begin; r < r_end; ++r) {
+      const int q = r / cout, co = r - q * cout;
       const int n = q * cpad + co;
       bias[n] = bt[co] + bs[co];
       float amax = 0.0f;   // prescale per GEMM row over BOTH weight sets of its K axis
@@ -587,7 +592,8 @@ Act* Engine::add_convT_skip(const std::string& up_name, const std::string& skip_
         if (split()) lo[d] = l;
       }
     }
- pc.w_hi = dupload(hi);
+  });
+  pc.w_hi = dupload(hi);
   pc.w_lo = split() ? dupload(lo) : nullptr;
   wbytes_[1] += 2 * (hi.size() + lo.size());
   pc.bias = dupload(bias);

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <thread>
 
 #include "conv_epilogue.hpp"
 #include "engine.hpp"
@@ -47,6 +49,32 @@ RowScale row_prescale(const float* w, size_t rows, size_t per, size_t rows_alloc
 // (one byte per weight in HBM) and multiply the fp32 accumulator by S in the epilogue (ConvGemmParams::wscale).
 uint8_t e4m3_encode(float q);                                  // nearest OCP e4m3 code of q (|q| <= 448)
 inline float fp8_row_scale(float amax) { return amax > 0.0f ? amax / 448.0f : 1.0f; }
+
+// Weight packing is host work over every weight of the network (~40 M scattered (hi, lo) stores for a scene network: 1.1 s of vp_create on one
+// thread, measured): rows [0, n) are handed to a few threads in contiguous ranges.  `fn(begin, end)` must write disjoint locations for disjoint
+// rows; the first exception any range throws (a RangeError of split_half) is re-thrown on the calling thread after all have joined.
+template <class Fn>
+void parallel_rows(int n, Fn&& fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nt = std::max(1, std::min<int>({8, (int)(hw ? hw : 1), n / 16}));
+  if (nt <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(nt);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      try {
+        fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
+      } catch (...) {
+        err[t] = std::current_exception();
+      }
+    });
+  for (std::thread& x : th) x.join();
+  for (const std::exception_ptr& e : err)
+    if (e) std::rethrow_exception(e);
+}
 
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {

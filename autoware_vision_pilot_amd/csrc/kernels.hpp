@@ -188,7 +188,9 @@ struct FusionParams {
   int shift[5];   // 4,3,2,1,0
   ActView out;    // 10x20 x 1472 (1456 real)
   int Creal_out;
+  int octets;     // 1: one workgroup per output pixel, 16-byte pieces, window slices meeting in LDS (fusion_octets_ok); 0: a thread per output element
 };
+bool fusion_octets_ok(const FusionParams& p);
 
 // tile ids: 0 = 128co x 128px, 1 = 64co x 128px, 2 = 64co x 64px, 3 = 32co x 128px ; bk = 32 | 64
 hipError_t launch_conv_gemm(const ConvGemmParams& p, int tile, int bk, bool split, hipStream_t st);

@@ -106,6 +106,8 @@ __global__ __launch_bounds__(256) void ctx_conv1_kernel(const CtxConv1Params p) 
 
 // --------------------------------------------------------------------------------- EgoLanes feature fusion
 // MaxPool2x2 applied n times == max over a 2^n x 2^n window; concat along C (backbone_feature_fusion.py:13-38).
+// One thread per output element, walking its window two bytes at a time: the fallback for channel counts that are not octet multiples
+// (and, until round 4, the only form: 115 us of an EgoLanes frame -- the 6400 threads of the stride-2 tap each chained 512 loads).
 __global__ __launch_bounds__(256) void fusion_kernel(const FusionParams p) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int HW = p.out.H * p.out.W;
@@ -130,6 +132,61 @@ __global__ __launch_bounds__(256) void fusion_kernel(const FusionParams p) {
   const half_t h = (half_t)best;
   p.out.hi[t] = h;
   if (p.out.lo) p.out.lo[t] = (half_t)(best - (float)h);
+}
+// Round 4: one workgroup per output pixel.  A work unit = (tap, channel octet, slice of the tap's window): up to 16 window elements fetched as
+// independent 16-byte pieces, their maximum parked in LDS; a second pass takes the maximum over a (tap, octet)'s slices and stores 8 channels.
+// Same values as the kernel above (a maximum has no rounding), ~8 us instead of 115.
+__global__ __launch_bounds__(256) void fusion_octet_kernel(const FusionParams p) {
+  __shared__ float part[512 * 8];
+  const int pix = blockIdx.x, tid = threadIdx.x;
+  const int y = pix / p.out.W, x = pix - y * p.out.W;
+  // unit ranges per tap: octets * slices, slices = min(window elements, 16)
+  int ubase[6], nsl[5];
+  ubase[0] = 0;
+#pragma unroll
+  for (int l = 0; l < 5; ++l) {
+    const int n2 = 1 << (2 * p.shift[l]);
+    nsl[l] = n2 < 16 ? n2 : 16;
+    ubase[l + 1] = ubase[l] + (p.creal[l] >> 3) * nsl[l];
+  }
+  for (int u = tid; u < ubase[5]; u += 256) {
+    int l = 0;
+    while (u >= ubase[l + 1]) ++l;
+    const int r = u - ubase[l], oct = r / nsl[l], sl = r - oct * nsl[l];
+    const ActView& a = p.f[l];
+    const int n = 1 << p.shift[l], n2 = n * n, per = n2 / nsl[l];
+    float best[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) best[i] = -3.0e38f;
+#pragma unroll 4
+    for (int e = sl * per; e < (sl + 1) * per; ++e) {
+      const int dy = e >> p.shift[l], dx = e & (n - 1);
+      float v[8];
+      load8(a, ((size_t)(y * n + dy) * a.W + (x * n + dx)) * a.C + oct * 8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) best[i] = fmaxf(best[i], v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[u * 8 + i] = best[i];
+  }
+  __syncthreads();
+  const int n_oct = p.out.C >> 3;
+  for (int o = tid; o < n_oct; o += 256) {
+    float best[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) best[i] = 0.0f;   // pad channels stay zero
+    if (o * 8 < p.Creal_out) {
+      int l = 0, oc = o;
+      while (oc >= (p.creal[l] >> 3)) { oc -= p.creal[l] >> 3; ++l; }
+      const float* src = part + (ubase[l] + oc * nsl[l]) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) best[i] = src[i];
+      for (int s = 1; s < nsl[l]; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) best[i] = fmaxf(best[i], src[s * 8 + i]);
+    }
+    store8(p.out, (size_t)pix * p.out.C + o * 8, best);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ decode
@@ -313,7 +370,21 @@ hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st) {
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st) {
   VP_LAUNCH(ctx_conv1_kernel, dim3(nblk((long long)p.H * p.W * (p.out.C >> 3))), dim3(256), 0, st, p);
 }
+bool fusion_octets_ok(const FusionParams& p) {
+  int units = 0, creal = 0;
+  for (int l = 0; l < 5; ++l) {
+    if ((p.creal[l] & 7) || p.shift[l] < 0 || p.shift[l] > 6) return false;
+    const int n2 = 1 << (2 * p.shift[l]);
+    units += (p.creal[l] >> 3) * (n2 < 16 ? n2 : 16);
+    creal += p.creal[l];
+  }
+  return units <= 512 && creal == p.Creal_out && (p.Creal_out & 7) == 0 && (p.out.C & 7) == 0;
+}
 hipError_t launch_fusion(const FusionParams& p, hipStream_t st) {
+  if (p.octets) {
+    if (!fusion_octets_ok(p)) return hipErrorInvalidValue;
+    VP_LAUNCH(fusion_octet_kernel, dim3(p.out.H * p.out.W), dim3(256), 0, st, p);
+  }
   VP_LAUNCH(fusion_kernel, dim3(nblk((long long)p.out.H * p.out.W * p.out.C)), dim3(256), 0, st, p);
 }
 hipError_t launch_decode_mask(const float* logits, int C, int HW, int mode, uint8_t* out, hipStream_t st) {

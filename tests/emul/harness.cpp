@@ -179,7 +179,7 @@ int emu_ctx_conv1(const float* map, int H, int W, const float* w, const float* b
 }
 // f[i]: hi/lo planes, H, W, C of the five backbone taps; out: 10x20-style map with Cout padded channels
 int emu_fusion(void** hi, void** lo, const int* H, const int* W, const int* C, const int* creal, const int* shift, void* out_hi, void* out_lo, int OH,
-               int OW, int Cout, int Creal_out) {
+               int OW, int Cout, int Creal_out, int octets) {
   FusionParams p{};
   for (int i = 0; i < 5; ++i) {
     p.f[i] = view(hi[i], lo ? lo[i] : nullptr, H[i], W[i], C[i]);
@@ -188,6 +188,7 @@ int emu_fusion(void** hi, void** lo, const int* H, const int* W, const int* C, c
   }
   p.out = view(out_hi, out_lo, OH, OW, Cout);
   p.Creal_out = Creal_out;
+  p.octets = octets;
   return launch_fusion(p, nullptr);
 }
 int emu_chan_copy(void* shi, void* slo, int H, int W, int C, int src_off, void* dhi, void* dlo, int dC, int dst_off, int nch) {

@@ -532,27 +532,38 @@ def test_context_path_kernels(emu):
 
 
 def test_egolanes_feature_fusion_kernel(emu):
-    """backbone_feature_fusion.py:13-38: MaxPool2x2 applied 4/3/2/1/0 times to the five taps, concat along C."""
+    """backbone_feature_fusion.py:13-38: MaxPool2x2 applied 4/3/2/1/0 times to the five taps, concat along C.  Two kernels: a thread per output
+    element (any channel counts) and, round 4, a workgroup per output pixel on 16-byte pieces with the window slices meeting in LDS (octet
+    multiples: the network's 32 / 24 / 40 / 80 / 1280) -- identical results, a maximum has no rounding."""
     rng = np.random.default_rng(19)
     OH, OW = 2, 3
-    creal, cpad, shift = [6, 5, 7, 9, 12], [32, 32, 32, 32, 32], [4, 3, 2, 1, 0]
-    taps, his, los = [], [], []
-    for cr, cp, sh in zip(creal, cpad, shift):
-        t = rng.standard_normal((cr, OH << sh, OW << sh)).astype(np.float32)
-        h, l = split16(nhwc(t, cp))
-        taps.append((h.astype(np.float32) + l.astype(np.float32)).transpose(2, 0, 1)[:cr])
-        his.append(h)
-        los.append(l)
-    Creal_out, Cout = sum(creal), 64
-    ohi, olo = np.full((OH, OW, Cout), 3, np.float16), np.full((OH, OW, Cout), 3, np.float16)
+    shift = [4, 3, 2, 1, 0]
     arr = lambda xs: (ct.c_void_p * 5)(*[x.ctypes.data for x in xs])
     ints = lambda xs: (ct.c_int * 5)(*xs)
-    assert emu.emu_fusion(arr(his), arr(los), ints([OH << s for s in shift]), ints([OW << s for s in shift]), ints(cpad), ints(creal), ints(shift),
-                          ptr(ohi), ptr(olo), OH, OW, Cout, Creal_out) == 0
-    want = np.concatenate([F.max_pool2d(torch.from_numpy(t)[None], 1 << s)[0].numpy() if s else t for t, s in zip(taps, shift)], axis=0)
-    got = (ohi.astype(np.float32) + olo.astype(np.float32)).transpose(2, 0, 1)
-    assert np.abs(got[:Creal_out] - want).max() <= 3e-7 * np.abs(want).max()
-    assert not got[Creal_out:].any()
+    for creal, cpad, Cout, modes in (([6, 5, 7, 9, 12], [32, 32, 32, 32, 32], 64, (0,)), ([32, 24, 40, 80, 136], [32, 32, 64, 96, 160], 320, (0, 1))):
+        taps, his, los = [], [], []
+        for cr, cp, sh in zip(creal, cpad, shift):
+            t = rng.standard_normal((cr, OH << sh, OW << sh)).astype(np.float32)
+            h, l = split16(nhwc(t, cp))
+            taps.append((h.astype(np.float32) + l.astype(np.float32)).transpose(2, 0, 1)[:cr])
+            his.append(h)
+            los.append(l)
+        Creal_out = sum(creal)
+        want = np.concatenate([F.max_pool2d(torch.from_numpy(t)[None], 1 << s)[0].numpy() if s else t for t, s in zip(taps, shift)], axis=0)
+        outs = []
+        for octets in modes:
+            ohi, olo = np.full((OH, OW, Cout), 3, np.float16), np.full((OH, OW, Cout), 3, np.float16)
+            assert emu.emu_fusion(arr(his), arr(los), ints([OH << s for s in shift]), ints([OW << s for s in shift]), ints(cpad), ints(creal), ints(shift),
+                                  ptr(ohi), ptr(olo), OH, OW, Cout, Creal_out, octets) == 0
+            got = (ohi.astype(np.float32) + olo.astype(np.float32)).transpose(2, 0, 1)
+            assert np.abs(got[:Creal_out] - want).max() <= 3e-7 * np.abs(want).max()
+            assert not got[Creal_out:].any()
+            outs.append((ohi.copy(), olo.copy()))
+        if len(outs) == 2:
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ohi, olo = np.zeros((OH, OW, 64), np.float16), np.zeros((OH, OW, 64), np.float16)
+    assert emu.emu_fusion(arr(his), arr(los), ints([OH << s for s in shift]), ints([OW << s for s in shift]), ints([32] * 5), ints([6, 5, 7, 9, 12]), ints(shift),
+                          ptr(ohi), ptr(olo), OH, OW, 64, 39, 1) != 0      # the octet kernel refuses ragged channel counts
 
 
 def test_autodrive_glue_kernels(emu):
