@@ -211,6 +211,15 @@ class Engine {
   void release();  // frees every device / host resource; idempotent (destructor and failed construction)
   void* dalloc(size_t bytes, bool zero = true);
   void dfree(void* p);  // hipFree + forget (buffers that are re-grown at run time; the caller has synchronised the stream)
+  // Synchronous copies / fills WITHOUT the legacy stream: hipMemcpy / hipMemset run on the NULL stream, which implicitly joins every blocking
+  // stream of the device, and the runtime refuses that while ANY thread captures a graph ("would make the legacy stream depend on a
+  // capturing ... stream") -- an engine created or read on one host thread invalidated the capture another thread's engine was recording
+  // (round 4: seen once vp_create got fast enough to overlap it).  These go through the engine's own non-blocking stream and wait for it.
+ public:
+  void copy_h2d(void* d, const void* h, size_t bytes);
+  void copy_d2h(void* h, const void* d, size_t bytes);
+  void fill_zero(void* d, size_t bytes);
+ private:
   template <class T>
   void upload_grow(T*& d, size_t& cap_elems, const std::vector<T>& v);  // re-uses d while v fits, else frees it and allocates anew
   const void* zero_page();  // 256 bytes of zeros in device memory (LDS-DMA source for out-of-image pixels, kernels_head.hip)

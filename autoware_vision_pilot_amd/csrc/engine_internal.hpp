@@ -79,7 +79,7 @@ void parallel_rows(int n, Fn&& fn) {
 template <class T>
 T* Engine::dupload(const std::vector<T>& v) {
   T* d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
-  VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  copy_h2d(d, v.data(), v.size() * sizeof(T));
   return d;
 }
 
@@ -90,7 +90,7 @@ void Engine::upload_grow(T*& d, size_t& cap_elems, const std::vector<T>& v) {
     d = static_cast<T*>(dalloc(v.size() * sizeof(T), false));
     cap_elems = v.size();
   }
-  VP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  copy_h2d(d, v.data(), v.size() * sizeof(T));
 }
 
 }  // namespace vp

@@ -23,7 +23,7 @@ void Engine::set_lane_ring(bool on) {
   VP_HIP_CHECK(hipSetDevice(gpu_));
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
   if (on && !d_lane_ring_) d_lane_ring_ = static_cast<float*>(dalloc((size_t)2 * out_c_ * out_h_ * out_w_ * sizeof(float), true));
-  if (on) VP_HIP_CHECK(hipMemset(d_lane_ring_, 0, (size_t)2 * out_c_ * out_h_ * out_w_ * sizeof(float)));
+  if (on) fill_zero(d_lane_ring_, (size_t)2 * out_c_ * out_h_ * out_w_ * sizeof(float));
   lane_ring_ = on;
   ring_frames_ = 0;
   graph_valid_ = false;
@@ -177,8 +177,8 @@ void Engine::ensure_tables(int h, int w) {
     d_ytab_ = static_cast<int*>(dalloc(net_h() * 4 * sizeof(int)));
   }
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  VP_HIP_CHECK(hipMemcpy(d_xtab_, xt.data(), xt.size() * sizeof(int), hipMemcpyHostToDevice));
-  VP_HIP_CHECK(hipMemcpy(d_ytab_, yt.data(), yt.size() * sizeof(int), hipMemcpyHostToDevice));
+  copy_h2d(d_xtab_, xt.data(), xt.size() * sizeof(int));
+  copy_h2d(d_ytab_, yt.data(), yt.size() * sizeof(int));
   tab_h_ = h;
   tab_w_ = w;
 }
@@ -455,7 +455,7 @@ void Engine::copy_outputs_device(void* logits_dst, void* mask_dst) {
 
 void Engine::read_input_tensor(float* dst) {
   VP_HIP_CHECK(hipStreamSynchronize(stream_));
-  VP_HIP_CHECK(hipMemcpy(dst, d_input_, (size_t)3 * net_h() * net_w() * sizeof(float), hipMemcpyDeviceToHost));
+  copy_d2h(dst, d_input_, (size_t)3 * net_h() * net_w() * sizeof(float));
 }
 
 // OpenCV resizeNN index table (oracle/pre_post.py nearest_index)
@@ -668,7 +668,8 @@ void Engine::read_act(int i, float* dst) {
   VP_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(float)));
   hipError_t e = launch_act_to_nchw(a.view(), a.Creal, d, stream_);
   if (e == hipSuccess) e = hipStreamSynchronize(stream_);
-  if (e == hipSuccess) e = hipMemcpy(dst, d, n * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpyAsync(dst, d, n * sizeof(float), hipMemcpyDeviceToHost, stream_);   // (not the legacy stream: engine.hpp copy_h2d)
+  if (e == hipSuccess) e = hipStreamSynchronize(stream_);
   hipFree(d);
   VP_HIP_CHECK(e);
 }

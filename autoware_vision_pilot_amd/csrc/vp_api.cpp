@@ -589,7 +589,7 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
       g.add_conv("op", a, std::vector<float>(weight, weight + wn3), std::vector<float>(bias, bias + cout), cout, 3, lo);
       g.run_eager();
       g.sync();
-      if (hipMemcpy(out, d_out, (size_t)cout * h * w * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("mode 3: copy back failed");
+      g.copy_d2h(out, d_out, (size_t)cout * h * w * sizeof(float));
       return VP_OK;
     }
     vp::ConvOpts o;

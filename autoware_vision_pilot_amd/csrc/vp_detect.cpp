@@ -156,8 +156,10 @@ int vp_detect_preprocess(vp_detect* d, const uint8_t* bgr, int h, int w, int str
         VP_HIP_CHECK(hipMalloc(&d->d_ytab, (size_t)d->net_h * 4 * sizeof(int)));
         d->tab_cap_h = d->net_h;
       }
-      VP_HIP_CHECK(hipMemcpy(d->d_xtab, xt.data(), xt.size() * sizeof(int), hipMemcpyHostToDevice));
-      VP_HIP_CHECK(hipMemcpy(d->d_ytab, yt.data(), yt.size() * sizeof(int), hipMemcpyHostToDevice));
+      // on the detector's own stream, then waited for: hipMemcpy would use the legacy stream, which the runtime refuses while any thread captures a graph
+      VP_HIP_CHECK(hipMemcpyAsync(d->d_xtab, xt.data(), xt.size() * sizeof(int), hipMemcpyHostToDevice, d->stream));
+      VP_HIP_CHECK(hipMemcpyAsync(d->d_ytab, yt.data(), yt.size() * sizeof(int), hipMemcpyHostToDevice, d->stream));
+      VP_HIP_CHECK(hipStreamSynchronize(d->stream));
       d->tab_w = w;
       d->tab_h = h;
     }
