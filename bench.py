@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all host cores, max 32)")
     ap.add_argument("--latency-iters", type=int, default=100)
+    ap.add_argument("--leg", default=None, choices=["three-heads-one-camera"], help="internal: one leg in a child process (see three_heads_note)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="developer knob of the dispatch rules (vp_set_option; repeatable) -- the library does not read the environment; "
                          "whatever is set shows in the line's `library` and `plan_hash` fields")
@@ -324,6 +325,39 @@ def main():
         return dict(steps=k, elapsed=el, fps=world * k / el, single=k1 / el1,
                     p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)))
 
+    def ego_engine():
+        e = lib.Engine("egolanes", vw.pack_state_dict(synthetic.make_state_dict("egolanes", SEEDS["egolanes"])), precision=args.precision, gpu_id=local_rank)
+        e.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB)
+        e.upload_frame(frame)
+        for _ in range(2):
+            e.enqueue()
+        e.sync()
+        return e
+
+    def three_heads_latency(cam, ego, iters):
+        cam.set_fork(True)           # one camera, one frame at a time: Scene3D forked behind the encoder, EgoLanes on its own stream
+        lat3 = []
+        for i in range(10 + iters):
+            t1 = time.perf_counter()
+            cam.enqueue()
+            ego.enqueue()
+            cam.sync()
+            ego.sync()
+            if i >= 10:
+                lat3.append((time.perf_counter() - t1) * 1e3)
+        cam.set_fork(False)
+        return lat3
+
+    if args.leg == "three-heads-one-camera":
+        # child process of the default run: ONE camera's engines alone in a process (SceneSeg + Scene3D on a shared encoder, EgoLanes on its own
+        # backbone) -- what a one-camera node holds.  The HIP runtime shares its few hardware queues among a process's streams: with the other
+        # in-flight cameras' streams alive, this camera's two base engines can land on ONE queue and run one after the other (4.2 ms against 3.6)
+        cam = Camera(lib, kinds, blobs, args.precision, local_rank, frame)
+        ego = ego_engine()
+        lat3 = three_heads_latency(cam, ego, max(20, args.latency_iters // 2))
+        print(json.dumps({"p50_ms": round(float(np.percentile(lat3, 50)), 4), "p99_ms": round(float(np.percentile(lat3, 99)), 4)}))
+        return
+
     # ---- the reported configuration
     cams = [Camera(lib, kinds, blobs, args.precision, local_rank, frame) for _ in range(nstreams)]
     if args.gather:
@@ -429,16 +463,7 @@ def main():
     # grafted onto SceneSeg's encoder.  957.6 GFLOP per frame.  N = 1 only.
     three = None
     if args.workload == "seg+3d" and not args.no_secondary and world == 1:
-        ego_blob = vw.pack_state_dict(synthetic.make_state_dict("egolanes", SEEDS["egolanes"]))
-        egos = []
-        for _ in range(nstreams):
-            e = lib.Engine("egolanes", ego_blob, precision=args.precision, gpu_id=local_rank)
-            e.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB)
-            e.upload_frame(frame)
-            for _ in range(2):
-                e.enqueue()
-            e.sync()
-            egos.append(e)
+        egos = [ego_engine() for _ in range(nstreams)]
 
         def run3(slots, steps):
             for c, e in slots:
@@ -460,24 +485,28 @@ def main():
         run3(slots, 30)
         k3 = max(60, int(math.ceil(1.15 * args.min_seconds / (run3(slots, 20) / 20))))
         el3 = run3(slots, k3)
-        cams[0].set_fork(True)           # one camera, one frame at a time: Scene3D forked behind the encoder, EgoLanes on its own stream
-        lat3 = []
-        for i in range(10 + max(20, args.latency_iters // 2)):
-            t1 = time.perf_counter()
-            cams[0].enqueue()
-            egos[0].enqueue()
-            cams[0].sync()
-            egos[0].sync()
-            if i >= 10:
-                lat3.append((time.perf_counter() - t1) * 1e3)
-        cams[0].set_fork(False)
+        lat3 = three_heads_latency(cams[0], egos[0], max(20, args.latency_iters // 2))
+        crowded_p50 = round(float(np.percentile(lat3, 50)), 4)
+        alone = None
+        try:   # the same measurement in a process that holds ONE camera's engines (see the leg above)
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", "three-heads-one-camera", "--precision", args.precision, "--frame", args.frame,
+                                "--latency-iters", str(args.latency_iters)] + [x for kv in args.option for x in ("--option", kv)],
+                               capture_output=True, text=True, timeout=180)
+            alone = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001 -- the crowded figure stays
+            alone = None
         g3 = workload_gflop(kinds) + FRAME_GFLOP["egolanes"]
-        three = {"three_heads_fps": round(k3 / el3, 2), "three_heads_p50_ms": round(float(np.percentile(lat3, 50)), 4),
+        three = {"three_heads_fps": round(k3 / el3, 2), "three_heads_p50_ms": alone["p50_ms"] if alone else crowded_p50,
+                 "three_heads_p50_ms_beside_other_cameras": crowded_p50,
                  "three_heads_gflop_per_frame": round(g3, 1),
                  "three_heads_whole_frame_frac": round(g3 * (k3 / el3) / 1e3 / PEAK_FP16_TFLOPS, 4),
                  "three_heads_note": ("BASELINE configs[2] / north_star target: SceneSeg + Scene3D on a shared encoder + EgoLanes on ITS OWN "
                                       "backbone weights and RGB-plane preprocess (a second base engine on its own stream), one 1280x720 "
-                                      f"camera, {args.precision}; fps with {nstreams} cameras in flight, p50 one frame at a time")}
+                                      f"camera, {args.precision}; fps with {nstreams} cameras in flight; p50 one frame at a time in a process that "
+                                      "holds that ONE camera's engines (a child process), _beside_other_cameras = the same in this process, where "
+                                      "the HIP runtime's few hardware queues are shared with the other cameras' streams and the two base engines "
+                                      "of a camera can end up on one queue")}
         for e in egos:
             e.close()
 
