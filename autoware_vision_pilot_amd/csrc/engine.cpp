@@ -331,13 +331,15 @@ void Engine::upload_fc_weights(FcParams* fp, const std::vector<float>& w, int N,
   }
   std::vector<uint8_t> codes((size_t)N * K);
   std::vector<float> scale(N);
-  for (int n = 0; n < N; ++n) {
-    float amax = row_amax ? (*row_amax)[n] : 0.0f;
-    if (!row_amax)
-      for (int k = 0; k < K; ++k) amax = std::max(amax, std::fabs(w[(size_t)n * K + k]));
-    scale[n] = fp8_row_scale(amax);
-    for (int k = 0; k < K; ++k) codes[(size_t)n * K + k] = e4m3_encode(w[(size_t)n * K + k] / scale[n]);
-  }
+  parallel_rows(N, [&](int n_begin, int n_end) {
+    for (int n = n_begin; n < n_end; ++n) {
+      float amax = row_amax ? (*row_amax)[n] : 0.0f;
+      if (!row_amax)
+        for (int k = 0; k < K; ++k) amax = std::max(amax, std::fabs(w[(size_t)n * K + k]));
+      scale[n] = fp8_row_scale(amax);
+      for (int k = 0; k < K; ++k) codes[(size_t)n * K + k] = e4m3_encode(w[(size_t)n * K + k] / scale[n]);
+    }
+  });
   fp->w8 = dupload(codes);
   fp->wscale8 = dupload(scale);
   wbytes_[0] += codes.size();
@@ -1039,7 +1041,8 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     fp.nslab = nslab;
     fp.Kstride = a->C;
     fp.inv_hw = 1.0f / (float)HW;
-    push(cp + ".exp0", "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, (fp.w8 ? 1.0 : 4.0) * HW * C);
+    fp.rows_kernel = fc_rows_ok(fp) ? 1 : 0;   // p2 / p3: 32768 x 32 and 8192 x 64 -- a thread per row
+    push(cp + ".exp0", fp.rows_kernel ? "fc<rows>" : "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, (fp.w8 ? 1.0 : 4.0) * HW * C);
     // ctx0: conv3x3 1 -> C/2 + SiLU (:216-217)
     const HostTensor& w0 = T(cp + ".ctx0.weight");
     const HostTensor& b0 = T(cp + ".ctx0.bias");

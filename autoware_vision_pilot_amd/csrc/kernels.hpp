@@ -168,10 +168,13 @@ struct FcParams {
   int N, K, act;
   // per-row activations of a small stacked matrix (N <= 4): byte n = ActFn of row n; 0 = `act` for every row (AutoDrive's three scalar heads in one launch)
   unsigned act_rows;
+  int rows_kernel;       // 1: a thread per row (fc_rows_kernel: K <= 64, N >= 2048 -- fc_rows_ok); 0: two rows per wave
   const float* partial;  // optional: x = mean over nslab partial sums (avg-pool input, scene_context.py:27)
   int nslab, Kstride;
   float inv_hw;
 };
+
+bool fc_rows_ok(const FcParams& p);
 
 struct CtxConv1Params {
   const float* map;  // [H][W] fp32

@@ -318,6 +318,47 @@ __global__ __launch_bounds__(256) void fc_kernel(const FcParams p) {
   }
 }
 
+// The same matvec for SHORT rows (K <= 64: AutoDrive's CTX expansion on the large maps is a [H*W = 32768][C = 32] matrix): fc_kernel gives a wave two
+// rows and a lane one 4-element piece of a row, so with K = 32 eight lanes of 64 work (26 us, measured).  Here a thread owns a row -- K bytes
+// (fp8 codes) or 4 K bytes contiguous per thread, neighbouring threads neighbouring rows -- and sums it front to back against x in LDS.
+__global__ __launch_bounds__(256) void fc_rows_kernel(const FcParams p) {
+  __shared__ __attribute__((aligned(16))) float xs[64];
+  if ((int)threadIdx.x < p.K) {
+    const int k = threadIdx.x;
+    float xv;
+    if (p.partial) {
+      xv = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < p.nslab; ++q) xv += p.partial[(size_t)q * p.Kstride + k];
+      xv *= p.inv_hw;
+    } else {
+      xv = p.x[k];
+    }
+    xs[k] = xv;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= p.N) return;
+  const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(xs);
+  const int K4 = p.K >> 2;
+  float s = 0.f;
+  if (p.w8) {
+    const unsigned* wr8 = reinterpret_cast<const unsigned*>(p.w8 + (size_t)n * p.K);
+    for (int k = 0; k < K4; ++k) {
+      const unsigned c4 = wr8[k];
+      const f32x4_t m = x4[k];
+      s += (e4m3_to_float(c4 & 0xffu) * m[0] + e4m3_to_float((c4 >> 8) & 0xffu) * m[1]) + (e4m3_to_float((c4 >> 16) & 0xffu) * m[2] + e4m3_to_float(c4 >> 24) * m[3]);
+    }
+  } else {
+    const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w + (size_t)n * p.K);
+    for (int k = 0; k < K4; ++k) {
+      const f32x4_t a = wr[k], m = x4[k];
+      s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+    }
+  }
+  p.out[n] = apply_act((p.w8 ? s * p.wscale8[n] : s) + p.b[n], p.act_rows ? (int)((p.act_rows >> (8 * (n & 3))) & 0xffu) : p.act);
+}
+
 // Zeroes the squeeze-excite accumulators once per frame (a kernel, not hipMemsetAsync: the memset was not replayed
 // by the captured graph on this ROCm, so the sums kept growing from frame to frame).
 __global__ __launch_bounds__(256) void zero_u64_kernel(unsigned long long* p, size_t n) {
@@ -363,8 +404,13 @@ hipError_t launch_se_gate_scale(const SeParams& se, const ScaleWParams& sw, hipS
   if (se.frames > 1) VP_LAUNCH(se_gate_scale_kernel<true>, dim3(sw.C / 32, se.frames), dim3(256), lds, st, se, sw);
   VP_LAUNCH(se_gate_scale_kernel<false>, dim3(sw.C / 32), dim3(256), lds, st, se, sw);
 }
+bool fc_rows_ok(const FcParams& p) { return p.K >= 4 && p.K <= 64 && (p.K & 3) == 0 && p.N >= 2048; }
 hipError_t launch_fc(const FcParams& p, hipStream_t st) {
   if (p.act_rows && p.N > 4) return hipErrorInvalidValue;
+  if (p.rows_kernel) {   // the plan's choice for short rows and many of them (fc_rows_ok)
+    if (!fc_rows_ok(p)) return hipErrorInvalidValue;
+    VP_LAUNCH(fc_rows_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, p);
+  }
   VP_LAUNCH(fc_kernel, dim3((p.N + 7) / 8), dim3(256), p.K * sizeof(float), st, p);
 }
 

@@ -173,6 +173,14 @@ int emu_fc_pooled(const float* partial, int nslab, int Kstride, float inv_hw, co
   p.w = w; p.b = b; p.out = out; p.N = N; p.K = K; p.act = act; p.partial = partial; p.nslab = nslab; p.Kstride = Kstride; p.inv_hw = inv_hw;
   return launch_fc(p, nullptr);
 }
+// a thread per row (short rows, many of them: AutoDrive's CTX expansion): fp32 rows or e4m3 codes + row scales
+int emu_fc_rows(const float* partial, int nslab, int Kstride, float inv_hw, const float* w, const unsigned char* w8, const float* wscale8, const float* b,
+                float* out, int N, int K, int act) {
+  FcParams p{};
+  p.w = w; p.w8 = w8; p.wscale8 = wscale8; p.b = b; p.out = out; p.N = N; p.K = K; p.act = act; p.partial = partial; p.nslab = nslab; p.Kstride = Kstride;
+  p.inv_hw = inv_hw; p.rows_kernel = 1;
+  return launch_fc(p, nullptr);
+}
 int emu_ctx_conv1(const float* map, int H, int W, const float* w, const float* b, void* hi, void* lo, int C, int act) {
   CtxConv1Params p{map, H, W, w, b, view(hi, lo, H, W, C), act};
   return launch_ctx_conv1(p, nullptr);

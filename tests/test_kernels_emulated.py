@@ -499,6 +499,14 @@ def test_layout_conversion_kernels_roundtrip(emu):
 
 
 # ------------------------------------------------------------------------------------------------ context / fusion
+def vplib_dequant(codes, scales):
+    """OCP e4m3 codes [rows][per] + fp32 row scales -> the fp32 weights they stand for."""
+    c = codes.astype(np.int32)
+    e, m = (c >> 3) & 15, c & 7
+    mag = np.where(e > 0, np.ldexp(1.0 + m / 8.0, e - 7), m * 2.0 ** -9).astype(np.float32)
+    return (np.where(c & 0x80, -mag, mag).astype(np.float32) * scales[:, None]).astype(np.float32)
+
+
 def test_context_path_kernels(emu):
     """scene_context.py:25-47 pieces: global average pool as slab partial sums -> first FC reading the partials (GELU),
     and context_layer_3 (conv 3x3 1 -> C on the 10x20 sigmoid map, GELU)."""
@@ -519,6 +527,23 @@ def test_context_path_kernels(emu):
     assert emu.emu_fc_pooled(ptr(partial), nslab, Cp, 1.0 / (H * W), ptr(w), ptr(b), ptr(out), N, Creal, 1) == 0
     mean = val.reshape(-1, Cp).mean(axis=0)[:Creal]
     assert np.abs(out - F.gelu(torch.from_numpy(w @ mean + b)).numpy()).max() <= 2e-5
+    # the thread-per-row form for short rows (AutoDrive's CTX expansion: [H*W][C] with C = 32 / 64): fp32 rows, then e4m3 codes + row scales
+    N2, K2 = 2300, 32
+    part2 = np.zeros((nslab, Cp), np.float32)
+    part2[:, :K2] = rng.standard_normal((nslab, K2)).astype(np.float32)
+    mean2 = part2.sum(axis=0)[:K2] / np.float32(H * W)
+    w2 = (rng.standard_normal((N2, K2)) * 0.3).astype(np.float32)
+    b2 = rng.standard_normal(N2).astype(np.float32) * 0.1
+    out2 = np.zeros(N2, np.float32)
+    emu.emu_fc_rows.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int]
+    assert emu.emu_fc_rows(ptr(part2), nslab, Cp, 1.0 / (H * W), ptr(w2), None, None, ptr(b2), ptr(out2), N2, K2, 2) == 0
+    assert np.abs(out2 - F.silu(torch.from_numpy(w2 @ mean2 + b2)).numpy()).max() <= 2e-5
+    from autoware_vision_pilot_amd import lib as vplib
+    codes, scales = vplib.fp8_encode_rows(w2)
+    wq = vplib_dequant(codes, scales)
+    assert emu.emu_fc_rows(ptr(part2), nslab, Cp, 1.0 / (H * W), None, ptr(codes), ptr(scales), ptr(b2), ptr(out2), N2, K2, 2) == 0
+    assert np.abs(out2 - F.silu(torch.from_numpy(wq @ mean2 + b2)).numpy()).max() <= 2e-5
+    assert emu.emu_fc_rows(ptr(part2), nslab, Cp, 1.0 / (H * W), ptr(w2), None, None, ptr(b2), ptr(out2), 100, K2, 2) != 0      # few rows: the plan keeps fc_kernel
 
     C = 32
     m = rng.uniform(0, 1, size=(H, W)).astype(np.float32)
