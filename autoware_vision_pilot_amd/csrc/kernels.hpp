@@ -276,7 +276,7 @@ struct AttnParams {
   ActView vout;  // [HW][heads * dv] copy of v (input of the depthwise positional conv)
   int heads, dk, dv;
   float scale;
-  int qblock;    // 4: four query tokens per workgroup (attention_block_kernel: dk = 32, dv = 64, <= 2048 tokens); 0: one workgroup per query token
+  int qblock;    // 4: four query tokens per workgroup (attention_block_kernel: dk = 32, dv = 64, <= 1760 tokens); 0: one workgroup per query token
 };
 bool attention_block_ok(const AttnParams& p);
 hipError_t launch_attention(const AttnParams& p, hipStream_t st);

@@ -333,7 +333,10 @@ hipError_t launch_chan_copy(const ActView& src, int src_off, const ActView& dst,
 hipError_t launch_maxpool5(const ActView& src, int src_off, const ActView& dst, int dst_off, int nch, hipStream_t st) {
   VP_LAUNCH(maxpool5_kernel, dim3(nblk((long long)src.H * src.W * (nch >> 3))), dim3(256), 0, st, src, src_off, dst, dst_off, nch);
 }
-bool attention_block_ok(const AttnParams& p) { return p.dk == 32 && p.dv == 64 && p.qkv.C % 8 == 0 && p.qkv.H * p.qkv.W <= 2048; }
+// LDS of attention_block_kernel<4>: [4][T] probabilities + [4][256] reduction scratch + [4][32] queries + [32][4][64] value partials, within the
+// 64 KB a launch gets without an attribute: T <= 1760 tokens (AutoDrive's P5 at 1024 x 512 input: 512)
+static size_t attention_block_lds(int T) { return (size_t)(4 * T + 4 * 256 + 4 * 32 + 32 * 4 * 64) * sizeof(float); }
+bool attention_block_ok(const AttnParams& p) { return p.dk == 32 && p.dv == 64 && p.qkv.C % 8 == 0 && attention_block_lds(p.qkv.H * p.qkv.W) <= 64 * 1024; }
 bool sppf_pool_ok(const ActView& src, const ActView& dst, int nch) {
   return !(nch & 7) && nch <= src.C && 4 * nch <= dst.C && src.H == dst.H && src.W == dst.W && src.H * src.W <= 512 && (src.lo == nullptr) == (dst.lo == nullptr);
 }
@@ -347,8 +350,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t st) {
   if (p.qblock == 4) {   // the engine selects it at plan time (attention_block_ok)
     if (!attention_block_ok(p)) return hipErrorInvalidValue;
     constexpr int QB = 4;
-    const size_t lds = (size_t)(QB * T + QB * 256 + QB * 32 + 32 * QB * 64) * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const size_t lds = attention_block_lds(T);
     VP_LAUNCH(attention_block_kernel<QB>, dim3((T + QB - 1) / QB, p.heads), dim3(256), lds, st, p);
   }
   if (p.qblock != 0) return hipErrorInvalidValue;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void fusion_kernel(const FusionParams p) {
 }
 // Round 4: one workgroup per output pixel.  A work unit = (tap, channel octet, slice of the tap's window): up to 16 window elements fetched as
 // independent 16-byte pieces, their maximum parked in LDS; a second pass takes the maximum over a (tap, octet)'s slices and stores 8 channels.
-// Same values as the kernel above (a maximum has no rounding), ~8 us instead of 115.
+// Same values as the kernel above (a maximum has no rounding), 16 us instead of 115 (measured).
 __global__ __launch_bounds__(256) void fusion_octet_kernel(const FusionParams p) {
   __shared__ float part[512 * 8];
   const int pix = blockIdx.x, tid = threadIdx.x;

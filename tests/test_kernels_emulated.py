@@ -484,6 +484,7 @@ def test_maxpool5_and_attention_kernels(emu):
             assert np.abs((vh.astype(np.float32) + vl.astype(np.float32))[:, h * dv:(h + 1) * dv] - v.numpy()).max() <= 1e-6
     oh2 = np.zeros((42, 128), np.float16)
     assert emu.emu_attention(ptr(qh), ptr(ql), 6, 7, 2, 16, 32, 0.25, ptr(oh2), ptr(oh2), ptr(oh2), ptr(oh2), 4) != 0    # the block kernel is dk = 32, dv = 64 only
+    assert emu.emu_attention(ptr(qh), ptr(ql), 32, 64, 2, 32, 64, 0.18, ptr(oh2), ptr(oh2), ptr(oh2), ptr(oh2), 4) != 0   # 2048 tokens: its LDS plan holds 1760 (the engine then plans the per-query kernel)
 
 
 def test_layout_conversion_kernels_roundtrip(emu):
