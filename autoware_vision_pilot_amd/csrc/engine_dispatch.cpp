@@ -144,8 +144,8 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       ht = best_c;
     }
     if (ht == 11) {
-      if (!conv3x3_map_supported(p)) throw std::invalid_argument("halo tile 11 (map kernel): 3x3 stride 1, fp16x3, 20x40 or 10x20 regions: " + name);
-      op.kernel = conv3x3_map_geometry(p.H, p.W) == 1 ? "conv3x3_map<co32,px800,x3>+splitk" : "conv3x3_map<co32,px200,x3>+splitk";
+      if (!conv3x3_map_supported(p)) throw std::invalid_argument("halo tile 11 (map kernel): 3x3 stride 1, 20x40 or 10x20 regions: " + name);
+      op.kernel = std::string("conv3x3_map<co32,") + (conv3x3_map_geometry(p.H, p.W) == 1 ? "px800," : "px200,") + (sp ? "x3>" : "x1,k32>") + "+splitk";
       op.run = [p](hipStream_t st) { return launch_conv3x3_map(p, st); };
       ops_.push_back(std::move(op));
       return;
@@ -291,15 +291,23 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       const char* envc = dev_option("VP_CTX3");
       const int geom = conv3x3_map_geometry(in->H, in->W);
       const bool geom_on = geom == 1 ? cin_pad >= 256 : (geom == 2 && cin_pad >= 128 && !(envc && envc[0] == '0'));
-      if (o.tile == 111 || (on && split() && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && geom_on &&
+      // round 4: the VP_FP16 engines take the kernel too (X1: steps of 32 channels, the halves in the two planes; VP_F16_MAP=0: the halo kernel's
+      // 64-channel tiles + split-K as before)
+      const char* envf = dev_option("VP_F16_MAP");
+      // measured per layer (profiles/r04_layers_sceneseg_fp16_map_ab.tsv, halo kernel + split-K -> map kernel, us): context_layer_4..6 20.5 / 16.5 / 22.7 ->
+      // 18.5 / 14.3 / 19.9, decode_layer_0 (1280 channels on 20x40) 40.4 -> 35.5; decode_layer_1..3 28.2 / 43.7 / 37.1 -> 29.9 / 45.5 / 37.8: the kernel
+      // where it wins (the 10x20 geometry, >= 1024 input channels on a single region); VP_F16_MAP=1 everywhere it fits
+      const bool f16_rule = (envf && envf[0] == '1') || geom == 2 || (cin_pad >= 1024 && M <= 800);
+      const bool prec_on = split() || (!fp8_storage() && cin_pad % 32 == 0 && !(envf && envf[0] == '0') && f16_rule);
+      if (o.tile == 111 || (on && prec_on && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && geom_on &&
                             conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
         halo = 11;
     }
     // VP_WEIGHTS_FP8 as storage (AutoDrive engines and the operator entry): the halo kernel's 8x16-pixel tiles of 64 / 32 channels are the ones
     // instantiated with the byte-weight staging path (kernels_conv3x3.hip W8)
     if (fp8_storage() && o.tile < 0 && halo >= 0) halo = ncols <= 32 ? 4 : 3;
-    if (halo == 11 && (!split() || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
-      throw std::invalid_argument("halo tile 11 (map kernel): fp16x3, maps that tile into 20x40 or 10x20 regions, >= 32 input channels: " + name);
+    if (halo == 11 && (fp8_storage() || (!split() && cin_pad % 32 != 0) || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
+      throw std::invalid_argument("halo tile 11 (map kernel): maps that tile into 20x40 or 10x20 regions, >= 32 input channels (a multiple of 32 in the fp16 engines): " + name);
     if (halo >= 6 && halo <= 8 && !split() && cin_pad % 64 != 0) throw std::invalid_argument("halo tiles 6 - 8 in the fp16 engines: input channels a multiple of 64: " + name);
   }
   if (halo >= 0) {
@@ -308,12 +316,12 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     pc.CoutW = round_up(ncols, halo_tile_co(halo));
     if (halo == 11) {  // map kernel: K slices until ~one round of workgroups (one per CU at 20x40 regions, two at 10x20), fp32 slabs <= 24 MB
       const int geom = conv3x3_map_geometry(in->H, in->W);
-      const int regions = geom == 1 ? (in->H / 20) * (in->W / 40) : (in->H / 10) * (in->W / 20), n_co = pc.CoutW / 32, KS = cin_pad / 16;
+      const int regions = geom == 1 ? (in->H / 20) * (in->W / 40) : (in->H / 10) * (in->W / 20), n_co = pc.CoutW / 32, KS = cin_pad / (split() ? 16 : 32);
       const int slots = geom == 1 ? 256 : 512;   // 155 KB of LDS = one workgroup per CU (a 257th waits a whole round); 74 KB = two
       int ns = o.nsplit > 0 ? o.nsplit : std::max(1, slots / (regions * n_co));
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
       while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
-      pc.bk = 16;
+      pc.bk = split() ? 16 : 32;
       pc.nsplit = std::max(1, std::min(ns, std::max(1, KS / 2)));
     } else {
     const int KC = cin_pad / 32;
@@ -387,7 +395,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   const bool w8 = fp8_storage() && ((halo < 0 && pc.tile == 2) || halo == 3 || halo == 4);
   // fp16 engines on the pipelined kernels (halo tiles 6 - 8 without the lo plane): 64-channel chunks, the chunk's halves in two plane arrays
   const bool k64 = halo >= 6 && halo <= 8 && !split();
-  std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad / (k64 ? 2 : 1), (half_t)0.0f), lo(((split() || k64) && !w8) ? hi.size() : 0, (half_t)0.0f);
+  const bool k32map = halo == 11 && !split();   // map kernel in the fp16 engines: 32-channel steps, the step's halves in the two plane arrays
+  std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad / ((k64 || k32map) ? 2 : 1), (half_t)0.0f), lo(((split() || k64 || k32map) && !w8) ? hi.size() : 0, (half_t)0.0f);
   std::vector<uint8_t> codes(w8 ? (size_t)taps * pc.CoutW * cin_pad : 0, (uint8_t)0);
   RowScale rs = row_prescale(w.data(), cout, (size_t)cin * taps, pc.CoutW);
   if (w8)   // the rows' quantisation scales instead of the power-of-two prescale (e4m3 values need none: |q| in [2^-9, 448] are normal fp16 numbers)
@@ -406,7 +415,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
         const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
-        const size_t d = halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)
+        const size_t d = k32map ? conv3x3_map_pack_index_k32(co, ci, t, cin_pad)
+                         : halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)
                          : k64     ? ((((size_t)(ci >> 6) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                          : halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                                    : (((size_t)t * pc.CoutW + co) * cin_pad + ci);
@@ -421,6 +431,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
           ((ci >> 5) & 1 ? lo : hi)[d] = h;
           continue;
         }
+        if (k32map) {
+          ((ci >> 4) & 1 ? lo : hi)[d] = h;
+          continue;
+        }
         hi[d] = h;
         if (split()) lo[d] = l;
       }
@@ -432,7 +446,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     wbytes_[0] += codes.size();
   } else {
     pc.w_hi = dupload(hi);
-    pc.w_lo = (split() || k64) ? dupload(lo) : nullptr;
+    pc.w_lo = (split() || k64 || k32map) ? dupload(lo) : nullptr;
     wbytes_[1] += 2 * (hi.size() + lo.size());
   }
   pc.bias = dupload(bias);

@@ -214,6 +214,7 @@ int halo_tile_th(int tile);
 int conv3x3_map_geometry(int H, int W);  // 1 = 20x40 regions (neck), 2 = 10x20 regions (context block), 0 = neither
 bool conv3x3_map_shape_ok(int H, int W, int cin_pad, int coutw);
 size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad);
+size_t conv3x3_map_pack_index_k32(int co, int ci, int t, int cin_pad);   // fp16 engines: steps of 32 channels, plane = (ci >> 4) & 1
 bool conv3x3_map_supported(const ConvGemmParams& p);
 hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st);
 // last convolution of a head: 3x3, 64 / 128 channels -> <= 4 logit channels, fp32 NCHW + fused decode (kernels_head.hip); weights packed

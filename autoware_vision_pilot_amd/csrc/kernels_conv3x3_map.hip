@@ -54,7 +54,10 @@ static_assert(Neck::NF == 25 && Neck::LDS == 155648 && Neck::IPW == 10 && Ctx::N
 // NFW = pixel tiles of THIS wave: 4 for wave 0 (tiles 0, 8, 16, 24), 3 for the others.  The body is instantiated per count and the kernel
 // branches ONCE on the (scalar) wave index: with `if (tile < 25)` tests inside the tap loop the compiler guarded every tap with
 // s_waitcnt lgkmcnt(0) at the joins, i.e. the fragments requested one tap ahead were awaited BEFORE the current tap's MFMAs.
-template <class G, int NFW, int ABL>
+// X1 (round 4): the VP_FP16 engines' form -- one fp16 plane per tensor, a step covers THIRTY-TWO input channels and the two LDS planes are its two
+// 16-channel halves (plane 0 = channels [32 s, 32 s + 16), plane 1 = [32 s + 16, 32 s + 32); weights packed likewise), two MFMAs per fragment pair
+// (a0 . b0 + a1 . b1) instead of three: the same LDS plan, DMA plan and barrier per step (kernels_conv3x3_x3.hip does the same with its chunks).
+template <class G, int NFW, int ABL, bool X1>
 __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const int wave) {
   constexpr int RH = G::RH, RW = G::RW, RPX = G::RPX, NWV = G::NWV, HW = G::HW, HPX = G::HPX, H_PLANE = G::H_PLANE, W_PLANE = G::W_PLANE, H_BUF = G::H_BUF,
                 W_BUF = G::W_BUF, NHI = G::NHI, NWI = G::NWI, NINSTR = G::NINSTR, IPW = G::IPW;
@@ -72,7 +75,9 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
   const int region = vid % n_regions, rest = vid / n_regions;
   const int tile_co = rest % n_co, zsplit = rest / n_co;
   const int ry0 = (region / regions_x) * RH, rx0 = (region % regions_x) * RW;
-  const int KS_all = p.Cin >> 4;  // steps of 16 input channels
+  constexpr int CS = X1 ? 32 : 16;  // input channels per step
+  const int KS_all = p.Cin / CS;
+  const half_t* const in_p1 = X1 ? p.in_hi + 16 : p.in_lo;  // second plane of the halo image
   const int s_first = (int)(((long long)KS_all * zsplit) / p.nsplit);
   const int KS = (int)(((long long)KS_all * (zsplit + 1)) / p.nsplit) - s_first;
 
@@ -93,8 +98,8 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
       const int hy = R / HW, hx = R - hy * HW;
       const int gy = ry0 - 1 + hy, gx = rx0 - 1 + hx;
       const bool ok = R < HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      d_src[i] = ok ? (pl ? p.in_lo : p.in_hi) + ((size_t)(gy * p.W + gx) * p.Cin + lslot * 8 + s_first * 16) : p.zeros;
-      d_step[i] = ok ? 16 : 0;
+      d_src[i] = ok ? (pl ? in_p1 : p.in_hi) + ((size_t)(gy * p.W + gx) * p.Cin + lslot * 8 + s_first * CS) : p.zeros;
+      d_step[i] = ok ? CS : 0;
       d_dst[i] = pl * H_PLANE + g * 1024;
       d_buf[i] = H_BUF;
     } else {
@@ -162,6 +167,9 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
   _Pragma("unroll") for (int j = 0; j < NFW; ++j) {                                                                  \
     if constexpr ((ABL & 2) != 0) {                                                                                  \
       acc[j][0] += (float)fa_lo[SET][0] + (float)fa_hi[SET][1] + (float)fb_hi[SET][j][2] + (float)fb_lo[SET][j][3];  \
+    } else if constexpr (X1) { /* the planes are the step's two K halves */                                          \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                   \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo[SET], fb_lo[SET][j], acc[j], 0, 0, 0);                   \
     } else {                                                                                                         \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_lo[SET], fb_hi[SET][j], acc[j], 0, 0, 0);                   \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_hi[SET], fb_lo[SET][j], acc[j], 0, 0, 0);                   \
@@ -207,21 +215,21 @@ __device__ __forceinline__ void conv3x3_map_body(const ConvGemmParams& p, const 
 
 // ABL: ablation bits for tools/map_ablate.hip only (1 = no DMA inside the loop, 2 = no MFMA, 4 = tap-invariant fragment addresses, 8 = no barrier / vmcnt
 // wait in the loop); 0 in the library.
-template <int ABL = 0>
+template <int ABL = 0, bool X1 = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_map_kernel(const ConvGemmParams p) {
   using G = mapk::Neck;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: keep it scalar
   // wave 0 carries pixel tiles 0, 8, 16, 24; waves 1..7 three each
-  if (wave == 0) conv3x3_map_body<G, 4, ABL>(p, wave);
-  else conv3x3_map_body<G, 3, ABL>(p, wave);
+  if (wave == 0) conv3x3_map_body<G, 4, ABL, X1>(p, wave);
+  else conv3x3_map_body<G, 3, ABL, X1>(p, wave);
 }
 // the context block's 10x20 maps: four waves, pixel tiles {0, 4}, {1, 5}, {2, 6}, {3}
-template <int ABL = 0>
+template <int ABL = 0, bool X1 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_map_ctx_kernel(const ConvGemmParams p) {
   using G = mapk::Ctx;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (wave < 3) conv3x3_map_body<G, 2, ABL>(p, wave);
-  else conv3x3_map_body<G, 1, ABL>(p, wave);
+  if (wave < 3) conv3x3_map_body<G, 2, ABL, X1>(p, wave);
+  else conv3x3_map_body<G, 1, ABL, X1>(p, wave);
 }
 
 // weight element (output channel co, input channel ci, tap t) -> index into the packed tensor: [co / 32][ci / 16][plane block of 9 x 32 rows x
@@ -230,6 +238,12 @@ size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad) {
   const int col = co & 31, k16 = ci & 15;
   const int slot = (k16 >> 3) ^ ((col >> 3) & 1);
   return (((size_t)(co >> 5) * (cin_pad >> 4) + (ci >> 4)) * (9 * 32) + (size_t)t * 32 + col) * 16 + slot * 8 + (k16 & 7);
+}
+// the fp16 engines' form (X1): steps of 32 input channels, the element's plane = (ci >> 4) & 1 (the caller's two plane arrays), index inside it:
+size_t conv3x3_map_pack_index_k32(int co, int ci, int t, int cin_pad) {
+  const int col = co & 31, k16 = ci & 15;
+  const int slot = (k16 >> 3) ^ ((col >> 3) & 1);
+  return (((size_t)(co >> 5) * (cin_pad >> 5) + (ci >> 5)) * (9 * 32) + (size_t)t * 32 + col) * 16 + slot * 8 + (k16 & 7);
 }
 
 // geometry a map takes: 1 = 20x40 regions (neck), 2 = 10x20 regions (context block; only where 20x40 does not tile), 0 = neither
@@ -243,25 +257,32 @@ bool conv3x3_map_shape_ok(int H, int W, int cin_pad, int coutw) {
 }
 
 bool conv3x3_map_supported(const ConvGemmParams& p) {
-  return p.ks == 3 && p.stride <= 1 && p.in_lo && p.w_lo && p.Cin2 == 0 && p.partial != nullptr && p.zeros != nullptr && p.nsplit >= 1 &&
-         p.nsplit <= (p.Cin >> 4) && conv3x3_map_shape_ok(p.H, p.W, p.Cin, p.CoutW);
+  const bool x1 = p.in_lo == nullptr;   // VP_FP16 engines: steps of 32 channels, the step's halves in the two planes
+  return p.ks == 3 && p.stride <= 1 && p.in_hi && p.w_hi && p.w_lo && p.Cin2 == 0 && p.partial != nullptr && p.zeros != nullptr && p.nsplit >= 1 &&
+         p.Cin % (x1 ? 32 : 16) == 0 && p.nsplit <= p.Cin / (x1 ? 32 : 16) && conv3x3_map_shape_ok(p.H, p.W, p.Cin, p.CoutW);
+}
+
+template <bool X1>
+static hipError_t launch_map_cfg(const ConvGemmParams& p, hipStream_t st) {
+  if (conv3x3_map_geometry(p.H, p.W) == 1) {
+    using G = mapk::Neck;
+    static LdsAttrOnce once;
+    if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel<0, X1>), G::LDS); e != hipSuccess) return e;
+    const int n_regions = (p.H / G::RH) * (p.W / G::RW);
+    hipLaunchKernelGGL((conv3x3_map_kernel<0, X1>), dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(64 * G::NWV), G::LDS, st, p);
+  } else {
+    using G = mapk::Ctx;
+    static LdsAttrOnce once;
+    if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_ctx_kernel<0, X1>), G::LDS); e != hipSuccess) return e;
+    const int n_regions = (p.H / G::RH) * (p.W / G::RW);
+    hipLaunchKernelGGL((conv3x3_map_ctx_kernel<0, X1>), dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(64 * G::NWV), G::LDS, st, p);
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st) {
   if (!conv3x3_map_supported(p)) return hipErrorInvalidValue;
-  if (conv3x3_map_geometry(p.H, p.W) == 1) {
-    using G = mapk::Neck;
-    static LdsAttrOnce once;
-    if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_kernel<0>), G::LDS); e != hipSuccess) return e;
-    const int n_regions = (p.H / G::RH) * (p.W / G::RW);
-    hipLaunchKernelGGL(conv3x3_map_kernel<0>, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(64 * G::NWV), G::LDS, st, p);
-  } else {
-    using G = mapk::Ctx;
-    static LdsAttrOnce once;
-    if (hipError_t e = set_max_dynamic_lds(once, reinterpret_cast<const void*>(conv3x3_map_ctx_kernel<0>), G::LDS); e != hipSuccess) return e;
-    const int n_regions = (p.H / G::RH) * (p.W / G::RW);
-    hipLaunchKernelGGL(conv3x3_map_ctx_kernel<0>, dim3(n_regions * (p.CoutW / 32) * p.nsplit), dim3(64 * G::NWV), G::LDS, st, p);
-  }
+  if (hipError_t e = p.in_lo ? launch_map_cfg<false>(p, st) : launch_map_cfg<true>(p, st); e != hipSuccess) return e;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return launch_splitk_finish(p, st);  // also for nsplit == 1: bias / activation / (hi, lo) split live there

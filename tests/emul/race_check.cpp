@@ -107,6 +107,7 @@ int main(int argc, char** argv) {
     if (precision == 0) {  // the fp16 engines' form of the pipelined kernels: 64-channel chunks, the chunk's halves as the two LDS planes
       bad |= conv(0, 0, 128, 128, 9, 17, 3, 1, 106, -1, 1);   // two chunks: the double-buffered halo hand-over
       if (!quick) bad |= conv(0, 0, 192, 128, 11, 19, 3, 1, 107, -1, 1);
+      bad |= conv(0, 0, 64, 32, 10, 20, 3, 1, 111, -1, 2);   // map kernel, fp16 form (32-channel steps), context geometry, two K slices
     }
     if (precision == 1 || quick) {  // 8-wave fp16x3 kernel: 3 weight buffers, cross-tap fragment prefetch, 2 chunks
       bad |= conv(1, 0, 64, 128, 17, 19, 3, 1, 106, -1, 1);

@@ -233,6 +233,10 @@ def test_map_kernel(emu_lib):
     with pytest.raises(emu_lib.VpError):
         x = np.zeros((32, 16, 40), np.float32)
         emu_lib.op_conv2d(x, np.zeros((32, 32, 3, 3), np.float32), np.zeros(32, np.float32), ks=3, precision=1, tile=111, nsplit=1)   # 16 rows: not a region multiple
+    # round 4, the VP_FP16 engines' form (X1): steps of 32 input channels, the step's two 16-channel halves in the two LDS planes, two MFMAs per fragment pair
+    _case(emu_lib, 48, 40, 20, 40, 3, 0, 1, 0, 0, [(111, -1, 1), (111, -1, 2)], seed=77)        # 64 padded channels = 2 steps; one and two K slices
+    _case(emu_lib, 160, 72, 40, 80, 3, 0, 0, 0, 0, [(111, -1, 3)], seed=78)                     # four regions, 5 steps in 3 slices (1, 2, 2), ragged channel tile
+    _case(emu_lib, 96, 40, 10, 20, 3, 0, 1, 2, 0, [(111, -1, 3)], seed=79)                      # the context geometry, mul-add residual behind 3 slices
 
 
 def _q_e4m3(w):
