@@ -81,7 +81,7 @@ def test_conv_op_matches_torch(case, precision):
 
 @pytest.mark.parametrize("cin,cout,h,w,act", [(128, 128, 64, 96, 1), (96, 256, 35, 50, 0), (512, 128, 32, 32, 1), (32, 384, 16, 16, 1)])
 def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
-    """kernels_conv3x3_x3.hip (halo tiles 6 and 7, fp16x3 only): fragments prefetched across tap / chunk boundaries, three
+    """kernels_conv3x3_x3.hip (halo tiles 6 - 8; fp16x3, and since round 4 the fp16 engines on 64-channel chunks): fragments prefetched across tap / chunk boundaries, three
     weight buffers, register epilogue; 8-wave 16x16 shape and 4-wave 8x16 shape.  Same K order as halo tile 1 => bit-identical."""
     from autoware_vision_pilot_amd import lib
 
