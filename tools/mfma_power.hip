@@ -33,6 +33,28 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const h8* src, float* out, l
   }
 }
 
+// Round 4: the same question for v_mfma_f32_16x16x32_f16 (half the FLOPs per instruction, a quarter of the accumulator registers): does the other
+// tile shape of the fp16 pipe draw less per FLOP, i.e. sustain a higher rate under the power limit?  Eight independent accumulators per wave.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 2) void mfma16_loop(const h8* src, float* out, long long* clk, int iters) {
+  const h8 a = src[threadIdx.x], b = src[512 + threadIdx.x];
+  f4v c[8] = {};
+  const long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16((k & 1) ? b : a, (k & 1) ? a : b, c[k], 0, 0, 0);
+  }
+  const long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  float s = 0;
+  for (int k = 0; k < 8; ++k)
+    for (int e = 0; e < 4; ++e) s += c[k][e];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
+}
+
 // The same loop with R 16-byte LDS reads (ds_read_b128, conflict-free, random data: the operands of the MFMAs) per 4 MFMAs -- what a
 // register tile costs in LDS traffic: the parity 3x3 kernel reads 8 fragments per 12 MFMAs (R = 2.7); a 2x larger register tile would
 // read 1.3.  If the pipe is POWER-limited, LDS energy comes out of the MFMA budget and the rate falls with R.
@@ -109,6 +131,28 @@ int main() {
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       const double flop = (double)n * 8 * iters * 4 * 32 * 32 * 16 * 2;
+      std::printf("%d\t%.3f\t%.1f\t%.2f\t%.0f\n", n, ms, flop / ms * 1e-9, flop / ms * 1e-9 / n, (double)clk[0] / clk[1] * 100.0);
+    }
+  }
+  {
+    unsigned s = 12345;
+    for (auto& v : h) {
+      s = s * 1664525u + 1013904223u;
+      v = (_Float16)(((int)(s >> 9) % 2001 - 1000) * 0.001f);
+    }
+    hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    std::printf("# random fp16 operands, v_mfma_f32_16x16x32_f16 (8 accumulators per wave)\n# active_CUs\tms\tTFLOP/s\tTFLOP/s_per_CU\tshader_clock_MHz\n");
+    for (int n : {64, 256}) {
+      const int iters = 40000;
+      hipLaunchKernelGGL(mfma16_loop, dim3(n), dim3(512), 0, 0, src, out, clk, 4000);
+      hipDeviceSynchronize();
+      hipEventRecord(e0, 0);
+      hipLaunchKernelGGL(mfma16_loop, dim3(n), dim3(512), 0, 0, src, out, clk, iters);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double flop = (double)n * 8 * iters * 8 * 16 * 16 * 32 * 2;
       std::printf("%d\t%.3f\t%.1f\t%.2f\t%.0f\n", n, ms, flop / ms * 1e-9, flop / ms * 1e-9 / n, (double)clk[0] / clk[1] * 100.0);
     }
   }
