@@ -60,8 +60,11 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvGemmParams 
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
   const int n_px_tiles = tiles_x * ((p.H + TH - 1) / TH), n_co_tiles = p.CoutW / CO_TILE;
-  const int tile_px = vid % n_px_tiles, tile_rest = vid / n_px_tiles;
-  const int tile_co = tile_rest % n_co_tiles, zsplit = tile_rest / n_co_tiles;
+  // nsplit == 1: the output-channel tile is the fastest index -- the channel tiles of one pixel tile run side by side on one XCD and share its
+  // input patch in L2 (round 4, measured on the pipelined kernels: kernels_conv3x3_x3.hip); split layers keep pixel tiles fastest inside a K slice
+  const bool co_fast = p.nsplit == 1;
+  const int tile_px = co_fast ? vid / n_co_tiles : vid % n_px_tiles, tile_rest = vid / n_px_tiles;
+  const int tile_co = co_fast ? vid % n_co_tiles : tile_rest % n_co_tiles, zsplit = co_fast ? 0 : tile_rest / n_co_tiles;
   const int tyi = tile_px / tiles_x, txi = tile_px - tyi * tiles_x;
   const int y0 = tyi * TH, x0 = txi * TW;
   const int co0 = tile_co * CO_TILE;

@@ -111,8 +111,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   const int a_ofs0 = (wco * 32 + (lane & 31)) * WROW + (((lane >> 5) ^ a_swz) << 4);  // K sub-step 1: chunk index ^ 2 -> ^ 32 bytes
 
   int c_first = 0, KC = KC_all, zsplit = 0;
-  const int tile_px = vid % n_px_tiles, tile_rest = vid / n_px_tiles;
-  const int tile_co = SPLITK ? tile_rest % n_co_tiles : tile_rest;
+  // Without split-K the OUTPUT-CHANNEL tile is the fastest index (round 4): the two or four channel tiles of one pixel tile get neighbouring ids, i.e.
+  // run side by side on one XCD, and the second one finds the input patch in that XCD's L2 (with the pixel tile fastest they ran a whole
+  // round apart: measured 139.9 -> 135.6 us per launch over decode_layer_4 / 6 / 7, `profiles/r04_x3_cofast_ab.txt`; the weights of all
+  // channel tiles -- 1.2-4.7 MB -- stay resident in the 4 MB L2 either way).  Same tiles, same K order: bit-identical results.
+  const int tile_px = SPLITK ? vid % n_px_tiles : vid / n_co_tiles;
+  const int tile_rest = vid / n_px_tiles;
+  const int tile_co = SPLITK ? tile_rest % n_co_tiles : vid % n_co_tiles;
   if constexpr (SPLITK) {
     zsplit = tile_rest / n_co_tiles;
     c_first = (int)(((long long)KC_all * zsplit) / p.nsplit);
