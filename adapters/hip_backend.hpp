@@ -95,6 +95,11 @@ public:
     // the C++ front-end's own float expression: convertTo(CV_32FC3, 1.0 / 255.0) = q * fl(1/255), then subtract / divide
     // (onnx_runtime_backend.cpp:45-49, tensorrt_backend.cpp:164-168) -- not torchvision's q / 255
     vp_set_norm_form(engine_, VP_NORM_OPENCV);
+    // What doInference copies to the host every frame (round 5): the decoded class map only.  The node consumes the mask when its GPU helper
+    // succeeds (run_model_node.cpp:144-177; createMask / createMaskFromTensorHIP below) and, for depth, the map createDepth resizes on the
+    // device; the 2.4 MB (0.8 MB) fp32 tensor stays in HBM and is fetched by the first getRawTensorData() that asks for it -- the pointer's
+    // contents and lifetime are as before.  setCopyLogitsEveryFrame(true) restores the copy inside doInference.
+    vp_set_outputs(engine_, kind == VP_SCENE3D ? 0 : VP_OUT_MASK);
     vp_input_hw(engine_, &in_h_, &in_w_);
   }
   ~HipBackend() override
@@ -131,9 +136,8 @@ public:
   }
   std::vector<int64_t> getTensorShape() const override
   {
-    const float * data = nullptr;
     int64_t shape[4];
-    if (!ran_ || vp_logits(engine_, &data, shape) != VP_OK)
+    if (!ran_ || vp_output_shape(engine_, shape) != VP_OK)   // the shape alone: no fetch of a tensor nobody asked for
       throw std::runtime_error("Inference has not been run yet. Call doInference() first.");
     return {shape[0], shape[1], shape[2], shape[3]};
   }
@@ -172,9 +176,13 @@ public:
     return vp_visualize_mask_bgr8(engine_, t, blended.data, frame_size.height, frame_size.width) == VP_OK;
   }
 
-  // A host that consumes only the decoded mask (createMask / visualizeMask) can drop the 2.4 MB logits copy per frame:
-  // logits then stay in HBM until getRawTensorData() asks for them.
+  // Default (round 5): the logits stay in HBM until getRawTensorData() asks for them; a host that reads the raw tensor every frame
+  // (the unpatched depth path, run_model_node.cpp:94-104) saves the extra synchronisation by copying it inside doInference again.
   void setCopyLogitsEveryFrame(bool on) { vp_set_outputs(engine_, (on ? VP_OUT_LOGITS : 0) | VP_OUT_MASK); }
+  // The node's frame pool (cv::Mat buffers it reuses): page-locked once, then doInference DMAs straight from the cv::Mat with no staging copy
+  // (vp_register_frames).  The pool must outlive the registration.
+  static bool registerFramePool(const void * pool, size_t bytes) { return vp_register_frames(pool, bytes) == VP_OK; }
+  static bool unregisterFramePool(const void * pool) { return vp_unregister_frames(pool) == VP_OK; }
   vp_engine * handle() { return engine_; }
 
 private:

@@ -78,6 +78,9 @@ struct ConvGemmParams {
   int decode_mode;
   // >= 16 bytes of zeros in device memory (the engine's zero page): LDS-DMA source for pixels outside the map (kernels_conv3x3_x3.hip)
   const half_t* zeros;
+  // convt_rs_kernel: cap on the persistent pixel-tile groups, resolved when the PLAN is built (developer option VP_CONVT_RS_GROUPS; 0 = no cap).
+  // It used to be read at launch / capture time: an option set later changed existing engines behind their plan hash
+  int rs_groups;
 };
 
 // nn.GELU() (exact erf form, scene_neck.py:8).  ~300 M activations per frame: libm's erff (~45 VALU ops, branchy)

@@ -1256,17 +1256,16 @@ void Engine::finish_plan() {
       ops_.push_back(std::move(op));
     }
     // range probe: an activation that left the fp16 range surfaces in the logits as inf / NaN (kernels_misc.hip finite_probe_kernel)
-    d_status_ = static_cast<unsigned*>(dalloc(sizeof(unsigned), true));
-    VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_status_), sizeof(unsigned), hipHostMallocDefault));
-    *h_status_ = 0;
+    d_status_ = static_cast<unsigned*>(dalloc(VP_PROBE_BLOCKS * sizeof(unsigned), true));
+    VP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_status_), VP_PROBE_BLOCKS * sizeof(unsigned), hipHostMallocDefault));
+    std::memset(h_status_, 0, VP_PROBE_BLOCKS * sizeof(unsigned));
     Op probe;
     probe.name = "finite_probe";
     probe.kernel = "finite_probe";
     probe.bytes = 4.0 * out_c_ * out_h_ * out_w_;
     probe.run = [this](hipStream_t st) -> hipError_t {
       if (!finite_check_) return hipSuccess;
-      // per-pass flag: cleared here (a 4-byte memset node in the captured graph), then OR-ed by the scan
-      if (hipError_t e = hipMemsetAsync(d_status_, 0, sizeof(unsigned), st); e != hipSuccess) return e;
+      // per-pass verdict: the scan OVERWRITES every word (no clear node in the graph, nothing sticky: ADVICE round 4)
       return launch_finite_probe(d_logits_, (size_t)out_c_ * out_h_ * out_w_, d_status_, st);
     };
     ops_.push_back(std::move(probe));

@@ -64,6 +64,7 @@ struct Act {
 struct Op {
   std::string name;
   std::string kernel;  // kernel instantiation tag (groups launches for the roofline report)
+  std::string launch;  // launch geometry fixed at PLAN time that the tag does not spell (split-K factor, persistent-group count): hashed by vp_plan_hash
   double flops = 0, bytes = 0;
   std::function<hipError_t(hipStream_t)> run;
 };
@@ -79,6 +80,11 @@ struct ConvOpts {
   int post_act = ACT_NONE;      // activation after the residual (CTX: SiLU(c4*x + x))
   bool pixel_shuffle = false;   // set by add_convT*: the GEMM stores with STORE_SHUFFLE2 (never the pointwise kernel)
 };
+
+// Frame pools registered for DMA (vp_register_frames): process-wide, engine_io.cpp
+int register_frame_range(const void* pool, size_t bytes);
+int unregister_frame_range(const void* pool);
+bool frame_range_registered(const void* p, size_t bytes);
 
 class Engine {
  public:

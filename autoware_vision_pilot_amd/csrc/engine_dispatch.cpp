@@ -78,7 +78,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   p.zeros = static_cast<const half_t*>(zero_page());
   // the head's logits convolution decodes the mask in its epilogue (one launch and a 2.4 MB re-read less per network)
   const bool fuse_decode = store_mode == STORE_NCHW_F32 && o.logits_out == d_logits_ && d_mask_ && cout_real <= 8 && ncols <= 32 && kind_ >= 0 &&
-                           kind_ != 4 && !(dev_option("VP_FUSE_DECODE") && dev_option("VP_FUSE_DECODE")[0] == '0');
+                           kind_ != 4 && !(dev_option_is("VP_FUSE_DECODE", '0'));
   if (fuse_decode) {
     p.mask_out = d_mask_;
     decode_fused_ = true;
@@ -95,6 +95,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
   const bool sp = split();
   Op op;
   op.name = name;
+  if (pc.nsplit > 1) op.launch = "nsplit=" + std::to_string(pc.nsplit);   // the tag only says "+splitk"
   op.flops = 2.0 * M * (double)cout_real * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * in->Creal * ks * ks;
   const double esz = sp ? 4.0 : 2.0;
   op.bytes = esz * ((double)M * in->Creal + (double)M * (store_mode == STORE_SHUFFLE2 ? 4 : 1) * cout_real) +
@@ -160,7 +161,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     }
     // the heads' logits convolution: weights stationary in registers, 16x16x32 MFMA, LDS-DMA halo (kernels_head.hip); same weight
     // packing as halo tile 4.  VP_HEAD_CONV=0 keeps the halo kernel.
-    if (ht == 4 && o.tile < 0 && head_conv_supported(p) && !(dev_option("VP_HEAD_CONV") && dev_option("VP_HEAD_CONV")[0] == '0')) {
+    if (ht == 4 && o.tile < 0 && head_conv_supported(p) && !(dev_option_is("VP_HEAD_CONV", '0'))) {
       const void* zeros = zero_page();
       op.kernel = std::string("head_conv3x3<c") + std::to_string(p.Cin) + (sp ? ",x3>" : ",x1>") + (fuse_decode ? "+decode" : "");
       op.run = [this, p, zeros, fuse_decode](hipStream_t st) {
@@ -190,10 +191,14 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       throw std::invalid_argument("LDS-DMA GEMM kernel (tile 6): ConvTranspose k2 s2 (+ skip link) + bias, 4 * Cout and Cout multiples of 256, K >= 256, >= 128 pixels: " + name);
     op.kernel = std::string("gemm_dma<co256,px128,") + (sp ? "x3>" : "x1>") + (pc.nsplit > 1 ? "+splitk" : "");
     op.run = [p](hipStream_t st) { return launch_gemm_dma(p, st); };
-  } else if (tile == 5 || (!(dev_option("VP_CONVT_RS") && dev_option("VP_CONVT_RS")[0] == '0') && convt_rs_supported(p, sp))) {
+  } else if (tile == 5 || (!(dev_option_is("VP_CONVT_RS", '0')) && convt_rs_supported(p, sp))) {
     if (!convt_rs_supported(p, sp))
       throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
     op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
+    if (const char* e = dev_option("VP_CONVT_RS_GROUPS")) {   // resolved HERE, at plan time, and part of the plan hash
+      p.rs_groups = std::max(1, std::atoi(e));
+      op.launch += "groups=" + std::to_string(p.rs_groups);
+    }
     op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
   } else {
     const int epi = (ks == 1 && !sp && !p.w8) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)
@@ -321,6 +326,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       int ns = o.nsplit > 0 ? o.nsplit : std::max(1, slots / (regions * n_co));
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
       while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
+      if (const char* e = dev_option("VP_MAP_NSPLIT_PCT")) {   // developer knob (K-slice sweeps of the map kernel): percentage of the rule's factor
+        if (o.nsplit <= 0 && ns > 1) ns = std::max(1, (int)(ns * std::atoi(e) / 100.0 + 0.5));
+      }
       pc.bk = split() ? 16 : 32;
       pc.nsplit = std::max(1, std::min(ns, std::max(1, KS / 2)));
     } else {
@@ -334,7 +342,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     if (o.nsplit > 0) {
       ns = o.nsplit;
     } else if (halo == 4 && o.logits_out && cout <= 4 && (cin_pad == 64 || cin_pad == 128) && o.res_mode == RES_NONE && o.act == ACT_NONE &&
-               cstride == 1 && !(dev_option("VP_HEAD_CONV") && dev_option("VP_HEAD_CONV")[0] == '0')) {
+               cstride == 1 && !(dev_option_is("VP_HEAD_CONV", '0'))) {
       ns = 1;  // a head's logits convolution goes to kernels_head.hip (persistent workgroups: needs no split on any map size)
     } else if (blocks < 256 && split()) {
       // parity mode (measured per layer with VP_NSPLIT_FORCE = 1..16, profiles/r02_splitk_sweep_fp16x3.txt): ONE full round of

@@ -2,6 +2,13 @@
 // capture and replay (single engine and base + shared heads), output fetch and the range probe's verdict, resizes, visualisation, timers.
 #include "engine_internal.hpp"
 
+#include <cstdint>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "../../include/vp_hip.h"
+
 namespace vp {
 
 // ------------------------------------------------------------------------------------------ frame handling
@@ -183,6 +190,47 @@ void Engine::ensure_tables(int h, int w) {
   tab_w_ = w;
 }
 
+// ---- frame pools registered for DMA (vp_register_frames): a short sorted table behind a mutex; the lookup is two compares per range
+namespace {
+std::mutex g_pool_mu;
+std::vector<std::pair<uintptr_t, size_t>> g_pools;   // [begin, bytes), disjoint
+}  // namespace
+int register_frame_range(const void* pool, size_t bytes) {
+  if (!pool || bytes == 0) return VP_ERR_ARG;
+  const uintptr_t b = reinterpret_cast<uintptr_t>(pool);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (const auto& r : g_pools)
+    if (b < r.first + r.second && r.first < b + bytes) return VP_ERR_ARG;   // overlaps a registered range
+  if (hipHostRegister(const_cast<void*>(pool), bytes, hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return VP_ERR_HIP;
+  }
+  g_pools.emplace_back(b, bytes);
+  return VP_OK;
+}
+int unregister_frame_range(const void* pool) {
+  if (!pool) return VP_ERR_ARG;
+  const uintptr_t b = reinterpret_cast<uintptr_t>(pool);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_pools.size(); ++i)
+    if (g_pools[i].first == b) {
+      g_pools.erase(g_pools.begin() + i);
+      if (hipHostUnregister(const_cast<void*>(pool)) != hipSuccess) {
+        (void)hipGetLastError();
+        return VP_ERR_HIP;
+      }
+      return VP_OK;
+    }
+  return VP_ERR_ARG;
+}
+bool frame_range_registered(const void* p, size_t bytes) {
+  const uintptr_t b = reinterpret_cast<uintptr_t>(p);
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (const auto& r : g_pools)
+    if (b >= r.first && b + bytes <= r.first + r.second) return true;
+  return false;
+}
+
 void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int index) {
   if (base_) throw std::invalid_argument("shared engine: frames go to the base engine (vp_infer on the base, then vp_infer_shared)");
   if (!frame || h < 2 || w < 2 || stride < 3 * w) throw std::invalid_argument("bad frame geometry");
@@ -209,7 +257,9 @@ void Engine::upload_frame(const uint8_t* frame, int h, int w, int stride, int in
   // itself is one DMA that overlaps other engines' kernels (the reference does the same H2D: tensorrt_backend.cpp:184-186).
   uint8_t* dst = d_frame_ + (size_t)index * need;
   const size_t packed = (size_t)(h - 1) * stride + (size_t)3 * w;
-  if (pinned_staging_) {
+  // a frame inside a pool the host registered (vp_register_frames) is page-locked already: one DMA straight from the caller's memory
+  const bool staged = pinned_staging_ && !frame_range_registered(frame, packed);
+  if (staged) {
     if (need > h_frame_cap_) {
       VP_HIP_CHECK(hipStreamSynchronize(stream_));
       if (h_frame_) hipHostFree(h_frame_);
@@ -391,14 +441,15 @@ void Engine::sync() {
 }
 
 // The probe's verdict on the pass whose outputs were last fetched (enqueue_fetch copies the flag behind them).  The flag is PER PASS: the
-// probe op clears it before it scans (engine.cpp finish_plan), so a bad frame is reported once, by the call that fetches THAT frame, and a
+// probe kernel overwrites every word of it on every pass (kernels_misc.hip; nothing to clear, nothing sticky), so a bad frame is reported once, by the call that fetches THAT frame, and a
 // pass that was enqueued but never fetched leaves nothing behind for a later frame.
 bool Engine::poll_status() {
   if (!status_pending_ || !h_status_) return false;
   status_pending_ = false;
-  const bool bad = *h_status_ != 0;
-  *h_status_ = 0;
-  return bad;
+  unsigned bad = 0;
+  for (int i = 0; i < VP_PROBE_BLOCKS; ++i) bad |= h_status_[i];
+  std::memset(h_status_, 0, VP_PROBE_BLOCKS * sizeof(unsigned));
+  return bad != 0;
 }
 void Engine::check_status() {
   if (poll_status())
@@ -422,7 +473,7 @@ void Engine::enqueue_fetch() {
   host_logits_valid_ = (outputs_ & 1) != 0;
   host_mask_valid_ = (outputs_ & 2) != 0;
   if (finite_check_ && d_status_) {
-    VP_HIP_CHECK(hipMemcpyAsync(h_status_, d_status_, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+    VP_HIP_CHECK(hipMemcpyAsync(h_status_, d_status_, VP_PROBE_BLOCKS * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
     status_pending_ = true;
   }
 }

@@ -6,6 +6,7 @@ namespace vp {
 
 // developer option set through vp_set_option (options.cpp), or nullptr -- the library never reads the environment
 const char* dev_option(const char* key);
+bool dev_option_is(const char* key, char first);  // value set and starting with `first`: one lookup
 
 struct PreprocessParams {
   const uint8_t* frame;  // device, HxWx3
@@ -256,7 +257,8 @@ hipError_t launch_resize_nearest(const uint8_t* src, int sw, const int* ytab, co
 hipError_t launch_resize_bilinear_f32(const float* src, int sw, const int* yi, const float* yf, const int* xi, const float* xf,
                                       int oh, int ow, float* dst, hipStream_t st);
 hipError_t launch_minmax_f32(const float* src, size_t n, unsigned* mm, hipStream_t st);
-hipError_t launch_finite_probe(const float* src, size_t n, unsigned* flag, hipStream_t st);  // *flag |= 1 if any inf / NaN (sticky)
+constexpr int VP_PROBE_BLOCKS = 64;  // words of the range probe's verdict
+hipError_t launch_finite_probe(const float* src, size_t n, unsigned* flags, hipStream_t st);  // flags[0..VP_PROBE_BLOCKS) = per-workgroup 0 / 1, overwritten every pass
 hipError_t launch_depth_colorize(const float* src, size_t n, const unsigned* mm, const uint8_t* lut, uint8_t* dst, hipStream_t st);
 hipError_t launch_viz_blend(const uint8_t* mask, int mw, const int* ytab, const int* xtab, const uint8_t* frame, int stride, int oh, int ow,
                             const uint8_t* lut, int frame_is_rgb, uint8_t* dst, hipStream_t st);

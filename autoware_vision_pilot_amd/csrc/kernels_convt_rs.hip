@@ -205,7 +205,7 @@ hipError_t launch_rs_cfg(const ConvGemmParams& p, hipStream_t st) {
   const int n_tiles = (p.H * p.W) >> 5, slices = p.Ncols / (256 * NT);
   // persistent, one workgroup per CU: the pixel tiles are dealt round-robin to 256 / slices groups
   int groups = std::max(1, std::min(n_tiles, 256 / slices));
-  if (const char* e = dev_option("VP_CONVT_RS_GROUPS")) groups = std::max(1, std::min(groups, std::atoi(e)));  // developer / test knob: more tiles per workgroup
+  if (p.rs_groups > 0) groups = std::max(1, std::min(groups, p.rs_groups));  // developer / test knob (VP_CONVT_RS_GROUPS, read when the plan is built): more tiles per workgroup
   hipLaunchKernelGGL(k, dim3(slices * groups), dim3(512), lds, st, p, groups);
   return hipGetLastError();
 }

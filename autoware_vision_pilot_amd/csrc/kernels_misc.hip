@@ -271,11 +271,12 @@ __device__ inline unsigned f32_order_key(float f) {
 }
 __device__ inline float f32_from_order_key(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
-// Range probe on a network's output: sets *flag (sticky until the host clears it) if any value is inf / NaN.  The parity mode carries
+// Range probe on a network's output: flags[blockIdx.x] = 1 if any value this workgroup scanned is inf / NaN, else 0.  The parity mode carries
 // fp16 EXPONENT range (hi = fp16(x) overflows to inf above 65504); an overflow anywhere in the network reaches the logits as inf or NaN
 // (inf - inf in the next convolution), so one pass over the 2.4 MB of logits (reads served by the L2 right behind the head's stores)
-// catches it.  f32x4 loads, one atomic per offending wave at most.
-__global__ __launch_bounds__(256) void finite_probe_kernel(const float* src, size_t n, unsigned* flag) {
+// catches it.  Every pass OVERWRITES all VP_PROBE_BLOCKS words (round 5): nothing is sticky, so no clear -- neither a memset node in the
+// captured graph nor a host-side one -- stands between a bad frame and the good frame behind it; the host ORs the words it fetched.
+__global__ __launch_bounds__(256) void finite_probe_kernel(const float* src, size_t n, unsigned* flags) {
   bool bad = false;
   const size_t n4 = n >> 2;
   const f32x4_t* s4 = reinterpret_cast<const f32x4_t*>(src);
@@ -285,7 +286,12 @@ __global__ __launch_bounds__(256) void finite_probe_kernel(const float* src, siz
     for (int r = 0; r < 4; ++r) bad |= (__float_as_uint(v[r]) & 0x7F800000u) == 0x7F800000u;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= (__float_as_uint(src[(n4 << 2) + threadIdx.x]) & 0x7F800000u) == 0x7F800000u;
-  if (bad) atomicOr(flag, 1u);
+  __shared__ unsigned s_any;
+  if (threadIdx.x == 0) s_any = 0u;
+  __syncthreads();
+  if (bad) s_any = 1u;   // every writer stores the same value
+  __syncthreads();
+  if (threadIdx.x == 0) flags[blockIdx.x] = s_any;
 }
 
 __global__ __launch_bounds__(256) void minmax_f32_kernel(const float* src, size_t n, unsigned* mm) {  // mm[0] = min key, mm[1] = max key
@@ -402,9 +408,8 @@ hipError_t launch_minmax_f32(const float* src, size_t n, unsigned* mm, hipStream
   const unsigned blocks = (unsigned)((n + 255) / 256);
   VP_LAUNCH(minmax_f32_kernel, dim3(blocks < 1024u ? (blocks ? blocks : 1u) : 1024u), dim3(256), 0, st, src, n, mm);
 }
-hipError_t launch_finite_probe(const float* src, size_t n, unsigned* flag, hipStream_t st) {
-  const unsigned blocks = (unsigned)((n / 4 + 255) / 256);
-  VP_LAUNCH(finite_probe_kernel, dim3(blocks < 256u ? (blocks ? blocks : 1u) : 256u), dim3(256), 0, st, src, n, flag);
+hipError_t launch_finite_probe(const float* src, size_t n, unsigned* flags, hipStream_t st) {
+  VP_LAUNCH(finite_probe_kernel, dim3(VP_PROBE_BLOCKS), dim3(256), 0, st, src, n, flags);  // always the full grid: every word is rewritten
 }
 hipError_t launch_depth_colorize(const float* src, size_t n, const unsigned* mm, const uint8_t* lut, uint8_t* dst, hipStream_t st) {
   VP_LAUNCH(depth_colorize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, n, mm, lut, dst);

@@ -318,6 +318,32 @@ int vp_set_finite_check(vp_engine* e, int enable) {
 int vp_set_pinned_staging(vp_engine* e, int enable) {
   return guarded(e, [&](vp::Engine& g) { g.set_pinned_staging(enable != 0); });
 }
+int vp_register_frames(const void* pool, size_t bytes) {
+  try {
+    return vp::register_frame_range(pool, bytes);
+  } catch (...) {
+    return VP_ERR_HIP;
+  }
+}
+int vp_unregister_frames(const void* pool) {
+  try {
+    return vp::unregister_frame_range(pool);
+  } catch (...) {
+    return VP_ERR_HIP;
+  }
+}
+int vp_output_shape(const vp_engine* e, int64_t shape[4]) {
+  if (!e || !e->impl || !shape) return VP_ERR_ARG;
+  if (!e->impl->have_outputs()) {
+    const_cast<vp_engine*>(e)->err = "Inference has not been run yet. Call vp_infer() first.";  // onnx_runtime_backend.cpp:86-88
+    return VP_ERR_STATE;
+  }
+  shape[0] = 1;
+  shape[1] = e->impl->out_c();
+  shape[2] = e->impl->out_h();
+  shape[3] = e->impl->out_w();
+  return VP_OK;
+}
 int vp_frame_hw(const vp_engine* e, int* h, int* w) {
   if (!e || !e->impl || !h || !w) return VP_ERR_ARG;
   *h = e->impl->frame_h();
@@ -474,7 +500,8 @@ int vp_layer_kernel(const vp_engine* e, int i, const char** kernel) {
   *kernel = e->impl->ops()[i].kernel.c_str();
   return VP_OK;
 }
-// FNV-1a over (launch name, kernel tag) of every launch of the plan: two engines with equal hashes run the same kernels in the same order
+// FNV-1a over (launch name, kernel tag, launch geometry) of every launch of the plan: two engines with equal hashes run the same kernels with the same
+// split factors / group counts in the same order
 unsigned long long vp_plan_hash(const vp_engine* e) {
   if (!e || !e->impl) return 0;
   unsigned long long h = 1469598103934665603ull;
@@ -489,6 +516,7 @@ unsigned long long vp_plan_hash(const vp_engine* e) {
   for (const vp::Op& op : e->impl->ops()) {
     mix(op.name);
     mix(op.kernel);
+    if (!op.launch.empty()) mix(op.launch);
   }
   return h ? h : 1;
 }

@@ -27,6 +27,49 @@ def image_loader(image):
     return np.ascontiguousarray(x.transpose(2, 0, 1))[None]
 
 
+class _ModelEngine(_lib.Engine):
+    """``self.model`` of the wrappers below: an Engine whose resize mode can be BORROWED by ``inference_resized``.  The borrowed mode
+    (Pillow's antialiased bicubic) stays set across consecutive ``inference_resized`` calls -- no per-frame rebuild of the tap tables and
+    no graph recapture -- and the caller's own mode comes back the moment the caller looks at it or feeds a frame
+    directly (``model.resize_mode()``, ``model.infer(frame)``, ``model.upload_frame`` ...)."""
+    _lent = None    # the caller's mode while the PIL one is borrowed
+
+    def _give_back(self):
+        if self._lent is not None:
+            prev, self._lent = self._lent, None
+            super().set_resize_mode(prev)
+
+    def borrow_resize_mode(self, mode):
+        cur = super().resize_mode()
+        if cur != mode:
+            if self._lent is None:
+                self._lent = cur
+            super().set_resize_mode(mode)
+
+    def infer_borrowed(self, frame_u8):
+        super().infer(frame_u8)
+
+    def resize_mode(self):
+        self._give_back()
+        return super().resize_mode()
+
+    def set_resize_mode(self, mode):
+        self._lent = None
+        super().set_resize_mode(mode)
+
+    def infer(self, frame_u8):
+        self._give_back()
+        super().infer(frame_u8)
+
+    def infer_multi(self, heads, frame_u8):
+        self._give_back()
+        super().infer_multi(heads, frame_u8)
+
+    def upload_frame(self, frame_u8, index=None):
+        self._give_back()
+        super().upload_frame(frame_u8, index)
+
+
 class _NetworkInfer:
     _kind = None
 
@@ -34,7 +77,7 @@ class _NetworkInfer:
         if checkpoint_path is None or len(checkpoint_path) == 0:
             raise ValueError("No path to checkpiont file provided in class initialization")
         self.device = f"hip:{gpu_id}"
-        self.model = _lib.Engine(self._kind, checkpoint_path, precision=precision, gpu_id=gpu_id)
+        self.model = _ModelEngine(self._kind, checkpoint_path, precision=precision, gpu_id=gpu_id)
         self.model.set_input_format(_lib.VP_RGB8, _lib.VP_PLANES_RGB)
 
     def _forward(self, image, check_size=True):
@@ -56,17 +99,11 @@ class _NetworkInfer:
         a = np.asarray(frame)
         if a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
             raise ValueError("frame must be HxWx3 uint8 RGB")
-        # the engine's resize mode is restored afterwards: a later self.model.infer(frame) by the caller resizes as documented
-        # (VP_RESIZE_CV_LINEAR unless the caller chose otherwise), not as this call did
-        prev = self.model.resize_mode()
-        if prev != _lib.VP_RESIZE_PIL_BICUBIC:
-            self.model.set_resize_mode(_lib.VP_RESIZE_PIL_BICUBIC)
-        try:
-            self.model.infer(a)
-            return self._post()
-        finally:
-            if prev != _lib.VP_RESIZE_PIL_BICUBIC:
-                self.model.set_resize_mode(prev)
+        # the PIL mode is BORROWED (see _ModelEngine): it stays set while inference_resized calls follow one another, and a later
+        # self.model.infer(frame) / resize_mode() by the caller sees the mode the caller chose (VP_RESIZE_CV_LINEAR by default)
+        self.model.borrow_resize_mode(_lib.VP_RESIZE_PIL_BICUBIC)
+        self.model.infer_borrowed(a)
+        return self._post()
 
 
 class SceneSegNetworkInfer(_NetworkInfer):

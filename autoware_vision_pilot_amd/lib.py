@@ -63,6 +63,9 @@ _SIGS = {
     "vp_frame_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_set_outputs": (C.c_int, [_P, C.c_int]),
     "vp_set_pinned_staging": (C.c_int, [_P, C.c_int]),
+    "vp_register_frames": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "vp_unregister_frames": (C.c_int, [C.c_void_p]),
+    "vp_output_shape": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "vp_set_finite_check": (C.c_int, [_P, C.c_int]),
     "vp_infer_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "vp_enqueue_multi": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
@@ -193,6 +196,24 @@ def options_from_env(environ=None):
         if k.startswith("VP_") and load().vp_set_option(k.encode(), v.encode()) == 0:
             done[k] = v
     return done
+
+
+def register_frames(buf):
+    """vp_register_frames: page-lock a host buffer (a C-contiguous uint8 ndarray that OUTLIVES the registration, e.g. a frame pool) so frames
+    inside it go to the device by one DMA with no staging copy.  Keep the array alive and call unregister_frames(buf) before freeing it."""
+    a = np.asarray(buf)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("frame pool must be C-contiguous")
+    rc = load().vp_register_frames(a.ctypes.data_as(C.c_void_p), a.nbytes)
+    if rc != 0:
+        raise VpError(f"vp_register_frames failed (rc {rc})")
+    return a
+
+
+def unregister_frames(buf):
+    rc = load().vp_unregister_frames(np.asarray(buf).ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise VpError(f"vp_unregister_frames failed (rc {rc})")
 
 
 def version():
@@ -417,6 +438,16 @@ class Engine:
     def set_outputs(self, logits=True, mask=True):
         """Which outputs infer() / infer_shared() / infer_multi() copy to the host; the rest is fetched on first use."""
         self._ck(self._lib.vp_set_outputs(self._h, (VP_OUT_LOGITS if logits else 0) | (VP_OUT_MASK if mask else 0)))
+
+    def host_logits_current(self):
+        """True when the pinned host copy of the logits belongs to the last pass (vp_host_logits_current)."""
+        return bool(self._lib.vp_host_logits_current(self._h))
+
+    def output_shape(self):
+        """(1, C, H, W) of the output tensor without fetching it (vp_output_shape)."""
+        sh = (C.c_int64 * 4)()
+        self._ck(self._lib.vp_output_shape(self._h, sh))
+        return tuple(int(v) for v in sh)
 
     def set_pinned_staging(self, on):
         self._ck(self._lib.vp_set_pinned_staging(self._h, int(bool(on))))

@@ -259,3 +259,44 @@ def synthetic_frame(h, w, seed, smooth=True):
         img[..., c] = 127.5 + 90.0 * np.sin(2 * np.pi * (fy * yy / h + fx * xx / w) + ph)
     img += rng.normal(0.0, 12.0, size=img.shape).astype(np.float32)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ a second weight family
+_PAIRS = (("context_layer_0", "context_layer_1"), ("context_layer_4", "context_layer_5"), ("decode_layer_0", "decode_layer_1"),
+          ("decode_layer_2", "decode_layer_3"), ("decode_layer_4", "decode_layer_5"), ("decode_layer_6", "decode_layer_7"),
+          ("decode_layer_8", "decode_layer_9"))
+
+
+def make_trained_like_state_dict(kind, seed):
+    """"Trained-like" statistics beside the variance-preserving family of make_state_dict: what a checkpoint has and a
+    Kaiming draw has not.
+      * encoder: every convolution that feeds a BatchNorm is scaled per OUTPUT CHANNEL by s * g_c (s ~ U(0.1, 0.3) per layer, g_c log-uniform
+        over three decades) and the layer's running_mean / running_var follow (x f, x f^2): gamma / sqrt(var + eps) then spreads over 10^3 across
+        the channels of a layer, the smallest variances sink to the order of eps (near-dead channels), and the function stays the base
+        family's up to eps -- BN folding, the per-row weight prescale and the (hi, lo) split see rows of very different magnitude;
+      * context / neck / head (no normalisation layers): the 3x3 convolutions and the context MLP come in (down, up) pairs -- the first of a
+        pair (weights and bias) x s, the second x 1 / s, s ~ U(0.1, 0.3) -- so every second tensor of the decoder is 3-10x SMALLER than in the
+        base family (|x| well under 0.1, where the lo plane of an fp16 pair is subnormal) while the logits stay O(1) (GELU is not
+        homogeneous, so the function differs from the base family's: a different network, not a re-parameterisation).
+    Same key layout, deterministic in (kind, seed)."""
+    f32 = np.float32
+    sd = make_state_dict(kind, seed)
+    rng = np.random.default_rng(seed + 7919)
+    for k, shape, kd in model_spec(kind):
+        if kd == "conv" and k.endswith(".0.weight") and (k[:-len("0.weight")] + "1.running_var") in sd:
+            base = k[:-len("0.weight")]
+            f = (rng.uniform(0.1, 0.3) * 10.0 ** rng.uniform(-1.5, 1.5, size=shape[0])).astype(f32)
+            sd[k] = (sd[k] * f[:, None, None, None]).astype(f32)
+            sd[base + "1.running_mean"] = (sd[base + "1.running_mean"] * f).astype(f32)
+            sd[base + "1.running_var"] = (sd[base + "1.running_var"] * f * f).astype(f32)
+    keys = list(sd)
+    for down, up in _PAIRS:
+        kd_ = [k for k in keys if k.endswith(down + ".weight")]
+        ku_ = [k for k in keys if k.endswith(up + ".weight")]
+        if not kd_ or not ku_:
+            continue
+        s = f32(rng.uniform(0.1, 0.3))
+        sd[kd_[0]] = (sd[kd_[0]] * s).astype(f32)
+        sd[kd_[0][:-len("weight")] + "bias"] = (sd[kd_[0][:-len("weight")] + "bias"] * s).astype(f32)
+        sd[ku_[0]] = (sd[ku_[0]] / s).astype(f32)
+    return sd

@@ -170,6 +170,21 @@ enum vp_output_bits { VP_OUT_LOGITS = 1, VP_OUT_MASK = 2 };
 int vp_set_outputs(vp_engine* e, int output_bits);
 /* vp_infer stages the caller's pageable frame through a pinned double buffer owned by the engine (default 1). */
 int vp_set_pinned_staging(vp_engine* e, int enable);
+/* FRAME POOLS (round 5).  The staging above is a single-threaded host memcpy of the whole frame (2.76 MB at 1280x720: ~130 us of a 3.5 ms
+ * node frame).  A host that owns its frame buffers (a cv::Mat pool, a camera ring, a ROS message arena) registers them ONCE:
+ *   vp_register_frames(pool, bytes)  page-locks [pool, pool + bytes) for DMA (hipHostRegister, portable across devices); process-wide;
+ * and every vp_infer* / vp_upload_frame* whose frame lies wholly inside a registered range is then copied by ONE DMA straight from the
+ * caller's memory -- no staging copy.  Contract for the asynchronous calls (vp_upload_frame*): such a frame must stay unmodified until the
+ * pass that consumes it has been synchronised (vp_sync / vp_fetch_outputs / vp_infer*); the staged path copied it before returning, this one
+ * does not.  The synchronous vp_infer* calls return after the copy, as before.  Frames outside every registered range take the staged path.
+ * What TensorRTBackend does with its own pinned input buffer (tensorrt_backend.cpp:184-186), offered to the caller's buffers instead.
+ * vp_unregister_frames(pool) releases a range registered with exactly that pointer (after the last pass that read it was synchronised).
+ * Returns VP_ERR_ARG (null / zero / overlapping an existing range / unknown pointer) or VP_ERR_HIP (the runtime refused to lock the pages). */
+int vp_register_frames(const void* pool, size_t bytes);
+int vp_unregister_frames(const void* pool);
+/* {1, C, H, W} of the output tensor WITHOUT touching the device: vp_logits also returns the shape but fetches a de-selected tensor
+ * (vp_set_outputs) on the way.  Same state rule as vp_logits: VP_ERR_STATE before the first inference (onnx_runtime_backend.cpp:86-91). */
+int vp_output_shape(const vp_engine* e, int64_t shape[4]);
 /* RANGE GUARD.  Both precision modes compute on fp16 planes: VP_FP16X3 has fp32-class SIGNIFICAND (hi + lo) but fp16 EXPONENT range.
  *   - at load: a BN-folded weight with |w| > 65504 (or non-finite) fails vp_create* with VP_ERR_RANGE instead of loading as inf;
  *   - per frame: an activation beyond 65504 becomes inf and reaches the logits as inf / NaN; a probe kernel over the logits at the end

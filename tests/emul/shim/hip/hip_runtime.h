@@ -483,6 +483,9 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipMalloc(reinterpret_cast<void**>(p), n); }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0, hipHostRegisterPortable = 1 };
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }   // host memory is host memory here
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   if (emu::capturing) {

@@ -213,6 +213,20 @@ def test_python_operator_api(state_dicts, oracle_runs):
             assert flips.mean() < 5e-4 and ((srt[-1] - srt[-2])[flips] < 2e-3).all()
             with pytest.raises(ValueError):
                 net.inference(img.resize((320, 160)))
+            # inference_resized = the scripts' `image.resize((640, 320))` + `inference(image)` in one device pass; the Pillow mode it needs is
+            # BORROWED: it stays set between consecutive calls (no per-frame table rebuild / recapture) and the caller's own mode is back the
+            # moment the caller looks
+            from autoware_vision_pilot_amd import lib
+            big = Image.fromarray(pre_post.synthetic_frame(720, 1280, 5))
+            r1 = net.inference_resized(big)
+            h1 = net.model.plan_hash()
+            r2 = net.inference_resized(big)
+            assert np.array_equal(r1, r2) and net.model.plan_hash() == h1
+            via_pil = net.inference(big.resize((640, 320)))
+            assert (r1 != via_pil).mean() < 5e-4
+            assert net.model.resize_mode() == lib.VP_RESIZE_CV_LINEAR
+            r3 = net.inference_resized(big)
+            assert np.array_equal(r1, r3)
         elif kind == "scene3d":
             assert out.dtype == np.float32 and out.shape == (320, 640, 1)
             assert _rel(out[..., 0], ref[0]) <= 1e-3

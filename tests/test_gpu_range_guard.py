@@ -69,3 +69,24 @@ def test_weight_beyond_fp16_fails_at_load(state_dicts):
     for prec in ("fp16x3", "fp16"):
         with pytest.raises(lib.VpRangeError, match="fp16 range"):
             lib.Engine("sceneseg", vw.pack_state_dict(sd), precision=prec)
+
+
+def test_bad_frame_then_good_frame_on_one_replaying_engine(engines, frame720):
+    """the probe's verdict is per pass -- a NaN tensor, then a finite frame, on ONE warmed engine whose pass is a replayed
+    hipGraph.  The second call must succeed (the probe overwrites every word of its verdict each pass: no clear node to lose in a capture)."""
+    from autoware_vision_pilot_amd import lib
+
+    eng = engines("sceneseg", "fp16x3")
+    for _ in range(3):                      # eager pass, capture, replay
+        eng.infer(frame720)
+    good = eng.logits().copy()
+    x = eng.input_tensor().copy()
+    bad = x.copy()
+    bad[0, 0, 7, 9] = np.nan
+    for _ in range(2):
+        with pytest.raises(lib.VpRangeError, match="non-finite"):
+            eng.infer_tensor(bad)
+        eng.infer_tensor(x)                 # a finite tensor right behind it: no stale verdict
+        assert np.array_equal(eng.logits(), good)
+        eng.infer(frame720)
+        assert np.array_equal(eng.logits(), good)
