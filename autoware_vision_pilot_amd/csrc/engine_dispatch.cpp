@@ -90,7 +90,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     p.in2_delta_lo = (in->lo && o.in2->lo) ? o.in2->lo - in->lo : 0;
   }
   const int M = p.H * p.W;
-  p.partial = (pc.nsplit > 1 || pc.tile == 111) ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
+  p.partial = (pc.nsplit > 1 || pc.tile == 111 || pc.tile == 112) ? static_cast<float*>(dalloc((size_t)pc.nsplit * M * pc.CoutW * sizeof(float), false)) : nullptr;
   const int tile = pc.tile, bk = pc.bk;
   const bool sp = split();
   Op op;
@@ -148,6 +148,13 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       if (!conv3x3_map_supported(p)) throw std::invalid_argument("halo tile 11 (map kernel): 3x3 stride 1, 20x40 or 10x20 regions: " + name);
       op.kernel = std::string("conv3x3_map<co32,") + (conv3x3_map_geometry(p.H, p.W) == 1 ? "px800," : "px200,") + (sp ? "x3>" : "x1,k32>") + "+splitk";
       op.run = [p](hipStream_t st) { return launch_conv3x3_map(p, st); };
+      ops_.push_back(std::move(op));
+      return;
+    }
+    if (ht == 12) {
+      if (!conv3x3_map2_supported(p)) throw std::invalid_argument("halo tile 12 (map kernel, 64-channel slabs): parity mode, 3x3 stride 1, 20x40 regions, output channels padded to 64: " + name);
+      op.kernel = "conv3x3_map2<co64,px800,x3>+splitk";
+      op.run = [p](hipStream_t st) { return launch_conv3x3_map2(p, st); };
       ops_.push_back(std::move(op));
       return;
     }
@@ -307,7 +314,15 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       if (o.tile == 111 || (on && prec_on && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && geom_on &&
                             conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
         halo = 11;
+      // round 5: 64-channel slabs (two M tiles per wave, kernels_conv3x3_map.hip "map2") where the geometry is the neck's and the output channels pad to 64
+      // without waste: parity mode only.  VP_MAP2=0 (developer knob, A/B timing): tile 11 everywhere.
+      if (halo == 11 && o.tile < 0 && split() && geom == 1 && !dev_option_is("VP_MAP2", '0') && round_up(ncols, 64) == round_up(ncols, 32) &&
+          conv3x3_map2_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 64)))
+        halo = 12;
     }
+    if (o.tile == 112) halo = 12;
+    if (halo == 12 && (!split() || fp8_storage() || !conv3x3_map2_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 64))))
+      throw std::invalid_argument("halo tile 12 (map kernel, 64-channel slabs): parity mode, maps that tile into 20x40 regions, >= 32 input channels: " + name);
     // VP_WEIGHTS_FP8 as storage (AutoDrive engines and the operator entry): the halo kernel's 8x16-pixel tiles of 64 / 32 channels are the ones
     // instantiated with the byte-weight staging path (kernels_conv3x3.hip W8)
     if (fp8_storage() && o.tile < 0 && halo >= 0) halo = ncols <= 32 ? 4 : 3;
@@ -319,7 +334,16 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     pc.tile = 100 + halo;
     pc.bk = 32;
     pc.CoutW = round_up(ncols, halo_tile_co(halo));
-    if (halo == 11) {  // map kernel: K slices until ~one round of workgroups (one per CU at 20x40 regions, two at 10x20), fp32 slabs <= 24 MB
+    if (halo == 12) {  // 64-channel slabs: a workgroup is twice the work of tile 11's, so the SAME K split gives half the workgroups (see the kernel's header)
+      const int regions = (in->H / 20) * (in->W / 40), n_co = pc.CoutW / 64, KS = cin_pad / 16;
+      int slots = 128;
+      if (const char* e = dev_option("VP_MAP2_SLOTS")) slots = std::max(1, std::atoi(e));   // developer knob: workgroups a layer aims at
+      int ns = o.nsplit > 0 ? o.nsplit : std::max(1, slots / (regions * n_co));
+      const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
+      while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
+      pc.bk = 16;
+      pc.nsplit = std::max(1, std::min(ns, std::max(1, KS / 2)));
+    } else if (halo == 11) {  // map kernel: K slices until ~one round of workgroups (one per CU at 20x40 regions, two at 10x20), fp32 slabs <= 24 MB
       const int geom = conv3x3_map_geometry(in->H, in->W);
       const int regions = geom == 1 ? (in->H / 20) * (in->W / 40) : (in->H / 10) * (in->W / 20), n_co = pc.CoutW / 32, KS = cin_pad / (split() ? 16 : 32);
       const int slots = geom == 1 ? 256 : 512;   // 155 KB of LDS = one workgroup per CU (a 257th waits a whole round); 74 KB = two
@@ -424,6 +448,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
         const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = k32map ? conv3x3_map_pack_index_k32(co, ci, t, cin_pad)
+                         : halo == 12 ? conv3x3_map2_pack_index(co, ci, t, cin_pad)
                          : halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)
                          : k64     ? ((((size_t)(ci >> 6) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)
                          : halo >= 0 ? ((((size_t)(ci >> 5) * 9 + t) * pc.CoutW + co) * 32 + ci_sw)

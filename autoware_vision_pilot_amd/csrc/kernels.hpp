@@ -218,6 +218,12 @@ size_t conv3x3_map_pack_index(int co, int ci, int t, int cin_pad);
 size_t conv3x3_map_pack_index_k32(int co, int ci, int t, int cin_pad);   // fp16 engines: steps of 32 channels, plane = (ci >> 4) & 1
 bool conv3x3_map_supported(const ConvGemmParams& p);
 hipError_t launch_conv3x3_map(const ConvGemmParams& p, hipStream_t st);
+// halo tile 12 ("map2", round 5): the map kernel on 64-channel weight slabs (two M tiles per wave), parity mode, 20x40 regions; weights packed by
+// conv3x3_map2_pack_index; always finishes through splitk_finish_kernel
+bool conv3x3_map2_shape_ok(int H, int W, int cin_pad, int coutw);
+bool conv3x3_map2_supported(const ConvGemmParams& p);
+size_t conv3x3_map2_pack_index(int co, int ci, int t, int cin_pad);
+hipError_t launch_conv3x3_map2(const ConvGemmParams& p, hipStream_t st);
 // last convolution of a head: 3x3, 64 / 128 channels -> <= 4 logit channels, fp32 NCHW + fused decode (kernels_head.hip); weights packed
 // as for halo tile 4; zeros = the engine's zero page (>= 16 bytes of zeros in device memory)
 bool head_conv_supported(const ConvGemmParams& p);

@@ -312,7 +312,7 @@ hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hi
   if (tile == 2) return split ? hipErrorInvalidValue : launch_halo_cfg<64, 16, 16, 1, 4, false>(p, st);
   return hipErrorInvalidValue;
 }
-int halo_tile_co(int tile) { return (tile <= 1 || tile == 6 || tile == 7) ? 128 : ((tile <= 3 || tile == 8) ? 64 : 32); }
+int halo_tile_co(int tile) { return (tile <= 1 || tile == 6 || tile == 7) ? 128 : ((tile <= 3 || tile == 8 || tile == 12) ? 64 : 32); }
 int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 256 : 128; }
 int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 16 : 8; }
 

@@ -239,6 +239,28 @@ def test_map_kernel(emu_lib):
     _case(emu_lib, 96, 40, 10, 20, 3, 0, 1, 2, 0, [(111, -1, 3)], seed=79)                      # the context geometry, mul-add residual behind 3 slices
 
 
+def test_map2_kernel(emu_lib):
+    """kernels_conv3x3_map.hip, halo tile 12 (round 5): the map kernel on 64-channel weight slabs -- two M tiles per wave, rolling fragment
+    prefetch, single-buffered weights in two tap groups behind two barriers per step, pixel tile 24 split by M tile between waves 0 and 1.  One
+    region and four, one K slice and several (unequal lengths, a one-step slice: no A refill / no halo refill paths), one and two channel slabs,
+    ragged channel counts (padded rows), GELU / none / mul-add residual; bit-identical to tile 11 for equal K slices (same summation order)."""
+    _case(emu_lib, 48, 40, 20, 40, 3, 0, 1, 0, 1, [(112, -1, 1), (112, -1, 2)], seed=71)        # 64 padded input channels = 4 steps; one 64-channel slab (40 real rows)
+    _case(emu_lib, 96, 72, 40, 80, 3, 0, 0, 0, 1, [(112, -1, 3)], seed=72)                      # four regions, 6 steps in 3 slices, two slabs (72 -> 128 rows)
+    _case(emu_lib, 80, 32, 20, 40, 3, 0, 1, 2, 1, [(112, -1, 5)], seed=73)                      # 96 padded channels = 6 steps in 5 slices (1, 1, 1, 1, 2): one-step slices
+    rng = np.random.default_rng(81)
+    x = rng.standard_normal((64, 20, 40), dtype=np.float32)
+    wt = rng.standard_normal((128, 64, 3, 3), dtype=np.float32) * np.float32(0.06)
+    b = rng.standard_normal((128,), dtype=np.float32) * np.float32(0.1)
+    for ns in (1, 2):
+        a = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=111, nsplit=ns)
+        c = emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=112, nsplit=ns)
+        assert np.array_equal(a, c), f"tile 12 differs from tile 11 at nsplit {ns}"
+    with pytest.raises(emu_lib.VpError):
+        emu_lib.op_conv2d(np.zeros((32, 10, 20), np.float32), np.zeros((64, 32, 3, 3), np.float32), np.zeros(64, np.float32), ks=3, precision=1, tile=112, nsplit=1)   # 10x20: tile 11's geometry only
+    with pytest.raises(emu_lib.VpError):
+        emu_lib.op_conv2d(np.zeros((32, 20, 40), np.float32), np.zeros((64, 32, 3, 3), np.float32), np.zeros(64, np.float32), ks=3, precision=0, tile=112, nsplit=1)   # parity mode only
+
+
 def _q_e4m3(w):
     """oracle/autodrive.py quantize_fp8_e4m3 on one weight tensor: per-output-row symmetric OCP e4m3, returned de-quantised (fp32)."""
     from oracle import autodrive

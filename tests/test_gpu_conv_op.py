@@ -248,3 +248,27 @@ def test_map_kernel_matches_torch(cin, cout, h, w, act, res_mode, nsplit):
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1, tile=111, nsplit=nsplit))
     auto = lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1)     # the engine's own choice
     assert (np.abs(auto - ref) / np.maximum(1.0, np.abs(ref))).max() <= 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,res_mode,nsplit", [(1280, 768, 20, 40, 1, 0, -1), (768, 512, 40, 80, 1, 0, -1), (512, 512, 40, 80, 1, 0, 4), (96, 40, 40, 80, 0, 0, 3),
+                                                             (256, 64, 20, 40, 1, 2, 5), (48, 128, 20, 40, 0, 0, 4)])
+def test_map2_kernel_matches_torch_and_tile11(cin, cout, h, w, act, res_mode, nsplit):
+    """kernels_conv3x3_map.hip, halo tile 12 (round 5; the engine's choice for the neck's 20x40 / 40x80 layers in the parity mode): 64-channel weight slabs,
+    two M tiles per wave, single-buffered weights in two tap groups behind two barriers per step, pixel tile 24 split between waves 0 and 1.
+    decode_layer_0 / 2 / 3 at their real sizes, ragged channel counts, one-step K slices, the mul-add residual; against torch, run to run, and bit
+    for bit against tile 11 with the same K slices (same summation order)."""
+    from autoware_vision_pilot_amd import lib
+
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.standard_normal((cin, h, w), dtype=np.float32)
+    wt = rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal((cout,), dtype=np.float32) * np.float32(0.1)
+    res = rng.standard_normal((cout, h, w), dtype=np.float32) if res_mode else None
+    ref = _reference(x, wt, b, 3, 0, act, res, res_mode, fp16=False)
+    got = lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1, tile=112, nsplit=nsplit)
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= 2e-5, err.max()
+    for _ in range(3):
+        assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1, tile=112, nsplit=nsplit))
+    if nsplit > 0:
+        assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, res=res, res_mode=res_mode, precision=1, tile=111, nsplit=nsplit))

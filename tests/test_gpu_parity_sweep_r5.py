@@ -213,12 +213,23 @@ def test_autodrive_sweep(wseed):
             for i in range(len(frames) - 1):
                 with torch.no_grad():
                     ref = np.array([float(v) for v in autodrive.forward(sdt, xs[i], xs[i + 1])], dtype=np.float32)
-                eng.infer_pair(frames[i], frames[i + 1])
+                tag = f"weight seed {wseed} pair {i}" + (" (all-0 -> all-255)" if i == len(frames) - 2 else "")
+                try:
+                    eng.infer_pair(frames[i], frames[i + 1])
+                except lib.VpRangeError:
+                    # the RANGE GUARD (include/vp_hip.h): the saturated frame drives this seed's multiplicative CTX gates past the fp16 exponent range of the
+                    # planes; the engine says so (VP_ERR_RANGE) instead of returning garbage.  Only the degenerate pair may do that.
+                    ROWS.append(("autodrive", "fp8-stored" if fp8 else "fp32-weights", tag, float("nan"), float("nan"), 0, 0, 0.0,
+                                 f"RANGE GUARD raised (VP_ERR_RANGE): an activation left the fp16 range on the saturated frame; oracle (fp32) {ref.tolist()}"))
+                    if i != len(frames) - 2:
+                        fails.append(f"autodrive seed {wseed} fp8={fp8} pair {i}: range guard on an ordinary frame pair")
+                    continue
                 got = eng.logits().reshape(3)
                 err = float(np.abs(got - ref).max())
-                ROWS.append(("autodrive", "fp8-stored" if fp8 else "fp32-weights", f"weight seed {wseed} pair {i}", err, float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max()), 0, 0, 0.0,
+                rel = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())     # the bar of every float tensor: |error| <= 1e-3 x max(1, |ref|)
+                ROWS.append(("autodrive", "fp8-stored" if fp8 else "fp32-weights", tag, err, rel, 0, 0, 0.0,
                              f"(distance, curvature, flag) oracle {ref.tolist()} engine {got.tolist()}"))
-                if not err <= 1e-3:
+                if not rel <= 1e-3:
                     fails.append(f"autodrive seed {wseed} fp8={fp8} pair {i}: got {got}, oracle {ref}")
         finally:
             eng.close()
@@ -240,5 +251,5 @@ def test_parity_sweep_r5_report():
         net = [r for r in ROWS if r[0] != "autodrive" and r[0] != "three-head(concurrent)"]
         f.write(f"# {len(ROWS)} rows; network passes {len(net)}: {sum(r[6] for r in net)} class flips in total (every one at an oracle margin <= 2 x that pass's logit error), "
                 f"worst rel err {max([r[4] for r in net] or [0.0]):.3e}, {sum(1 for r in net if r[8])} judged against fp64; AutoDrive passes "
-                f"{sum(1 for r in ROWS if r[0] == 'autodrive')}: worst abs err {max([r[3] for r in ROWS if r[0] == 'autodrive'] or [0.0]):.3e}\n")
+                f"{sum(1 for r in ROWS if r[0] == 'autodrive')}: worst rel err {max([r[4] for r in ROWS if r[0] == 'autodrive' and r[4] == r[4]] or [0.0]):.3e}, {sum(1 for r in ROWS if r[0] == 'autodrive' and r[4] != r[4])} range-guard reports on the all-0 -> all-255 pair\n")
     print(f"parity sweep r5: {len(ROWS)} rows")
