@@ -158,10 +158,10 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
       ops_.push_back(std::move(op));
       return;
     }
-    if (ht >= 6 && ht <= 8) {
-      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 8 (pipelined kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles, fp16: input channels a multiple of 64; any epilogue with split-K (7 / 8): " + name);
+    if (ht >= 6 && ht <= 9) {
+      if (!conv3x3_x3_supported(p, ht)) throw std::invalid_argument("halo tiles 6 - 9 (pipelined kernels): conv + bias + {GELU, none}, NHWC, 128- (64-) channel tiles, fp16: input channels a multiple of 64; any epilogue with split-K (7 / 8): " + name);
       // fp16 engines ("x1"): the same schedule on 64-channel chunks, the chunk's two halves in the two LDS planes (kernels_conv3x3_x3.hip X1)
-      op.kernel = std::string(sp ? "conv3x3_x3" : "conv3x3_x1") + (ht == 6 ? "w8<co128,px256" : (ht == 7 ? "w4<co128,px128" : "w4<co64,px128")) + (sp ? ">" : ",k64>") + (pc.nsplit > 1 ? "+splitk" : "");
+      op.kernel = std::string(sp ? "conv3x3_x3" : "conv3x3_x1") + (ht == 6 ? "w8<co128,px256" : (ht == 7 ? "w4<co128,px128" : (ht == 8 ? "w4<co64,px128" : "w4<co64,px256"))) + (sp ? ">" : ",k64>") + (pc.nsplit > 1 ? "+splitk" : "");
       op.run = [p, ht](hipStream_t st) { return launch_conv3x3_x3(p, ht, st); };
       ops_.push_back(std::move(op));
       return;
@@ -328,7 +328,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
     if (fp8_storage() && o.tile < 0 && halo >= 0) halo = ncols <= 32 ? 4 : 3;
     if (halo == 11 && (fp8_storage() || (!split() && cin_pad % 32 != 0) || !conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
       throw std::invalid_argument("halo tile 11 (map kernel): maps that tile into 20x40 or 10x20 regions, >= 32 input channels (a multiple of 32 in the fp16 engines): " + name);
-    if (halo >= 6 && halo <= 8 && !split() && cin_pad % 64 != 0) throw std::invalid_argument("halo tiles 6 - 8 in the fp16 engines: input channels a multiple of 64: " + name);
+    if (halo >= 6 && halo <= 9 && !split() && cin_pad % 64 != 0) throw std::invalid_argument("halo tiles 6 - 9 in the fp16 engines: input channels a multiple of 64: " + name);
   }
   if (halo >= 0) {
     pc.tile = 100 + halo;
@@ -415,6 +415,14 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         pc.tile = 108;
       }
     }
+    // round 5: 64-channel tiles of the parity mode on 16x16 pixels with the four waves side by side (halo tile 9: every wave 64 channels x 64 pixels, 8
+    // fragment reads per 12 MFMAs instead of 6 per 6) -- the 64-channel-output layers without split-K (decode_layer_5, decode_layer_9 of SceneSeg / DomainSeg).
+    // VP_X3_T16=0 (developer knob, A/B timing): tiles 3 / 8 as before.
+    if ((halo == 3 || halo == 8) && split() && o.tile < 0 && pc.nsplit == 1 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 && cstride == 1 &&
+        (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !dev_option_is("VP_X3_T16", '0') && M >= 12800) {
+      halo = 9;
+      pc.tile = 109;
+    }
     }
   } else {
     ConvOpts og = o;
@@ -426,7 +434,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
   // de-quantised fp16 planes
   const bool w8 = fp8_storage() && ((halo < 0 && pc.tile == 2) || halo == 3 || halo == 4);
   // fp16 engines on the pipelined kernels (halo tiles 6 - 8 without the lo plane): 64-channel chunks, the chunk's halves in two plane arrays
-  const bool k64 = halo >= 6 && halo <= 8 && !split();
+  const bool k64 = halo >= 6 && halo <= 9 && !split();
   const bool k32map = halo == 11 && !split();   // map kernel in the fp16 engines: 32-channel steps, the step's halves in the two plane arrays
   std::vector<half_t> hi(w8 ? 0 : (size_t)taps * pc.CoutW * cin_pad / ((k64 || k32map) ? 2 : 1), (half_t)0.0f), lo(((split() || k64 || k32map) && !w8) ? hi.size() : 0, (half_t)0.0f);
   std::vector<uint8_t> codes(w8 ? (size_t)taps * pc.CoutW * cin_pad : 0, (uint8_t)0);
@@ -446,7 +454,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // generic kernel: [tap][CoutW][Cin] ; halo kernel: [cin/32][tap][CoutW][32] (contiguous per-tap tiles)
         // halo tiles 6 / 7 (kernels_conv3x3_x3.hip) copy weight tiles to LDS by LDS-DMA, a LINEAR copy: the tile is stored
         // in its LDS image order, i.e. with the 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-        const int ci_sw = (halo >= 6 && halo <= 8) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
+        const int ci_sw = (halo >= 6 && halo <= 9) ? ((((ci & 31) >> 3) ^ ((co >> 2) & 3)) << 3 | (ci & 7)) : (ci & 31);
         const size_t d = k32map ? conv3x3_map_pack_index_k32(co, ci, t, cin_pad)
                          : halo == 12 ? conv3x3_map2_pack_index(co, ci, t, cin_pad)
                          : halo == 11 ? conv3x3_map_pack_index(co, ci, t, cin_pad)

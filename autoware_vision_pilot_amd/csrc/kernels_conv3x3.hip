@@ -299,7 +299,7 @@ static hipError_t launch_halo_cfg(const ConvGemmParams& p, hipStream_t st) {
 hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hipStream_t st) {
 #define VP_HCASE(T, CO, TH, TW, WCO, WPX) \
   if (tile == T) return split ? launch_halo_cfg<CO, TH, TW, WCO, WPX, true>(p, st) : launch_halo_cfg<CO, TH, TW, WCO, WPX, false>(p, st);
-  if (tile >= 6 && tile <= 8) return launch_conv3x3_x3(p, tile, st);  // pipelined kernels (kernels_conv3x3_x3.hip): fp16x3, or fp16 on 64-channel chunks (its own weight layout)
+  if (tile >= 6 && tile <= 9) return launch_conv3x3_x3(p, tile, st);  // pipelined kernels (kernels_conv3x3_x3.hip): fp16x3, or fp16 on 64-channel chunks (its own weight layout)
   if (tile == 3 && !split) return launch_halo_cfg<64, 8, 16, 1, 4, false>(p, st);
   VP_HCASE(1, 128, 8, 16, 2, 2)
   VP_HCASE(3, 64, 8, 16, 2, 2)
@@ -312,8 +312,8 @@ hipError_t launch_conv3x3_halo(const ConvGemmParams& p, int tile, bool split, hi
   if (tile == 2) return split ? hipErrorInvalidValue : launch_halo_cfg<64, 16, 16, 1, 4, false>(p, st);
   return hipErrorInvalidValue;
 }
-int halo_tile_co(int tile) { return (tile <= 1 || tile == 6 || tile == 7) ? 128 : ((tile <= 3 || tile == 8 || tile == 12) ? 64 : 32); }
-int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 256 : 128; }
-int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6) ? 16 : 8; }
+int halo_tile_co(int tile) { return (tile <= 1 || tile == 6 || tile == 7) ? 128 : ((tile <= 3 || tile == 8 || tile == 9 || tile == 12) ? 64 : 32); }
+int halo_tile_px(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6 || tile == 9) ? 256 : 128; }
+int halo_tile_th(int tile) { return (tile == 0 || tile == 2 || tile == 5 || tile == 6 || tile == 9) ? 16 : 8; }
 
 }  // namespace vp

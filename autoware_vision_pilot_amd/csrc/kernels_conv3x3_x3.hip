@@ -33,6 +33,10 @@
 //             wave of each per SIMD -- they drift out of phase, so one workgroup's prologue / chunk hand-over / epilogue
 //             (exact GELU + split: ~1000 VALU instructions per wave, 64 KiB of stores) runs under the other's MFMAs.
 //   8 "x3w4c64": shape 7 on 64-channel tiles (53 KB, three workgroups per CU).
+//   9 "x3w4c64t16" (round 5): 16x16 pixels x 64 channels, 4 waves SIDE BY SIDE along the pixels (WCO = 1): every wave owns all 64 channels x 64 pixels
+//             = 2 x 2 MFMA tiles, 8 fragment reads per 12 MFMAs like shape 6 (shape 8's waves own 32 channels x 64 pixels: 6 reads per 6 MFMAs -- as
+//             LDS-bound as the halo kernel's 64-channel tile, profiles/r04: decode_layer_5 / decode_layer_9 at 0.11 of peak); halo single-buffered
+//             (six pieces per thread wait in registers), 76 416 B: two independent workgroups per CU.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -65,7 +69,7 @@ namespace vp {
 // 64c + 64) of the one fp16 tensor (weights packed likewise by the engine: w_hi / w_lo carry the two halves).  Same LDS plan, same DMA and
 // halo traffic per step, two MFMAs per fragment pair instead of three -- two thirds of the parity kernel's matrix work per barrier.
 template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, int ABL = 0, bool SPLITK = false, bool X1 = false>
-__global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2) void conv3x3_x3_kernel(const ConvGemmParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
   constexpr int HALO_BYTES = HPX * ROWB, WROW = 64, W_BYTES = CO_TILE * WROW;
@@ -75,7 +79,8 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   constexpr int PL = 2;                // planes per tensor: (hi, lo)
   constexpr int HSTRIDE = HALO_BYTES;  // plane stride in LDS
   constexpr int LT = 0;                // HDB: tap at which the next chunk's halo pieces are loaded (stored at the start of tap 3)
-  static_assert(MT >= 1 && NT >= 1 && HP <= 3, "tile shape");
+  constexpr int RING = HP > 3 ? HP : 3;   // halo staging ring (registers): one slot per piece a thread moves (shape 9: six)
+  static_assert(MT >= 1 && NT >= 1 && HP <= 6 && (HP <= 3 || !HDB), "tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo_base = smem;                               // [NHB][2 planes][HALO_BYTES]
   char* const w_base = smem + NHB * PL * HSTRIDE;             // [3][PL planes][W_BYTES]
@@ -156,9 +161,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
   // fragment sets [K sub-step parity]: set 0 = channels 0..15 of the tap's 32, set 1 = channels 16..31
   h8_t fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
   // halo staging ring (compile-time slots): piece pc in slot pc
-  u32x4 rh_hi[3], rh_lo[3];
+  u32x4 rh_hi[RING], rh_lo[RING];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) rh_hi[r] = rh_lo[r] = zero4;
+  for (int r = 0; r < RING; ++r) rh_hi[r] = rh_lo[r] = zero4;
   const int s_last = KC * 9 - 1;
 
   // weight tile SIDX (clamped to the last one: the tail requests are harmless re-reads) -> LDS buffer BUF, asynchronously
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
       _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_LOAD_H(pc, pc, next_chunk ? c + 1 : c) \
     }                                                                                        \
     if constexpr (!HDB && (T) < HP && !(ABL & 1) && !(ABL & 64)) {                           \
-      if (next_chunk) VP_LOAD_H((T) % 3, (T) < HP ? (T) : 0, c + 1)                          \
+      if (next_chunk) VP_LOAD_H((T) % RING, (T) < HP ? (T) : 0, c + 1)                       \
     }                                                                                        \
     VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
     /* round 4 (ISA): keep these MFMAs IN FRONT of the barrier's lgkmcnt(0) -- the scheduler moved five of the six behind it, so set 1's */ \
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, CO_TILE == 64 ? 3 : 2) void conv3x3
 // The layers whose 128-channel tiles are too few (64-channel outputs, small maps with split-K): same workgroup count and split
 // factor as the halo kernel's 64-channel tile (halo tile 3), the pipelined schedule instead of its lone-wave one.
 bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
-  const int co_tile = shape == 8 ? 64 : 128;
+  const int co_tile = (shape == 8 || shape == 9) ? 64 : 128;
   const bool x1 = p.in_lo == nullptr;  // VP_FP16 engines: the two planes are the halves of a 64-channel chunk (template parameter X1)
   if (!(p.ks == 3 && p.stride <= 1 && p.in_hi && p.w_hi && p.w_lo && p.CoutW % co_tile == 0 && p.Cin % (x1 ? 64 : 32) == 0 && p.Cin2 == 0 && p.nsplit >= 1)) return false;
   const bool act_ok = x1 ? (p.act == ACT_GELU_F16 || p.act == ACT_NONE) : (p.act == ACT_GELU || p.act == ACT_NONE);
@@ -432,18 +437,18 @@ bool conv3x3_x3_supported(const ConvGemmParams& p, int shape) {
   return plain;
 }
 
-template <int CO, int TH, int WPX, bool HDB, bool X1>
+template <int CO, int TH, int WPX, bool HDB, bool X1, int WCO = 2>
 static hipError_t launch_x3_cfg(const ConvGemmParams& p, hipStream_t st) {
   constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (CO * 64);
   static_assert(lds <= 160 * 1024, "LDS budget");
   constexpr int GELU = X1 ? ACT_GELU_F16 : ACT_GELU;
   const bool gelu = p.act == GELU, sk = p.nsplit > 1;
-  auto k = sk ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, 0, true, X1>
-              : (gelu ? conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, GELU, 0, false, X1> : conv3x3_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, 0, false, X1>);
+  auto k = sk ? conv3x3_x3_kernel<CO, TH, WCO, WPX, HDB, ACT_NONE, 0, true, X1>
+              : (gelu ? conv3x3_x3_kernel<CO, TH, WCO, WPX, HDB, GELU, 0, false, X1> : conv3x3_x3_kernel<CO, TH, WCO, WPX, HDB, ACT_NONE, 0, false, X1>);
   static LdsAttrOnce attr_once[3];
   if (hipError_t e = set_max_dynamic_lds(attr_once[sk ? 2 : gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * (p.CoutW / CO) * p.nsplit);
-  hipLaunchKernelGGL(k, grid, dim3(128 * WPX), lds, st, p);
+  hipLaunchKernelGGL(k, grid, dim3(64 * WCO * WPX), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return sk ? launch_splitk_finish(p, st) : hipSuccess;
@@ -457,11 +462,13 @@ hipError_t launch_conv3x3_x3(const ConvGemmParams& p, int shape, hipStream_t st)
     if (shape == 6) return launch_x3_cfg<128, 16, 4, true, true>(p, st);
     if (shape == 7) return launch_x3_cfg<128, 8, 2, false, true>(p, st);
     if (shape == 8) return launch_x3_cfg<64, 8, 2, false, true>(p, st);
+    if (shape == 9) return launch_x3_cfg<64, 16, 4, false, true, 1>(p, st);
     return hipErrorInvalidValue;
   }
   if (shape == 6) return launch_x3_cfg<128, 16, 4, true, false>(p, st);
   if (shape == 7) return launch_x3_cfg<128, 8, 2, false, false>(p, st);
   if (shape == 8) return launch_x3_cfg<64, 8, 2, false, false>(p, st);
+  if (shape == 9) return launch_x3_cfg<64, 16, 4, false, false, 1>(p, st);
   return hipErrorInvalidValue;
 }
 

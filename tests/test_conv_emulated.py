@@ -94,6 +94,12 @@ def test_x3w8_kernel(emu_lib):
     assert np.array_equal(a, c)
     assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=107, nsplit=1), c)
     assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=108, nsplit=1), c)      # 64-channel shape: same K order too
+    assert np.array_equal(emu_lib.op_conv2d(x, wt, b, ks=3, act=1, precision=1, tile=109, nsplit=1), c)      # round 5: 64 channels x 16x16 pixels, waves side by side
+    # halo tile 9 (round 5): four waves side by side along the pixels (WCO = 1), each 64 channels x 64 pixels; six halo pieces per thread wait in registers
+    # across the chunk hand-over; one and several chunks, ragged maps, GELU / none, split-K slices, and the fp16 engines' 64-channel chunks
+    _case(emu_lib, 32, 64, 16, 32, 3, 0, 1, 0, 1, [(109, -1, 1)], seed=91)
+    _case(emu_lib, 96, 128, 19, 21, 3, 0, 0, 0, 1, [(109, -1, 1), (109, -1, 2)], seed=92)
+    _case(emu_lib, 128, 64, 35, 17, 3, 0, 1, 0, 0, [(109, -1, 1)], seed=93)
     # split-K slices of the 4-wave shape (fp32 partials + finish kernel), incl. a mul-add residual (context_layer_6's epilogue)
     _case(emu_lib, 160, 128, 10, 20, 3, 0, 1, 0, 1, [(107, -1, 2), (107, -1, 5)], seed=24)
     _case(emu_lib, 96, 256, 12, 18, 3, 0, 1, 2, 1, [(107, -1, 3), (108, -1, 3)], seed=25)

@@ -96,6 +96,7 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=101, nsplit=1))
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=1))   # 4-wave shape, single halo buffer
     assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=108, nsplit=1))   # 64-channel shape, three workgroups per CU
+    assert np.array_equal(got, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=109, nsplit=1))   # round 5: 64 channels x 16x16 pixels, waves side by side
     for ns in (2, 3):                                                                                      # split-K slices + finish kernel
         if cin >= 32 * ns:
             sk = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=107, nsplit=ns)
@@ -103,7 +104,7 @@ def test_x3w8_kernel_matches_torch_and_halo_tile(cin, cout, h, w, act):
             assert np.array_equal(sk, lib.op_conv2d(x, wt, b, ks=3, act=act, precision=1, tile=108, nsplit=ns))   # same slices, same finish kernel
     # VP_FP16 engines: the same shapes on 64-channel chunks (X1: the chunk's halves in the two LDS planes); other channel counts are refused
     ref16 = _reference(x, wt, b, 3, 0, act, None, 0, fp16=True)
-    for tile in (106, 107, 108):
+    for tile in (106, 107, 108, 109):
         if ((cin + 31) // 32 * 32) % 64 == 0:
             g16 = lib.op_conv2d(x, wt, b, ks=3, act=act, precision=0, tile=tile, nsplit=1)
             assert (np.abs(g16 - ref16) / np.maximum(1.0, np.abs(ref16))).max() <= 1.5e-3, tile
