@@ -154,6 +154,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     if (ht == 12) {
       if (!conv3x3_map2_supported(p)) throw std::invalid_argument("halo tile 12 (map kernel, 64-channel slabs): parity mode, 3x3 stride 1, 20x40 regions, output channels padded to 64: " + name);
       op.kernel = "conv3x3_map2<co64,px800,x3>+splitk";
+      op.launch += " wgs=" + std::to_string((p.H / 20) * (p.W / 40) * (p.CoutW / 64) * p.nsplit);
       op.run = [p](hipStream_t st) { return launch_conv3x3_map2(p, st); };
       ops_.push_back(std::move(op));
       return;
@@ -340,7 +341,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       if (const char* e = dev_option("VP_MAP2_SLOTS")) slots = std::max(1, std::atoi(e));   // developer knob: workgroups a layer aims at
       int ns = o.nsplit > 0 ? o.nsplit : std::max(1, slots / (regions * n_co));
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
-      while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > 26.0) --ns;
+      double cap_mb = 26.0;
+      if (const char* e = dev_option("VP_MAP2_CAP_MB")) cap_mb = std::atof(e);   // developer knob: ceiling of the fp32 slabs a layer may write
+      while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > cap_mb) --ns;
       pc.bk = 16;
       pc.nsplit = std::max(1, std::min(ns, std::max(1, KS / 2)));
     } else if (halo == 11) {  // map kernel: K slices until ~one round of workgroups (one per CU at 20x40 regions, two at 10x20), fp32 slabs <= 24 MB
@@ -416,10 +419,12 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       }
     }
     // round 5: 64-channel tiles of the parity mode on 16x16 pixels with the four waves side by side (halo tile 9: every wave 64 channels x 64 pixels, 8
-    // fragment reads per 12 MFMAs instead of 6 per 6) -- the 64-channel-output layers without split-K (decode_layer_5, decode_layer_9 of SceneSeg / DomainSeg).
-    // VP_X3_T16=0 (developer knob, A/B timing): tiles 3 / 8 as before.
+    // fragment reads per 12 MFMAs instead of 6 per 6).  Built for the 64-channel-output layers without split-K on VERDICT round 4's reading that they are
+    // fragment-read-bound; MEASURED SLOWER (profiles/r05_x3_t16_ab.txt): decode_layer_5 99.2 -> 135.1 us (200 workgroups of four waves = one wave per
+    // SIMD on 200 CUs), decode_layer_9 103.9 -> 110.6 us (800 tiles on 512 slots: two rounds), frames/s level (412.8 against 412.7).  Kept as a shape
+    // (tile 109, tests), selected only by VP_X3_T16=1.
     if ((halo == 3 || halo == 8) && split() && o.tile < 0 && pc.nsplit == 1 && cin_pad % 32 == 0 && !o.logits_out && !o.in2 && cstride == 1 &&
-        (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE && !dev_option_is("VP_X3_T16", '0') && M >= 12800) {
+        (o.act == ACT_GELU || o.act == ACT_NONE) && o.res_mode == RES_NONE && o.post_act == ACT_NONE && dev_option_is("VP_X3_T16", '1') && M >= 12800) {
       halo = 9;
       pc.tile = 109;
     }
