@@ -718,6 +718,10 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
   const float* x = nullptr;
   int K = cctx;
   const int widths[3] = {800, 800, 200};
+  // round 5: context_layer_2 (the matvec that builds the 10x20 map) and context_layer_3 (the 3x3 convolution that reads it) in ONE launch
+  // (kernels_misc.hip ctx_exp_conv1_kernel); VP_CTX_FUSE=0 (developer knob, A/B timing): two launches as before
+  const bool fuse23 = !dev_option_is("VP_CTX_FUSE", '0') && widths[2] == HW;
+  FcParams fp2{};
   for (int i = 0; i < 3; ++i) {
     const std::string lp = p + "context_layer_" + std::to_string(i);
     const HostTensor& w = blob.get(lp + ".weight");
@@ -736,6 +740,10 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
       fp.nslab = nslab;
       fp.Kstride = deep->C;
       fp.inv_hw = 1.0f / (float)HW;
+    }
+    if (i == 2 && fuse23) {
+      fp2 = fp;
+      break;
     }
     Op op;
     op.name = lp;
@@ -764,9 +772,28 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
     cp.b = dupload(bk);
     cp.out = c->view();
     Op op;
-    op.name = p + "context_layer_3";
     op.flops = 2.0 * 9 * 128 * HW;
-    op.run = [cp](hipStream_t st) { return launch_ctx_conv1(cp, st); };
+    CtxExpConv1Params q{fp2, cp, 8, 64};   // 8x8 patches: six workgroups on the 10x20 map; 800-element rows: a wave per row
+    if (fuse23 && ctx_exp_conv1_ok(q)) {
+      op.name = p + "context_layer_2+3";
+      op.kernel = "ctx_exp_conv1<t8>";
+      op.flops += 2.0 * fp2.N * fp2.K;
+      op.bytes = (fp2.w8 ? 1.0 : 4.0) * fp2.N * fp2.K;
+      op.run = [q](hipStream_t st) { return launch_ctx_exp_conv1(q, st); };
+    } else {
+      if (fuse23) {   // the shape does not fit the fused kernel: the matvec on its own after all
+        Op o2;
+        o2.name = p + "context_layer_2";
+        o2.flops = 2.0 * fp2.N * fp2.K;
+        o2.bytes = (fp2.w8 ? 1.0 : 4.0) * fp2.N * fp2.K;
+        const FcParams fpc = fp2;
+        o2.run = [fpc](hipStream_t st) { return launch_fc(fpc, st); };
+        ops_.push_back(std::move(o2));
+        cp.map = fp2.out;
+      }
+      op.name = p + "context_layer_3";
+      op.run = [cp](hipStream_t st) { return launch_ctx_conv1(cp, st); };
+    }
     ops_.push_back(std::move(op));
   }
   const int couts[3] = {256, 512, cctx};
@@ -941,6 +968,7 @@ void Engine::build_model(const WeightBlob& blob) {
 // C2PSA, PSABlock, Attention).  One plan: preprocess -> backbone (P5 256x16x32) -> [shift: previous frame's P5 to the
 // first half of the 512-channel head input] -> [place: this frame's P5 to the second half] -> head -> 3 scalars.
 void Engine::build_autodrive(const WeightBlob& blob) {
+  Act* head_cat = nullptr;
   auto T = [&](const std::string& k) -> const HostTensor& { return blob.get(k); };
   auto push = [&](const std::string& name, const char* kernel, std::function<hipError_t(hipStream_t)> fn, double flops = 0, double bytes = 0) {
     Op op;
@@ -1042,7 +1070,6 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     fp.Kstride = a->C;
     fp.inv_hw = 1.0f / (float)HW;
     fp.rows_kernel = fc_rows_ok(fp) ? 1 : 0;   // p2 / p3: 32768 x 32 and 8192 x 64 -- a thread per row
-    push(cp + ".exp0", fp.rows_kernel ? "fc<rows>" : "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, (fp.w8 ? 1.0 : 4.0) * HW * C);
     // ctx0: conv3x3 1 -> C/2 + SiLU (:216-217)
     const HostTensor& w0 = T(cp + ".ctx0.weight");
     const HostTensor& b0 = T(cp + ".ctx0.bias");
@@ -1062,7 +1089,17 @@ void Engine::build_autodrive(const WeightBlob& blob) {
       cpp.b = dupload(bk);
       cpp.out = c2->view();
       cpp.act = ACT_SILU;
-      push(cp + ".ctx0", "ctx_conv1", [cpp](hipStream_t st) { return launch_ctx_conv1(cpp, st); }, 2.0 * 9 * c0n * HW);
+      // round 5: exp0 (the matvec that builds the H x W map) and ctx0 (the convolution that reads it) in ONE launch (kernels_misc.hip
+      // ctx_exp_conv1_kernel): 16x16 patches on the large maps, 8x8 from 2048 pixels down; lanes per row by the row length (32 / 64 / 128 / 256 channels).
+      // VP_CTX_FUSE=0 (developer knob, A/B timing): two launches as before
+      CtxExpConv1Params q{fp, cpp, HW > 2048 ? 16 : 8, a->C <= 64 ? 1 : (a->C <= 128 ? 4 : 16)};
+      if (!dev_option_is("VP_CTX_FUSE", '0') && ctx_exp_conv1_ok(q)) {
+        push(cp + ".exp0+ctx0", q.tile == 16 ? "ctx_exp_conv1<t16>" : "ctx_exp_conv1<t8>", [q](hipStream_t st) { return launch_ctx_exp_conv1(q, st); },
+             2.0 * HW * C + 2.0 * 9 * c0n * HW, (fp.w8 ? 1.0 : 4.0) * HW * C);
+      } else {
+        push(cp + ".exp0", fp.rows_kernel ? "fc<rows>" : "fc", [fp](hipStream_t st) { return launch_fc(fp, st); }, 2.0 * HW * C, (fp.w8 ? 1.0 : 4.0) * HW * C);
+        push(cp + ".ctx0", "ctx_conv1", [cpp](hipStream_t st) { return launch_ctx_conv1(cpp, st); }, 2.0 * 9 * c0n * HW);
+      }
     }
     // ctx1: conv3x3 C/2 -> C + SiLU, gate: c4*x + x, SiLU (:218-224)
     ConvOpts o1;
@@ -1157,18 +1194,35 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     }
     const ActView y2v = y2->view();
     push(cp + ".cat", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(y2v, 0, tv, c_, c_, st); });  // cat((a, y), 1) in place
-    x = conv_bn(cp + ".cv2", t, 1, 1, ACT_SILU);
+    // ---- head input (autodrive_head.py:70-87): cat([prev, curr]).  Round 5: cv2 -- the backbone's last convolution -- stores this frame's P5 STRAIGHT into
+    // the second half of the 512-channel tensor (an alias view with the tensor's row pitch: the epilogues store at pixel * Cstore + channel), so the
+    // "place" copy launch is gone; the previous frame's features move to the first half right BEFORE it ("shift": the only copy a streaming pair needs).
+    Folded f2 = fold_conv_norm(blob, cp + ".cv2");
+    const int c5 = f2.cout;
+    if (c5 % 32 != 0) throw std::runtime_error("backbone.p5.3.cv2: output channels must be a multiple of 32");
+    head_cat = new_act("head.cat", 2 * c5, t->H, t->W);
+    {
+      const ActView cv = head_cat->view();
+      ad_shift_op_ = ops_.size();
+      push("head.shift_prev", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(cv, c5, cv, 0, c5, st); });
+    }
+    auto slice = std::make_unique<Act>();
+    slice->name = cp + ".cv2";
+    slice->Creal = c5;
+    slice->C = head_cat->C;            // row pitch of the tensor it lives in
+    slice->H = head_cat->H;
+    slice->W = head_cat->W;
+    slice->hi = head_cat->hi + c5;
+    slice->lo = head_cat->lo ? head_cat->lo + c5 : nullptr;
+    acts_.push_back(std::move(slice));
+    ConvOpts o2;
+    o2.act = ACT_SILU;
+    ad_place_op_ = ops_.size();        // prime_previous() runs the plan up to and including this launch (minus the shift)
+    x = add_conv(cp + ".cv2", t, f2.w, f2.b, f2.cout, 1, o2, acts_.back().get());
+    if (ops_.size() != ad_place_op_ + 1) throw std::runtime_error("backbone.p5.3.cv2: expected ONE launch (no split-K finish) in front of the head");
   }
-  // ---- head (autodrive_head.py:70-87): cat([prev, curr]) -> 3 x (conv3x3 + SiLU) -> flatten (C-major) -> MLP
-  const int c5 = x->Creal;
-  Act* cat = new_act("head.cat", 2 * c5, x->H, x->W);
-  {
-    const ActView cv = cat->view(), xv = x->view();
-    ad_shift_op_ = ops_.size();
-    push("head.shift_prev", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(cv, c5, cv, 0, c5, st); });
-    ad_place_op_ = ops_.size();
-    push("head.place_curr", "chan_copy", [=](hipStream_t st) { return launch_chan_copy(xv, 0, cv, c5, c5, st); });
-  }
+  // ---- head: 3 x (conv3x3 + SiLU) -> flatten (C-major) -> MLP
+  Act* cat = head_cat;
   ConvOpts so;
   so.act = ACT_SILU;
   Act* h1 = add_conv("head.conv_1", cat, T("head.conv_1.weight").data, T("head.conv_1.bias").data, T("head.conv_1.weight").shape[0], 3, so);

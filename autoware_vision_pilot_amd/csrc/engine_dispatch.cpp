@@ -317,8 +317,10 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         halo = 11;
       // round 5: 64-channel slabs (two M tiles per wave, kernels_conv3x3_map.hip "map2") where the geometry is the neck's and the output channels pad to 64
       // without waste: parity mode only.  VP_MAP2=0 (developer knob, A/B timing): tile 11 everywhere.
+      int min_regions = 1;
+      if (const char* e = dev_option("VP_MAP2_MIN_REGIONS")) min_regions = std::atoi(e);   // developer knob: 4 = the 40x80 maps only
       if (halo == 11 && o.tile < 0 && split() && geom == 1 && !dev_option_is("VP_MAP2", '0') && round_up(ncols, 64) == round_up(ncols, 32) &&
-          conv3x3_map2_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 64)))
+          (in->H / 20) * (in->W / 40) >= min_regions && conv3x3_map2_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 64)))
         halo = 12;
     }
     if (o.tile == 112) halo = 12;
@@ -341,7 +343,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       if (const char* e = dev_option("VP_MAP2_SLOTS")) slots = std::max(1, std::atoi(e));   // developer knob: workgroups a layer aims at
       int ns = o.nsplit > 0 ? o.nsplit : std::max(1, slots / (regions * n_co));
       const double slice_mb = (double)M * pc.CoutW * 4.0 / 1e6;
-      double cap_mb = 26.0;
+      double cap_mb = 27.0;   // 40x80 maps: four K slices (26.2 MB of slabs) -- measured 124 -> 103 / 91 -> 76 us per layer and +1.1 % frames/s against three (gpurun r5c04)
       if (const char* e = dev_option("VP_MAP2_CAP_MB")) cap_mb = std::atof(e);   // developer knob: ceiling of the fp32 slabs a layer may write
       while (o.nsplit <= 0 && ns > 2 && ns * slice_mb > cap_mb) --ns;
       pc.bk = 16;

@@ -186,6 +186,19 @@ struct CtxConv1Params {
   int act;           // ACT_GELU (scene_context.py:46-47) or ACT_SILU (CTX.ctx0, common_layers.py:216-217)
 };
 
+// Round 5: the matvec that BUILDS the one-channel map and the 3x3 convolution that reads it, in one launch (ctx_exp_conv1_kernel):
+//   scene networks: context_layer_2 (Linear 800 -> 200 + sigmoid, reshaped 10x20: scene_context.py:36-43) + context_layer_3 (conv 1 -> 128 + GELU, :46-47);
+//   AutoDrive CTX : exp0 (C -> H*W, SiLU twice: common_layers.py:210-213) + ctx0 (conv 1 -> C/2 + SiLU, :216-217).
+// fc.out is unused (the map never leaves LDS); fc.partial / nslab as for launch_fc; cv.map is unused.
+struct CtxExpConv1Params {
+  FcParams fc;
+  CtxConv1Params cv;
+  int tile;     // square pixel patch per workgroup: 16 or 8
+  int glanes;   // lanes that share one row of the matvec: 1, 4, 16 or 64
+};
+bool ctx_exp_conv1_ok(const CtxExpConv1Params& p);
+hipError_t launch_ctx_exp_conv1(const CtxExpConv1Params& p, hipStream_t st);
+
 struct FusionParams {
   ActView f[5];
   int creal[5];   // 32,24,40,80,1280

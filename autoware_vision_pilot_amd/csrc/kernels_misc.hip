@@ -104,6 +104,89 @@ __global__ __launch_bounds__(256) void ctx_conv1_kernel(const CtxConv1Params p) 
   store8(p.out, (size_t)pix * p.out.C + cg * 8, acc);
 }
 
+// Round 5: the matvec that builds the one-channel H x W map (scene networks: context_layer_2 + sigmoid; AutoDrive CTX: exp0 + SiLU twice) FUSED with
+// the 3x3 convolution 1 -> C that reads it (context_layer_3 / ctx0): the map was a launch boundary and 0.8 - 131 KB through HBM for a tensor a
+// workgroup can rebuild where it needs it.  A workgroup owns a T x T pixel patch: (1) x -- the previous layer's vector, or the average pool rebuilt
+// from slab partials in their fixed order -- goes to LDS; (2) the (T + 2)^2 map values under the patch: row n of the matrix against x, G lanes per
+// row (each a strided quarter-vector walk, then an xor-shuffle tree: a fixed order), bias, activation, zero outside the map (the convolution pads the
+// MAP); (3) the nine taps per (pixel, channel octet), ctx_conv1_kernel's arithmetic term for term.  Neighbouring workgroups recompute the halo rows
+// (1.27x at T = 16, 1.56x at T = 8: a few thousand multiply-adds).
+template <int T>
+__global__ __launch_bounds__(256) void ctx_exp_conv1_kernel(const CtxExpConv1Params q) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const FcParams& p = q.fc;
+  const CtxConv1Params& c = q.cv;
+  constexpr int HT = T + 2;
+  float* const xs = smem_f;                       // [K]
+  float* const mp = smem_f + ((p.K + 3) & ~3);    // [HT][HT]
+  for (int k = threadIdx.x; k < p.K; k += 256) {
+    float xv;
+    if (p.partial) {
+      xv = 0.f;
+#pragma unroll 8
+      for (int s = 0; s < p.nslab; ++s) xv += p.partial[(size_t)s * p.Kstride + k];
+      xv *= p.inv_hw;
+    } else {
+      xv = p.x[k];
+    }
+    xs[k] = xv;
+  }
+  __syncthreads();
+  const int tiles_x = (c.W + T - 1) / T;
+  const int y0 = (blockIdx.x / tiles_x) * T, x0 = (blockIdx.x % tiles_x) * T;
+  const int G = q.glanes, rows_per_pass = 256 / G;
+  const int g = threadIdx.x / G, l = threadIdx.x % G;
+  const f32x4_t* x4 = reinterpret_cast<const f32x4_t*>(xs);
+  const int K4 = p.K >> 2;
+  for (int r0 = 0; r0 < HT * HT; r0 += rows_per_pass) {   // uniform trip count: every lane takes part in the shuffle tree of every pass
+    const int r = r0 + g;
+    const bool live = r < HT * HT;
+    const int hy = r / HT, hx = r - hy * HT;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool inside = live && (unsigned)iy < (unsigned)c.H && (unsigned)ix < (unsigned)c.W;
+    const int n = inside ? iy * c.W + ix : 0;
+    float s = 0.f;
+    if (p.w8) {
+      const unsigned* wr8 = reinterpret_cast<const unsigned*>(p.w8 + (size_t)n * p.K);
+      for (int k = l; k < K4; k += G) {
+        const unsigned c4 = wr8[k];
+        const f32x4_t m = x4[k];
+        s += (e4m3_to_float(c4 & 0xffu) * m[0] + e4m3_to_float((c4 >> 8) & 0xffu) * m[1]) + (e4m3_to_float((c4 >> 16) & 0xffu) * m[2] + e4m3_to_float(c4 >> 24) * m[3]);
+      }
+    } else {
+      const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w + (size_t)n * p.K);
+      for (int k = l; k < K4; k += G) {
+        const f32x4_t a = wr[k], m = x4[k];
+        s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
+      }
+    }
+    for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (l == 0 && live) mp[r] = inside ? apply_act((p.w8 ? s * p.wscale8[n] : s) + p.b[n], p.act) : 0.f;
+  }
+  __syncthreads();
+  const int CG = c.out.C >> 3;
+  for (int t = threadIdx.x; t < T * T * CG; t += 256) {
+    const int cg = t % CG, lp = t / CG;
+    const int ly = lp / T, lx = lp - ly * T;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= c.H || x >= c.W) continue;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = c.b[cg * 8 + i];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float v = mp[(ly + ky) * HT + lx + kx];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(v, c.w[(ky * 3 + kx) * c.out.C + cg * 8 + i], acc[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = c.act == ACT_GELU ? gelu_exact(acc[i]) : apply_act(acc[i], c.act);
+    store8(c.out, (size_t)(y * c.W + x) * c.out.C + cg * 8, acc);
+  }
+}
+
 // --------------------------------------------------------------------------------- EgoLanes feature fusion
 // MaxPool2x2 applied n times == max over a 2^n x 2^n window; concat along C (backbone_feature_fusion.py:13-38).
 // One thread per output element, walking its window two bytes at a time: the fallback for channel counts that are not octet multiples
@@ -372,6 +455,22 @@ hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st) {
   hipLaunchKernelGGL(pil_resample_h_kernel, dim3(nblk(p.out_w), p.in_h), dim3(256), 0, st, p);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   VP_LAUNCH(pil_resample_v_kernel, dim3(nblk(p.out_w), p.out_h), dim3(256), 0, st, p);
+}
+bool ctx_exp_conv1_ok(const CtxExpConv1Params& q) {
+  const FcParams& p = q.fc;
+  const bool g_ok = q.glanes == 1 || q.glanes == 4 || q.glanes == 16 || q.glanes == 64;
+  return (q.tile == 8 || q.tile == 16) && g_ok && p.K >= 4 && (p.K & 3) == 0 && p.N == q.cv.H * q.cv.W && (p.w != nullptr) != (p.w8 != nullptr) && p.b && q.cv.w && q.cv.b &&
+         (q.cv.out.C & 7) == 0 && p.act_rows == 0 && (p.partial != nullptr || p.x != nullptr) && (size_t)(((p.K + 3) & ~3) + (q.tile + 2) * (q.tile + 2)) * 4 <= 48 * 1024;
+}
+hipError_t launch_ctx_exp_conv1(const CtxExpConv1Params& q, hipStream_t st) {
+  if (!ctx_exp_conv1_ok(q)) return hipErrorInvalidValue;
+  const int T = q.tile;
+  const unsigned grid = (unsigned)(((q.cv.H + T - 1) / T) * ((q.cv.W + T - 1) / T));
+  const size_t lds = (size_t)(((q.fc.K + 3) & ~3) + (T + 2) * (T + 2)) * sizeof(float);
+  if (T == 16) {
+    VP_LAUNCH(ctx_exp_conv1_kernel<16>, dim3(grid), dim3(256), lds, st, q);
+  }
+  VP_LAUNCH(ctx_exp_conv1_kernel<8>, dim3(grid), dim3(256), lds, st, q);
 }
 hipError_t launch_ctx_conv1(const CtxConv1Params& p, hipStream_t st) {
   VP_LAUNCH(ctx_conv1_kernel, dim3(nblk((long long)p.H * p.W * (p.out.C >> 3))), dim3(256), 0, st, p);

@@ -12,6 +12,7 @@ alignas(16) VP_EMU_LDS unsigned char bk_smem[64 << 10];
 alignas(16) VP_EMU_LDS unsigned char det_smem[160 << 10];
 alignas(16) VP_EMU_LDS float xs[40 << 10];
 alignas(16) VP_EMU_LDS float sh[40 << 10];
+alignas(16) VP_EMU_LDS float smem_f[12 << 10];   // ctx_exp_conv1_kernel (round 5)
 }  // namespace vp
 
 using namespace vp;
