@@ -773,10 +773,12 @@ Act* Engine::build_context(const WeightBlob& blob, const std::string& p, const A
     cp.out = c->view();
     Op op;
     op.flops = 2.0 * 9 * 128 * HW;
-    CtxExpConv1Params q{fp2, cp, 8, 64};   // 8x8 patches: six workgroups on the 10x20 map; 800-element rows: a wave per row
+    // 2x2 patches: 50 workgroups on the 10x20 map, the 16 map rows under a patch in ONE pass of 16 lanes per 800-element row (13 independent loads per
+    // lane).  (First cut: 8x8 patches, a wave per row = 25 dependent passes per workgroup: 69 us against 21 for the two launches it replaced.)
+    CtxExpConv1Params q{fp2, cp, 2, 16};
     if (fuse23 && ctx_exp_conv1_ok(q)) {
       op.name = p + "context_layer_2+3";
-      op.kernel = "ctx_exp_conv1<t8>";
+      op.kernel = "ctx_exp_conv1<t2>";
       op.flops += 2.0 * fp2.N * fp2.K;
       op.bytes = (fp2.w8 ? 1.0 : 4.0) * fp2.N * fp2.K;
       op.run = [q](hipStream_t st) { return launch_ctx_exp_conv1(q, st); };
@@ -1089,11 +1091,14 @@ void Engine::build_autodrive(const WeightBlob& blob) {
       cpp.b = dupload(bk);
       cpp.out = c2->view();
       cpp.act = ACT_SILU;
-      // round 5: exp0 (the matvec that builds the H x W map) and ctx0 (the convolution that reads it) in ONE launch (kernels_misc.hip
-      // ctx_exp_conv1_kernel): 16x16 patches on the large maps, 8x8 from 2048 pixels down; lanes per row by the row length (32 / 64 / 128 / 256 channels).
-      // VP_CTX_FUSE=0 (developer knob, A/B timing): two launches as before
-      CtxExpConv1Params q{fp, cpp, HW > 2048 ? 16 : 8, a->C <= 64 ? 1 : (a->C <= 128 ? 4 : 16)};
-      if (!dev_option_is("VP_CTX_FUSE", '0') && ctx_exp_conv1_ok(q)) {
+      // round 5: exp0 (the matvec that builds the H x W map) and ctx0 (the convolution that reads it) CAN run as one launch (kernels_misc.hip
+      // ctx_exp_conv1_kernel: 16x16 patches on the large maps, 8x8 from 2048 pixels down) -- built for VERDICT round 4 item 7 and MEASURED SLOWER here
+      // (gpurun r5c06, fp16, us per launch pair -> fused): p2 19.0 -> 23.2, p3 17.6 -> 22.2, p4 16.7 -> 15.6, p5 14.9 -> 19.3; frame p50 0.452 -> 0.479 ms
+      // with four launches fewer: the two launches spread the matvec over 32-128 workgroups, a patch's workgroup walks its 100-324 rows alone.
+      // Selected only by VP_CTX_FUSE=1; the scene networks' context_layer_2 + 3 (200 rows, 2x2 patches, 50 workgroups) keep the fused form (21 -> 17 us).
+      // lanes per row: as few as keep every map row under a patch in one pass (16x16: 324 rows, one lane each in two passes; 8x8: 100 rows, two lanes each)
+      CtxExpConv1Params q{fp, cpp, HW > 2048 ? 16 : 8, HW > 2048 ? 1 : 2};
+      if (dev_option_is("VP_CTX_FUSE", '1') && ctx_exp_conv1_ok(q)) {
         push(cp + ".exp0+ctx0", q.tile == 16 ? "ctx_exp_conv1<t16>" : "ctx_exp_conv1<t8>", [q](hipStream_t st) { return launch_ctx_exp_conv1(q, st); },
              2.0 * HW * C + 2.0 * 9 * c0n * HW, (fp.w8 ? 1.0 : 4.0) * HW * C);
       } else {

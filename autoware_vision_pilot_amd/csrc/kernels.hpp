@@ -193,8 +193,8 @@ struct CtxConv1Params {
 struct CtxExpConv1Params {
   FcParams fc;
   CtxConv1Params cv;
-  int tile;     // square pixel patch per workgroup: 16 or 8
-  int glanes;   // lanes that share one row of the matvec: 1, 4, 16 or 64
+  int tile;     // square pixel patch per workgroup: 16, 8 or 2 -- the (tile + 2)^2 map rows under it should fit ONE pass of 256 / glanes rows
+  int glanes;   // lanes that share one row of the matvec (a power of two <= 64): few enough that a lane's pieces of a row are <= ~16 loads
 };
 bool ctx_exp_conv1_ok(const CtxExpConv1Params& p);
 hipError_t launch_ctx_exp_conv1(const CtxExpConv1Params& p, hipStream_t st);

@@ -148,13 +148,15 @@ __global__ __launch_bounds__(256) void ctx_exp_conv1_kernel(const CtxExpConv1Par
     float s = 0.f;
     if (p.w8) {
       const unsigned* wr8 = reinterpret_cast<const unsigned*>(p.w8 + (size_t)n * p.K);
-      for (int k = l; k < K4; k += G) {
+#pragma unroll 16
+      for (int k = l; k < K4; k += G) {   // (unrolled: a lane's pieces of the row are independent loads -- one or two round trips, not one per piece)
         const unsigned c4 = wr8[k];
         const f32x4_t m = x4[k];
         s += (e4m3_to_float(c4 & 0xffu) * m[0] + e4m3_to_float((c4 >> 8) & 0xffu) * m[1]) + (e4m3_to_float((c4 >> 16) & 0xffu) * m[2] + e4m3_to_float(c4 >> 24) * m[3]);
       }
     } else {
       const f32x4_t* wr = reinterpret_cast<const f32x4_t*>(p.w + (size_t)n * p.K);
+#pragma unroll 16
       for (int k = l; k < K4; k += G) {
         const f32x4_t a = wr[k], m = x4[k];
         s += (a[0] * m[0] + a[1] * m[1]) + (a[2] * m[2] + a[3] * m[3]);
@@ -458,8 +460,8 @@ hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st) {
 }
 bool ctx_exp_conv1_ok(const CtxExpConv1Params& q) {
   const FcParams& p = q.fc;
-  const bool g_ok = q.glanes == 1 || q.glanes == 4 || q.glanes == 16 || q.glanes == 64;
-  return (q.tile == 8 || q.tile == 16) && g_ok && p.K >= 4 && (p.K & 3) == 0 && p.N == q.cv.H * q.cv.W && (p.w != nullptr) != (p.w8 != nullptr) && p.b && q.cv.w && q.cv.b &&
+  const bool g_ok = q.glanes >= 1 && q.glanes <= 64 && (q.glanes & (q.glanes - 1)) == 0;
+  return (q.tile == 2 || q.tile == 8 || q.tile == 16) && g_ok && p.K >= 4 && (p.K & 3) == 0 && p.N == q.cv.H * q.cv.W && (p.w != nullptr) != (p.w8 != nullptr) && p.b && q.cv.w && q.cv.b &&
          (q.cv.out.C & 7) == 0 && p.act_rows == 0 && (p.partial != nullptr || p.x != nullptr) && (size_t)(((p.K + 3) & ~3) + (q.tile + 2) * (q.tile + 2)) * 4 <= 48 * 1024;
 }
 hipError_t launch_ctx_exp_conv1(const CtxExpConv1Params& q, hipStream_t st) {
@@ -469,6 +471,9 @@ hipError_t launch_ctx_exp_conv1(const CtxExpConv1Params& q, hipStream_t st) {
   const size_t lds = (size_t)(((q.fc.K + 3) & ~3) + (T + 2) * (T + 2)) * sizeof(float);
   if (T == 16) {
     VP_LAUNCH(ctx_exp_conv1_kernel<16>, dim3(grid), dim3(256), lds, st, q);
+  }
+  if (T == 2) {
+    VP_LAUNCH(ctx_exp_conv1_kernel<2>, dim3(grid), dim3(256), lds, st, q);
   }
   VP_LAUNCH(ctx_exp_conv1_kernel<8>, dim3(grid), dim3(256), lds, st, q);
 }

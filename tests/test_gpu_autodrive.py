@@ -106,3 +106,30 @@ def test_autodrive_fp16_close(setup):
         assert np.array_equal(got, eng.logits().reshape(3))  # graph replay is deterministic
     finally:
         eng.close()
+
+
+def test_autodrive_ctx_fused_form_matches(setup, vp_opts):
+    """Round 5: the CTX expansion matvec + the 1 -> C/2 convolution as ONE launch per stage (kernels_misc.hip ctx_exp_conv1_kernel, 16x16 and 8x8 patches) --
+    measured slower than the two launches on this network and therefore opt-in (VP_CTX_FUSE=1), but a shipped kernel: same three scalars
+    (the matvec's summation order differs: a few ulp), four launches fewer, a different plan hash."""
+    from autoware_vision_pilot_amd import lib
+
+    g, frames, sd, blob = setup
+    base = lib.Engine("autodrive", blob, precision="fp16x3")
+    try:
+        base.infer_pair(frames[0], frames[1])
+        want, n0, h0 = base.logits().reshape(3).copy(), len(base.layers()), base.plan_hash()
+    finally:
+        base.close()
+    vp_opts.setenv("VP_CTX_FUSE", "1")
+    eng = lib.Engine("autodrive", blob, precision="fp16x3")
+    try:
+        assert len(eng.layers()) == n0 - 4 and eng.plan_hash() != h0
+        assert sum(1 for k in eng.layer_kernels() if k.startswith("ctx_exp_conv1<t")) == 4
+        for _ in range(2):
+            eng.infer_pair(frames[0], frames[1])
+            got = eng.logits().reshape(3)
+            assert np.abs(got - want).max() <= 1e-5, (got, want)
+            assert np.abs(got - g["fp32_out"]).max() <= 1e-3
+    finally:
+        eng.close()
