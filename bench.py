@@ -84,13 +84,19 @@ def pmc_traffic(tag):
     (profiles/r0N_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
     1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  The file must carry the hash of
     the CURRENT kernel sources (kernel_source_hash); None if not profiled on them."""
-    m8 = re.match(r"conv3x3_x3w(8|4)<", tag)
+    m8 = re.match(r"conv3x3_x3w(8|4)<co(\d+),px(\d+)", tag)
     m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
-    if m8:
-        pat = r"conv3x3_x3_kernel<128, 16, 2, 4, true" if m8.group(1) == "8" else r"conv3x3_x3_kernel<128, 8, 2, 2, false"
+    if m8:   # the pipelined shapes: <CO_TILE, TH, WCO, WPX, HDB, ...>
+        co8, px8 = int(m8.group(2)), int(m8.group(3))
+        if m8.group(1) == "8":
+            pat = r"conv3x3_x3_kernel<128, 16, 2, 4, true"
+        elif px8 == 256:
+            pat = rf"conv3x3_x3_kernel<{co8}, 16, 1, 4, false"
+        else:
+            pat = rf"conv3x3_x3_kernel<{co8}, 8, 2, 2, false"
     elif m:
         co, px, x, reg = int(m.group(1)), int(m.group(2)), m.group(3), m.group(4)
-        pat = rf"conv3x3_halo_kernel<{co}, {px // 16}, 16, \d, \d, {'true' if x == '3' else 'false'}, 0, {'true' if reg else 'false'}>"
+        pat = rf"conv3x3_halo_kernel<{co}, {px // 16}, 16, \d, \d, {'true' if x == '3' else 'false'}, 0, {'true' if reg else 'false'}(, \w+)*>"
     else:
         m = re.match(r"conv_gemm<bk(\d+),co(\d+),px(\d+),x(\d)(?:,regepi(\d))?>", tag)
         if not m:
@@ -622,12 +628,15 @@ def main():
             return "hbm", f["bytes"] / (f["ms"] * 1e-3) / 1e9 / 8000.0
 
         by_time = []
-        for k in sorted(single, key=lambda k: -fam[k]["ms"])[:8]:
+        # every kernel family by its share of the frame's (eager, single-stream) time; "+splitk" families are TWO launches per timing interval (the
+        # kernel + the shared finish kernel): their `frac` includes the finish launch, and `launches` counts intervals
+        for k in sorted(fam, key=lambda k: -fam[k]["ms"])[:10]:
             trk = pmc_traffic(k)
             by_time.append({"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / tot_ms, 3),
                             "bound": frac_of(k)[0], "frac": round(frac_of(k)[1], 4),
                             "algorithmic_mb_per_launch": round(fam[k]["bytes"] / fam[k]["n"] / 1e6, 2),
-                            "traffic_mb_per_launch": round(trk["bytes"] / 1e6, 2) if trk else None})
+                            "traffic_mb_per_launch": round(trk["bytes"] / 1e6, 2) if trk else None,
+                            **({"includes_finish_launch": True} if "+splitk" in k else {})})
         gflop = workload_gflop(kinds)
         frame_tflops = gflop * (main_fig["fps"] / world) / 1e3
         if dom.startswith("conv"):
