@@ -276,7 +276,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // the halo kernel's lone-wave schedule left them at 0.29-0.31 of peak.  VP_F16_BIG=0 (developer knob, A/B timing): the halo kernel.
       const char* envf = dev_option("VP_F16_BIG");
       if (!split() && !fp8_storage() && o.tile < 0 && !(envf && envf[0] == '0') && halo >= 0 && halo <= 3 && ncols % 128 == 0 && cin_pad % 64 == 0 && !o.logits_out &&
-          !o.in2 && plain && wgs16 >= 160) {
+          !o.in2 && plain && wgs16 >= (dev_option("VP_F16_MIN_WGS") ? std::atoi(dev_option("VP_F16_MIN_WGS")) : 160)) {
         // measured per layer (profiles/r04_layers_sceneseg_fp16_big_ab.tsv): the 8-wave shape wins where ONE round of its workgroups covers the
         // map and the K loop is long (decode_layer_4: 79.6 -> 68.9 us, decode_layer_7: 45.6 -> 40.9); with two rounds (decode_layer_6: 75.6 ->
         // 77.2) or two chunks per workgroup (decode_layer_8: 85.8 -> 95.6 / 83.7 on the 4-wave shape) the halo kernel's two workgroups per CU
@@ -288,8 +288,13 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured
         // on MI355X, the 4-wave shape without split-K took 139 vs 100 us on decode_layer_5 (200 patches) and its split-K form
         // (kernel support kept, tile 107 + nsplit) 63 vs 47 / 79 vs 70 us on decode_layer_1 / 3 (profiles/r02_splitk_x3w4.txt)
+        // Round 5: the floor is 100 tiles of 16x16 x 128 channels (it was 160): decode_layer_5 (512 -> 256 on 80x160: exactly 100) moves from the halo kernel's
+        // 400 64-channel workgroups to 100 8-wave workgroups of the pipelined shape.  ALONE the layer is slower (101 -> 138 us: 100 CUs), per occupied CU
+        // it runs at 2.2 TFLOP/s against 1.16 -- 100 CUs do not pull the package to its power limit -- and with the other head or the other cameras on
+        // the remaining CUs the frame rate gains 1.5-3 % at an unchanged one-camera p50 (profiles/r05_dec5_x3w8_ab.txt).  Below 100 (the 40x80 / 20x40
+        // maps: 60 / 36 workgroups) the same move LOSES 2 % / 11 %: their launches get 2-4x longer than the rest of the frame can cover.
         const char* envw = dev_option("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
-        if (plain && wgs16 >= (envw ? std::atoi(envw) : 160)) halo = want == 6 ? 6 : 7;
+        if (plain && wgs16 >= (envw ? std::atoi(envw) : 100)) halo = want == 6 ? 6 : 7;
         (void)wgs8;
       }
     }
@@ -312,7 +317,9 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // where it wins (the 10x20 geometry, >= 1024 input channels on a single region); VP_F16_MAP=1 everywhere it fits
       const bool f16_rule = (envf && envf[0] == '1') || geom == 2 || (cin_pad >= 1024 && M <= 800);
       const bool prec_on = split() || (!fp8_storage() && cin_pad % 32 == 0 && !(envf && envf[0] == '0') && f16_rule);
-      if (o.tile == 111 || (on && prec_on && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= 3200 && geom_on &&
+      int map_max_m = 3200;
+      if (const char* e = dev_option("VP_MAP_MAX_M")) map_max_m = std::atoi(e);   // developer knob: largest map (pixels) the map kernels take
+      if (o.tile == 111 || (on && prec_on && o.tile < 0 && halo >= 0 && ncols > 32 && !o.logits_out && !o.in2 && M <= map_max_m && geom_on &&
                             conv3x3_map_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 32))))
         halo = 11;
       // round 5: 64-channel slabs (two M tiles per wave, kernels_conv3x3_map.hip "map2") where the geometry is the neck's and the output channels pad to 64
