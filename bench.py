@@ -654,6 +654,10 @@ def main():
             "mfma_issue_frac": round(mfma_per_product * achieved / peak, 4) if bound == "mfma" else None,
             "slowest_layer": d["worst"][0], "slowest_layer_us": round(1e3 * d["worst"][1], 1),
             "kernel_time_share": round(d["ms"] / tot_ms, 3), "by_time": by_time,
+            # every launch of that instantiation: a family average hides that a launch's rate follows its workgroup count (decode_layer_5: 100 workgroups of the
+            # 8-wave shape on 100 of 256 CUs -- chosen for its CU-time, DESIGN.md section 3 -- against 200 / 400 for its siblings)
+            "layers": [{"layer": name, "us": round(1e3 * t, 1), "tflops": round(fl / (t * 1e-3) / 1e12, 1), "frac": round(fl / (t * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4)}
+                       for (name, fl, by), k, t in rows if k == dom],
             "whole_frame": {"achieved": round(frame_tflops, 2), "frac": round(frame_tflops / PEAK_FP16_TFLOPS, 4),
                             "mfma_issue_frac": round(mfma_per_product * frame_tflops / PEAK_FP16_TFLOPS, 4),
                             "gflop_per_frame": round(gflop, 1), "unit": "TFLOP/s"},
