@@ -203,10 +203,15 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     if (!convt_rs_supported(p, sp))
       throw std::invalid_argument("register-stationary ConvTranspose kernel (tile 5): k2 s2 + bias, K = 128 or 256 + 32 (skip link), map width a multiple of 32, >= 2048 pixels: " + name);
     op.kernel = "convt_rs<k" + std::to_string(p.Cin + p.Cin2) + (sp ? ",x3>" : ",x1>");
-    if (const char* e = dev_option("VP_CONVT_RS_GROUPS")) {   // resolved HERE, at plan time, and part of the plan hash
-      p.rs_groups = std::max(1, std::atoi(e));
-      op.launch += "groups=" + std::to_string(p.rs_groups);
-    }
+    // Round 5: the K = 256 + 32 case (ConvTranspose + skip link 80x160 -> 160x320: four quadrant slices per pixel range) runs on 32 pixel-tile groups per
+    // slice = 128 persistent workgroups instead of 256.  An HBM-side byte mover does not need every CU to pull its bytes: ALONE the launch is slower
+    // (37.8 -> 52.7 us), with the other head or other cameras on the freed CUs the frame gains 1.2-1.3 % on two boxes and one camera's p50 is level or
+    // better (profiles/r05_convt_groups_ab.txt: 403.6 / 402.9 -> 408.4, 414.4 / 413.5 -> 418.7 / 419.9 frames/s; 24 groups +0.7 %, the K = 128 case at
+    // 192 / 128 groups +-0).  VP_CONVT_RS_GROUPS_K288 / VP_CONVT_RS_GROUPS (developer knobs, one per shape case) override; both are read HERE, at plan
+    // time, and are part of the plan hash.
+    if (p.Cin2 > 0) p.rs_groups = 32;
+    if (const char* e = dev_option(p.Cin2 > 0 ? "VP_CONVT_RS_GROUPS_K288" : "VP_CONVT_RS_GROUPS")) p.rs_groups = std::max(1, std::atoi(e));
+    if (p.rs_groups > 0) op.launch += "groups=" + std::to_string(p.rs_groups);
     op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
   } else {
     const int epi = (ks == 1 && !sp && !p.w8) ? regepi_case(p, conv_tile_co(tile), sp) : 0;  // same rule as launch_cfg (kernels_conv.hip)

@@ -172,7 +172,7 @@ def test_convt_register_stationary_kernel(emu_lib, precision, vp_opts):
     vp_opts.setenv("VP_CONVT_RS_GROUPS", "5")
     _case(emu_lib, 128, 128, 32, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=42)                  # 12-13 tiles per workgroup
     _case(emu_lib, 100, 120, 34, 64, 2, 1, 0, 0, precision, [(5, -1, 1)], seed=43)                  # channels padded to 128 / 128
-    vp_opts.setenv("VP_CONVT_RS_GROUPS", "3")
+    vp_opts.setenv("VP_CONVT_RS_GROUPS_K288", "3")        # (round 5: one key per shape case)
     a = _skip_case(emu_lib, 256, 24, 256, 16, 128, precision, seed=44)                              # 64 tiles x 4 quadrant slices, 21-22 per workgroup
     vp_opts.setenv("VP_CONVT_RS", "0")
     b = _skip_case(emu_lib, 256, 24, 256, 16, 128, precision, seed=44)                              # same layer through the GEMM kernel
