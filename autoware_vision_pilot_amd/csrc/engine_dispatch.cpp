@@ -5,6 +5,13 @@
 
 namespace vp {
 
+// Round 5: the dispatch rules trade a layer's OWN latency for CU-time where the rest of the frame can use the freed CUs (decode_layer_5 on 100
+// workgroups, the neck's map layers on half the workgroups, the K = 288 ConvTranspose on 128) -- right for a camera with forked heads and for several
+// cameras per GPU, the configurations bench.py measures; a host that runs ONE network on ONE camera, one frame at a time, has nothing to put on the
+// freed CUs and pays 3-7 % of its frame (SceneSeg alone 1.79 -> 1.91 ms).  vp_set_option("VP_PLAN_TARGET", "latency") selects the round-4 choices
+// for engines created afterwards (it shows in vp_version() and changes vp_plan_hash() like every option); default / "throughput": the rules above.
+static bool plan_for_latency() { return dev_option_is("VP_PLAN_TARGET", 'l'); }
+
 // ------------------------------------------------------------------------------------------- conv planning
 void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc) {
   auto cdiv = [](long long a, long long b) { return (a + b - 1) / b; };
@@ -209,7 +216,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     // better (profiles/r05_convt_groups_ab.txt: 403.6 / 402.9 -> 408.4, 414.4 / 413.5 -> 418.7 / 419.9 frames/s; 24 groups +0.7 %, the K = 128 case at
     // 192 / 128 groups +-0).  VP_CONVT_RS_GROUPS_K288 / VP_CONVT_RS_GROUPS (developer knobs, one per shape case) override; both are read HERE, at plan
     // time, and are part of the plan hash.
-    if (p.Cin2 > 0) p.rs_groups = 32;
+    if (p.Cin2 > 0 && !plan_for_latency()) p.rs_groups = 32;
     if (const char* e = dev_option(p.Cin2 > 0 ? "VP_CONVT_RS_GROUPS_K288" : "VP_CONVT_RS_GROUPS")) p.rs_groups = std::max(1, std::atoi(e));
     if (p.rs_groups > 0) op.launch += "groups=" + std::to_string(p.rs_groups);
     op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
@@ -299,7 +306,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // the remaining CUs the frame rate gains 1.5-3 % at an unchanged one-camera p50 (profiles/r05_dec5_x3w8_ab.txt).  Below 100 (the 40x80 / 20x40
         // maps: 60 / 36 workgroups) the same move LOSES 2 % / 11 %: their launches get 2-4x longer than the rest of the frame can cover.
         const char* envw = dev_option("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
-        if (plain && wgs16 >= (envw ? std::atoi(envw) : 100)) halo = want == 6 ? 6 : 7;
+        if (plain && wgs16 >= (envw ? std::atoi(envw) : (plan_for_latency() ? 160 : 100))) halo = want == 6 ? 6 : 7;
         (void)wgs8;
       }
     }
@@ -331,7 +338,8 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // without waste: parity mode only.  VP_MAP2=0 (developer knob, A/B timing): tile 11 everywhere.
       int min_regions = 1;
       if (const char* e = dev_option("VP_MAP2_MIN_REGIONS")) min_regions = std::atoi(e);   // developer knob: 4 = the 40x80 maps only
-      if (halo == 11 && o.tile < 0 && split() && geom == 1 && !dev_option_is("VP_MAP2", '0') && round_up(ncols, 64) == round_up(ncols, 32) &&
+      if (halo == 11 && o.tile < 0 && split() && geom == 1 && !dev_option_is("VP_MAP2", '0') && !(plan_for_latency() && !dev_option_is("VP_MAP2", '1')) &&
+          round_up(ncols, 64) == round_up(ncols, 32) &&
           (in->H / 20) * (in->W / 40) >= min_regions && conv3x3_map2_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 64)))
         halo = 12;
     }

@@ -347,7 +347,10 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
  * tile / split-K sweeps: DESIGN.md section 3, csrc/options.cpp for the key list) are set here, process-wide, and affect engines
  * created AFTERWARDS; value NULL removes a key; an unknown key is VP_ERR_ARG.  No option is needed in production and none changes a
  * result beyond fp32 summation order.  vp_version() lists every option in force; vp_plan_hash() = FNV-1a over (launch name, kernel
- * tag) of an engine's plan, so a host (bench.py does) can record exactly which kernels ran. */
+ * tag, launch geometry) of an engine's plan, so a host (bench.py does) can record exactly which kernels ran.
+ * ONE key is meant for hosts (round 5): "VP_PLAN_TARGET" = "latency" | "throughput" (default).  The default plan spends a layer's own latency where
+ * the rest of the frame can use the CUs it frees (forked heads on one camera, several cameras per GPU: +3.6 % frames/s); a host that runs ONE
+ * network on ONE camera, one frame at a time, has nothing to put there and gets its 3-7 % back with "latency" (SceneSeg alone: p50 1.91 -> 1.8 ms). */
 int vp_set_option(const char* key, const char* value);
 const char* vp_get_option(const char* key);       /* NULL when unset */
 void vp_clear_options(void);

@@ -318,3 +318,16 @@ def test_kernel_plan_is_the_committed_one(emu_lib, monkeypatch):
     finally:
         emu_lib.clear_options()
     assert h0 != 0 and h0 != h1 and any("conv3x3_map" in k for k in k0) and not any("conv3x3_map" in k for k in k1)
+    # round 5: the one option meant for hosts.  Default plan = CU-time rules (decode_layer_5 on the 8-wave pipelined shape, the neck on 64-channel slabs);
+    # VP_PLAN_TARGET=latency = the round-4 choices for a host that runs one network on one camera, one frame at a time
+    assert sum(1 for k in k0 if k.startswith("conv3x3_map2<")) == 4
+    emu_lib.set_option("VP_PLAN_TARGET", "latency")
+    try:
+        eng = emu_lib.Engine("egolanes", blob, precision="fp16x3")
+        h2, k2, names = eng.plan_hash(), eng.layer_kernels(), [n for n, _, _ in eng.layers()]
+        eng.close()
+    finally:
+        emu_lib.clear_options()
+    assert h2 not in (h0, h1) and not any(k.startswith("conv3x3_map2<") for k in k2) and sum(1 for k in k2 if k.startswith("conv3x3_map<co32,px800")) == 4
+    d5 = [k for n, k in zip(names, k2) if n.endswith("decode_layer_5")]
+    assert d5 == ["conv3x3_halo<co64,px128,x3>"] and [k for n, k in zip(names, k0) if n.endswith("decode_layer_5")] == ["conv3x3_x3w8<co128,px256>"]
