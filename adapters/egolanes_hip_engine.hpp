@@ -29,6 +29,9 @@ public:
     (void)cache_dir;
     char err[512] = {0};
     const int prec = (precision == "fp32" || precision == "fp16x3") ? VP_FP16X3 : VP_FP16;
+    // one network, one camera, one frame at a time on the lateral thread (main.cpp:505): the latency plan, unless the host already chose
+    // (process-wide option; hip_backend.hpp has the reasoning; EgoLanes alone: p50 1.43 -> 1.32 ms)
+    if (vp_get_option("VP_PLAN_TARGET") == nullptr) vp_set_option("VP_PLAN_TARGET", "latency");
     if (vp_create(&engine_, VP_EGOLANES, model_path.c_str(), prec, device_id, err, sizeof(err)) != VP_OK)
       throw std::runtime_error(std::string("[hip_engine] ") + err);
     vp_set_input_format(engine_, VP_BGR8, VP_PLANES_RGB);  // resize, BGR->RGB, ImageNet norm: onnxruntime_engine.cpp:72-102

@@ -83,6 +83,11 @@ public:
     if (precision == "fp16") prec = VP_FP16;
     else if (precision == "fp32" || precision == "fp16x3") prec = VP_FP16X3;
     else throw std::invalid_argument("HipBackend: precision must be fp16 or fp32, got '" + precision + "'");
+    // One backend instance = one network on one camera, one frame at a time (run_model_node.cpp:79-86): nothing runs beside a layer on the CUs the
+    // default (several-cameras / forked-heads) kernel plan frees, so ask for the latency plan -- unless the host already chose (the option is
+    // process-wide: a process that packs several cameras onto one GPU sets "throughput" before it constructs its backends).  SceneSeg alone:
+    // p50 1.91 -> 1.80 ms (profiles/r05_plan_target_ab.txt).
+    if (vp_get_option("VP_PLAN_TARGET") == nullptr) vp_set_option("VP_PLAN_TARGET", "latency");
     char err[512] = {0};
     const int rc = vp_create(&engine_, kind, model_path.c_str(), prec, gpu_id, err, sizeof(err));
     if (rc != VP_OK) {
