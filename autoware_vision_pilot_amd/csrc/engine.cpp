@@ -821,9 +821,18 @@ Act* Engine::build_neck(const WeightBlob& blob, const std::string& p, const Act*
   for (int blk = 0; blk < 3; ++blk) {
     const std::string up = p + "upsample_layer_" + std::to_string(blk), sk = p + "skip_link_layer_" + std::to_string(blk);
     // d = upsample(x) + skip(feature): one GEMM over K = [x channels | feature channels]
+    // round 6: upsample + skip link + the first 3x3 of the block are one linear map -- composed at load into ONE launch (engine_upconv.cpp)
+    const bool composed = upconv_wanted();
+    if (composed) {
+      const std::string dl = p + "decode_layer_" + std::to_string(2 * blk);
+      x = add_upconv(up + "+skip_link_layer_" + std::to_string(blk) + "+decode_layer_" + std::to_string(2 * blk), x, feats[3 - blk],
+                     blob.get(up + ".weight").data, blob.get(up + ".bias").data, blob.get(sk + ".weight").data, blob.get(sk + ".bias").data,
+                     blob.get(dl + ".weight").data, blob.get(dl + ".bias").data, up_c[blk], d_c[2 * blk], ACT_GELU, -1, 0, dl);
+    } else {
     x = add_convT_skip(up, sk, x, feats[3 - blk], blob.get(up + ".weight").data, blob.get(up + ".bias").data,
                        blob.get(sk + ".weight").data, blob.get(sk + ".bias").data, up_c[blk]);
-    for (int k = 0; k < 2; ++k) {
+    }
+    for (int k = composed ? 1 : 0; k < 2; ++k) {
       const std::string dl = p + "decode_layer_" + std::to_string(2 * blk + k);
       ConvOpts o;
       o.act = ACT_GELU;
@@ -849,12 +858,24 @@ void Engine::build_head(const WeightBlob& blob, const std::string& p, const Act*
     c_last = 3;
   } else {  // scene_seg_head.py:21-44, scene_3d_head.py:23-47, domain_seg_head.py:21-44
     const int c9 = kind_ == 1 ? 128 : 64;
+    const bool composed = upconv_wanted();   // round 6: (upsample + skip link | upsample) + the 3x3 behind it as ONE launch (engine_upconv.cpp)
+    if (composed) {
+      x = add_upconv(p + "upsample_layer_3+skip_link_layer_3+decode_layer_6", x, feats[0], W("upsample_layer_3"), B("upsample_layer_3"),
+                     W("skip_link_layer_3"), B("skip_link_layer_3"), W("decode_layer_6"), B("decode_layer_6"), 256, 256, ACT_GELU, -1, 0, p + "decode_layer_6");
+    } else {
     const Act* u = add_convT_skip(p + "upsample_layer_3", p + "skip_link_layer_3", x, feats[0], W("upsample_layer_3"),
                                   B("upsample_layer_3"), W("skip_link_layer_3"), B("skip_link_layer_3"), 256);
     x = add_conv(p + "decode_layer_6", u, W("decode_layer_6"), B("decode_layer_6"), 256, 3, gelu);
+    }
     x = add_conv(p + "decode_layer_7", x, W("decode_layer_7"), B("decode_layer_7"), 128, 3, gelu);
+    if (composed) {
+      const std::vector<float> none;
+      x = add_upconv(p + "upsample_layer_4+decode_layer_8", x, nullptr, W("upsample_layer_4"), B("upsample_layer_4"), none, none, W("decode_layer_8"),
+                     B("decode_layer_8"), 128, 128, ACT_GELU, -1, 0, p + "decode_layer_8");
+    } else {
     x = add_convT(p + "upsample_layer_4", x, W("upsample_layer_4"), B("upsample_layer_4"), 128, ConvOpts{});
     x = add_conv(p + "decode_layer_8", x, W("decode_layer_8"), B("decode_layer_8"), 128, 3, gelu);
+    }
     x = add_conv(p + "decode_layer_9", x, W("decode_layer_9"), B("decode_layer_9"), c9, 3, gelu);
     last = "decode_layer_10";
     c_last = kind_ == 0 ? 3 : 1;

@@ -66,7 +66,18 @@ struct Op {
   std::string kernel;  // kernel instantiation tag (groups launches for the roofline report)
   std::string launch;  // launch geometry fixed at PLAN time that the tag does not spell (split-K factor, persistent-group count): hashed by vp_plan_hash
   double flops = 0, bytes = 0;
+  // matrix work the launch EXECUTES when that differs from the reference formulation's count in `flops` (composed up-sampling stages: flops keeps
+  // SURVEY.md 8d's three-op count so whole-frame figures stay comparable across rounds); 0 = same as flops
+  double flops_executed = 0;
   std::function<hipError_t(hipStream_t)> run;
+};
+
+// ConvTranspose2d(k2, s2) [+ 1x1 skip link] -> Conv3x3 multiplied out at load (engine_upconv.cpp): fp64, real (un-padded) channel counts
+struct UpconvComposed {
+  int cin = 0, cm = 0, cout = 0, cs = 0;
+  std::vector<double> wx;    // [4 phases (py * 2 + px)][4 taps (a * 2 + b)][cout][cin]: out(2y + py, 2x + px) += wx . x(y + py - 1 + a, x + px - 1 + b)
+  std::vector<double> ws;    // [9 taps (ty * 3 + tx)][cout][cs]: 3x3 convolution of the skip tensor
+  std::vector<double> bias;  // [9 classes (row class * 3 + column class)][cout]; class 0 / 1 / 2 = first / inner / last row (column) of the output map
 };
 
 struct ConvOpts {
@@ -184,6 +195,13 @@ class Engine {
                       const std::vector<float>& bs, int cout);
   Act* add_convT(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout,
                  const ConvOpts& o);
+  void compose_upconv(const float* wt, const float* bt, const float* ws, const float* bs, const float* w3, const float* b3, int cin, int cm, int cout,
+                      int cs, UpconvComposed* out);
+  // shape: 6 / 7 (kernels.hpp), -1 = dispatch rule; nsplit: K slices, <= 0 = dispatch rule
+  Act* add_upconv(const std::string& name, const Act* in, const Act* skip_in, const std::vector<float>& wt, const std::vector<float>& bt,
+                  const std::vector<float>& ws, const std::vector<float>& bs, const std::vector<float>& w3, const std::vector<float>& b3, int cm,
+                  int cout, int act, int shape = -1, int nsplit = 0, const std::string& out_name = std::string());
+  bool upconv_wanted() const;  // composed up-sampling stages in this engine's plan (parity mode; VP_UPCONV=0: the three-op form of rounds 1-5)
   void run_eager();
   void run_ops(hipStream_t st, size_t begin, size_t end);
   void enqueue_multi(const std::vector<Engine*>& heads);

@@ -250,6 +250,81 @@ hipError_t launch_gemm_dma(const ConvGemmParams& p, hipStream_t st);
 bool convt_rs_supported(const ConvGemmParams& p, bool split);
 int convt_rs_shape_case(int H, int W, int cin_pad, int cin2_pad, int ncols, int cstore);  // 0 = not covered
 hipError_t launch_convt_rs(const ConvGemmParams& p, hipStream_t st);
+// ---- composed up-sampling stage (kernels_upconv.hip, round 6) ------------------------------------------------------------------------
+// ConvTranspose2d(k2, s2) [+ Conv1x1(skip)] followed by Conv3x3 with NO nonlinearity in between (scene_neck.py:29-35,41-46,52-57;
+// scene_seg_head.py:24-29,35-38; scene_3d_head.py:26-31,38-41) is ONE linear map: a transposed convolution with a 4x4 kernel, stride 2, pad 1
+// from the LOW-resolution tensor -- per output phase (Y & 1, X & 1) a 2x2 convolution of it -- plus a 3x3 convolution of the skip tensor with
+// pre-multiplied weights, plus a bias that depends only on which of the 9 high-resolution taps are inside the map.  The weights are composed
+// at load (upconv_compose: fp64 accumulation on the device) and the stage is ONE launch: 0.40-0.51x the matrix work of the two it replaces.
+struct UpconvParams {
+  const half_t* in_hi;   // low-resolution input  H x W x Cin (NHWC, Cin a multiple of 32), (hi, lo)
+  const half_t* in_lo;
+  const half_t* sk_hi;   // skip tensor 2H x 2W x Cs (Cs a multiple of 32) or null (Cs = 0)
+  const half_t* sk_lo;
+  int H, W, Cin, Cs;
+  const half_t* w_hi;    // [4 phases][S steps][CoutW][32] in LDS image order (upconv_pack_index), S = upconv_steps(Cin, Cs)
+  const half_t* w_lo;
+  const float* bias;     // [9][CoutW]: (row class * 3 + column class), class 0 = first row / column of the OUTPUT map, 2 = last, 1 = inside
+  const float* wscale;   // [4][CoutW] 2^-prescale of the weight rows of each phase (ConvGemmParams::wscale)
+  int CoutW, Ncols, Cstore;
+  half_t* out_hi;        // 2H x 2W x Cstore
+  half_t* out_lo;
+  int act;               // ACT_GELU | ACT_NONE
+  int nsplit;            // K slices over the chunk list (> 1: fp32 partials + upconv_finish_kernel)
+  float* partial;        // [nsplit][4 H W][CoutW]
+};
+// shapes: 6 = 8 waves, 16x16 low-resolution pixels x 128 channels per phase (one workgroup per CU); 7 = 4 waves, 8x16 pixels x 128 channels (two per CU)
+bool upconv_supported(const UpconvParams& p, int shape);
+// The K axis of one output phase (py, px) is a list of 32-channel CHUNKS, each with its own tap list (a K "step" = one chunk x one tap = one weight
+// tile of CoutW x 32 and one shifted read of the chunk's halo image):
+//   chunks [0, Cin / 32): the low-resolution input, 4 taps (a, b) in {0, 1}^2 = low-resolution pixel (y + py - 1 + a, x + px - 1 + b);
+//   then per CLASS (qy, qx) of skip pixels (the skip tensor seen as four half-resolution images S[qy][qx](y, x) = skip(2y + qy, 2x + qx)), Cs / 32
+//   chunks each: the taps of the 3x3 window around output pixel (2y + py, 2x + px) that fall on that class -- 2 per axis where the class bit differs
+//   from the phase bit (high-resolution taps 0 and 2: a = 0, 1), 1 where it is equal (tap 1: a = 1 - py).  Class order (1-py, 1-px) [4 taps],
+//   (1-py, px) [2], (py, 1-px) [2], (py, px) [1]: 9 * Cs / 32 steps, neighbours in the order share their cache lines.
+// tap k of a chunk: a = a0 + k / nb, b = b0 + k % nb; the halo image (origin = low-resolution pixel (y0 - 1, x0 - 1) of the workgroup's patch) is read
+// at rows + py + a, columns + px + b.
+struct UpconvChunk {
+  int skip, ch0, qy, qx, nt, nb, a0, b0, step0;
+};
+__host__ __device__ inline UpconvChunk upconv_chunk(int c, int py, int px, int cin_pad, int cs_pad) {
+  const int kcx = cin_pad >> 5, kcs = cs_pad >> 5;
+  UpconvChunk d;
+  if (c < kcx || kcs == 0) {
+    d.skip = 0; d.ch0 = c << 5; d.qy = 0; d.qx = 0; d.nt = 4; d.nb = 2; d.a0 = 0; d.b0 = 0; d.step0 = 4 * c;
+    return d;
+  }
+  const int r = c - kcx, cls = r / kcs, cc = r - cls * kcs;
+  d.skip = 1;
+  d.ch0 = cc << 5;
+  d.qy = cls < 2 ? 1 - py : py;
+  d.qx = (cls & 1) ? px : 1 - px;
+  const int na = d.qy != py ? 2 : 1;
+  d.nb = d.qx != px ? 2 : 1;
+  d.a0 = na == 2 ? 0 : 1 - py;
+  d.b0 = d.nb == 2 ? 0 : 1 - px;
+  d.nt = na * d.nb;
+  const int cls_step0 = cls == 0 ? 0 : (cls == 1 ? 4 : (cls == 2 ? 6 : 8));
+  d.step0 = 4 * kcx + cls_step0 * kcs + cc * d.nt;
+  return d;
+}
+__host__ __device__ inline int upconv_chunks(int cin_pad, int cs_pad) { return (cin_pad >> 5) + 4 * (cs_pad >> 5); }
+__host__ __device__ inline int upconv_steps(int cin_pad, int cs_pad) { return 4 * (cin_pad >> 5) + 9 * (cs_pad >> 5); }   // K steps of one phase
+// packed position of weight element (phase, step, output channel co, channel i of the step's 32): [phase][step][CoutW][32] with the 16-byte pieces of
+// a row XOR-swizzled by (co >> 2) & 3 -- the LDS image of a (CoutW x 32) tile, so the LDS-DMA copy is linear (as halo tiles 6 - 9, engine_dispatch.cpp)
+inline size_t upconv_pack_index(int phase, int step, int co, int i, int steps, int coutw) {
+  const int i_sw = ((((i & 31) >> 3) ^ ((co >> 2) & 3)) << 3) | (i & 7);
+  return (((size_t)phase * steps + step) * coutw + co) * 32 + i_sw;
+}
+hipError_t launch_upconv(const UpconvParams& p, int shape, hipStream_t st);
+// fp64-accumulating GEMM of the weight composition: C[g][m][n] = sum over the group's (A_i, B_i) pairs of sum_k A_i[m][k] * B_i[n][k] (fp32 in, fp64 out)
+struct ComposeGemmParams {
+  const float* a[4];   // [M][K]
+  const float* b[4];   // [N][K]
+  int pairs, M, N, K;
+  double* c;           // [M][N]
+};
+hipError_t launch_compose_gemm(const ComposeGemmParams* groups_dev, int n_groups, int M, int N, hipStream_t st);
 hipError_t launch_preprocess(const PreprocessParams& p, hipStream_t st);
 hipError_t launch_pil_resample(const PilResampleParams& p, hipStream_t st);  // both passes
 hipError_t launch_stem(const StemParams& p, hipStream_t st);

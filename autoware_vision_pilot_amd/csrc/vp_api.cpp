@@ -652,4 +652,64 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
   }
 }
 
+// ---- composed up-sampling stage (round 6): the load-time weight composition alone, and the whole stage as one operator
+int vp_compose_upconv(int gpu_id, const float* wt, const float* bt, const float* ws, const float* bs, const float* w3, const float* b3, int cin, int cm,
+                      int cout, int cs, double* wx, double* wsk, double* bias, char* err, size_t err_len) {
+  if (!wt || !bt || !w3 || !b3 || !wx || !bias || cin < 1 || cm < 1 || cout < 1 || cs < 0 || (cs > 0 && (!ws || !bs || !wsk))) {
+    set_err(err, err_len, "bad argument");
+    return VP_ERR_ARG;
+  }
+  try {
+    vp::Engine g(-1, nullptr, VP_FP16X3, gpu_id);
+    vp::UpconvComposed c;
+    g.compose_upconv(wt, bt, ws, bs, w3, b3, cin, cm, cout, cs, &c);
+    std::memcpy(wx, c.wx.data(), c.wx.size() * sizeof(double));
+    if (cs > 0) std::memcpy(wsk, c.ws.data(), c.ws.size() * sizeof(double));
+    std::memcpy(bias, c.bias.data(), c.bias.size() * sizeof(double));
+    return VP_OK;
+  } catch (const std::invalid_argument& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_ARG;
+  } catch (const std::exception& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_HIP;
+  }
+}
+
+int vp_op_upconv(int gpu_id, const float* in, int cin, int h, int w, const float* skip, int cs, const float* wt, const float* bt, const float* ws,
+                 const float* bs, const float* w3, const float* b3, int cm, int cout, int act, int shape, int nsplit, float* out, char* err,
+                 size_t err_len) {
+  if (!in || !wt || !bt || !w3 || !b3 || !out || cin < 1 || cm < 1 || cout < 1 || h < 1 || w < 1 || cs < 0 || (cs > 0 && (!skip || !ws || !bs))) {
+    set_err(err, err_len, "bad argument");
+    return VP_ERR_ARG;
+  }
+  try {
+    vp::Engine g(-1, nullptr, VP_FP16X3, gpu_id);
+    vp::Act* a = g.new_act("in", cin, h, w);
+    g.upload_act(a, in);
+    vp::Act* sk = nullptr;
+    if (cs > 0) {
+      sk = g.new_act("skip", cs, 2 * h, 2 * w);
+      g.upload_act(sk, skip);
+    }
+    const std::vector<float> vwt(wt, wt + (size_t)cin * cm * 4), vbt(bt, bt + cm), vw3(w3, w3 + (size_t)cout * cm * 9), vb3(b3, b3 + cout);
+    const std::vector<float> vws(cs > 0 ? ws : nullptr, cs > 0 ? ws + (size_t)cm * cs : nullptr), vbs(cs > 0 ? bs : nullptr, cs > 0 ? bs + cm : nullptr);
+    vp::Act* y = g.add_upconv("op", a, sk, vwt, vbt, vws, vbs, vw3, vb3, cm, cout, act, shape, nsplit);
+    g.run_eager();
+    g.sync();
+    for (size_t i = 0; i < g.acts().size(); ++i)
+      if (g.acts()[i].get() == y) g.read_act((int)i, out);
+    return VP_OK;
+  } catch (const vp::RangeError& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_RANGE;
+  } catch (const std::invalid_argument& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_ARG;
+  } catch (const std::exception& ex) {
+    set_err(err, err_len, ex.what());
+    return VP_ERR_HIP;
+  }
+}
+
 }  // extern "C"

@@ -90,6 +90,9 @@ _SIGS = {
     "vp_tensor_read": (C.c_int, [_P, C.c_int, _P]),
     "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
+    "vp_compose_upconv": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_char_p, C.c_size_t]),
+    "vp_op_upconv": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P,
+                               C.c_char_p, C.c_size_t]),
     "vp_detect_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "vp_detect_destroy": (None, [_P]),
     "vp_detect_last_error": (C.c_char_p, [_P]),
@@ -651,6 +654,46 @@ def op_conv2d(x, weight, bias, ks=3, mode=0, act=0, res=None, res_mode=0, precis
                           _ptr(r) if r is not None else None, tile, bk, nsplit, _ptr(out), err, len(err))
     if rc != 0:
         raise VpError(f"vp_op_conv2d failed ({rc}): {err.value.decode(errors='replace')}")
+    return out
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def compose_upconv(wt, bt, w3, b3, ws=None, bs=None, gpu_id=0):
+    """vp_compose_upconv: ConvTranspose2d(k2, s2) [+ 1x1 skip link] -> Conv3x3 multiplied out (fp64).  wt [cin][cm][2][2], w3 [cout][cm][3][3],
+    ws [cm][cs] or [cm][cs][1][1].  Returns (wx [4][4][cout][cin], wsk [9][cout][cs] or None, bias [9][cout])."""
+    lib = load()
+    wt, bt, w3, b3, ws, bs = (_f32(v) for v in (wt, bt, w3, b3, ws, bs))
+    cin, cm = wt.shape[:2]
+    cout = w3.shape[0]
+    cs = 0 if ws is None else ws.shape[1]
+    wx = np.empty((4, 4, cout, cin), dtype=np.float64)
+    wsk = np.empty((9, cout, cs), dtype=np.float64) if cs else None
+    bias = np.empty((9, cout), dtype=np.float64)
+    err = C.create_string_buffer(512)
+    rc = lib.vp_compose_upconv(gpu_id, _ptr(wt), _ptr(bt), _ptr(ws) if cs else None, _ptr(bs) if cs else None, _ptr(w3), _ptr(b3), cin, cm, cout, cs,
+                               _ptr(wx), _ptr(wsk) if cs else None, _ptr(bias), err, len(err))
+    if rc != 0:
+        raise VpError(f"vp_compose_upconv failed ({rc}): {err.value.decode(errors='replace')}")
+    return wx, wsk, bias
+
+
+def op_upconv(x, wt, bt, w3, b3, skip=None, ws=None, bs=None, act=1, shape=-1, nsplit=0, gpu_id=0):
+    """vp_op_upconv: one composed up-sampling stage through the engine's kernel (parity mode): x [cin][h][w], skip [cs][2h][2w] -> [cout][2h][2w]."""
+    lib = load()
+    x, wt, bt, w3, b3, skip, ws, bs = (_f32(v) for v in (x, wt, bt, w3, b3, skip, ws, bs))
+    cin, h, w = x.shape
+    cm = wt.shape[1]
+    cout = w3.shape[0]
+    cs = 0 if skip is None else skip.shape[0]
+    out = np.empty((cout, 2 * h, 2 * w), dtype=np.float32)
+    err = C.create_string_buffer(512)
+    rc = lib.vp_op_upconv(gpu_id, _ptr(x), cin, h, w, _ptr(skip) if cs else None, cs, _ptr(wt), _ptr(bt), _ptr(ws) if cs else None,
+                          _ptr(bs) if cs else None, _ptr(w3), _ptr(b3), cm, cout, act, shape, nsplit, _ptr(out), err, len(err))
+    if rc != 0:
+        raise VpError(f"vp_op_upconv failed ({rc}): {err.value.decode(errors='replace')}")
     return out
 
 

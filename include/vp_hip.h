@@ -342,6 +342,25 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
                  int cout, int ks, int act, int res_mode, const float* res, int tile, int bk, int nsplit, float* out,
                  char* err, size_t err_len);
 
+/* ---- composed up-sampling stage (round 6; unit parity tests, not used by callers) --------------------------
+ * The decoders apply ConvTranspose2d(k2, s2) [+ Conv2d 1x1 of a skip tensor] and then Conv2d 3x3 with NO nonlinearity in between
+ * (Models/model_components/scene_neck.py:29-35,41-46,52-57; scene_seg_head.py:24-29,35-38; scene_3d_head.py:26-31,38-41): one linear map.
+ * The engine multiplies the three weight sets out at load (fp64 accumulation) and runs the stage as ONE launch on the LOW-resolution
+ * tensor: per output phase (Y & 1, X & 1) a 2x2 convolution of it, a 3x3 convolution of the skip tensor with pre-multiplied weights,
+ * and a bias that depends only on which high-resolution taps lie inside the map -- 0.40-0.51x the matrix work, same result.
+ * vp_compose_upconv: the composition alone.  wt [cin][cm][2][2], bt [cm] (ConvTranspose2d); ws [cm][cs], bs [cm] (1x1 skip link; cs = 0:
+ *   none, ws / bs / wsk may be NULL); w3 [cout][cm][3][3], b3 [cout].  Results (fp64):
+ *   wx [4 phases py*2+px][4 taps a*2+b][cout][cin]: out(2y+py, 2x+px) += wx . x(y+py-1+a, x+px-1+b) (zero outside the low-resolution map);
+ *   wsk [9 taps ty*3+tx][cout][cs]: plain 3x3 / pad 1 convolution of the skip tensor;
+ *   bias [9 classes rc*3+cc][cout]: rc / cc = 0 first, 1 inner, 2 last row / column of the OUTPUT map.
+ * vp_op_upconv: the whole stage through the engine's kernel (VP_FP16X3): in [cin][h][w], skip [cs][2h][2w] -> out [cout][2h][2w], fp32 CHW host
+ *   buffers; act 0 none, 1 GELU; shape 6 / 7 or -1 (dispatch rule); nsplit K slices or 0 (dispatch rule). */
+int vp_compose_upconv(int gpu_id, const float* wt, const float* bt, const float* ws, const float* bs, const float* w3, const float* b3, int cin, int cm,
+                      int cout, int cs, double* wx, double* wsk, double* bias, char* err, size_t err_len);
+int vp_op_upconv(int gpu_id, const float* in, int cin, int h, int w, const float* skip, int cs, const float* wt, const float* bt, const float* ws,
+                 const float* bs, const float* w3, const float* b3, int cm, int cout, int act, int shape, int nsplit, float* out, char* err,
+                 size_t err_len);
+
 /* ---- developer options ------------------------------------------------------------------------------------
  * The library NEVER reads the environment.  The dispatch rules' developer knobs (A/B timing of a kernel against the one it replaced,
  * tile / split-K sweeps: DESIGN.md section 3, csrc/options.cpp for the key list) are set here, process-wide, and affect engines

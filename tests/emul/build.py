@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "autoware_vision_pilot_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-UNITS = ("kernels_conv.hip", "kernels_convt_rs.hip", "kernels_head.hip", "kernels_gemm_dma.hip", "kernels_conv3x3.hip", "kernels_conv3x3_x3.hip", "kernels_conv3x3_map.hip", "kernels_backbone.hip", "kernels_mbconv.hip",
-         "kernels_misc.hip", "kernels_autodrive.hip", "kernels_detect.hip", "engine.cpp", "engine_dispatch.cpp", "engine_io.cpp", "onnx_reader.cpp", "vp_api.cpp", "vp_detect.cpp", "options.cpp")
+UNITS = ("kernels_conv.hip", "kernels_convt_rs.hip", "kernels_head.hip", "kernels_gemm_dma.hip", "kernels_conv3x3.hip", "kernels_conv3x3_x3.hip", "kernels_conv3x3_map.hip", "kernels_upconv.hip", "kernels_backbone.hip", "kernels_mbconv.hip",
+         "kernels_misc.hip", "kernels_autodrive.hip", "kernels_detect.hip", "engine.cpp", "engine_dispatch.cpp", "engine_upconv.cpp", "engine_io.cpp", "onnx_reader.cpp", "vp_api.cpp", "vp_detect.cpp", "options.cpp")
 HEADERS = ("common.hpp", "kernels.hpp", "act_io.hpp", "se_phases.hpp", "conv_epilogue.hpp", "lds_dma.hpp", "engine.hpp", "engine_internal.hpp", "vp_handle.hpp", "viridis_lut.inc")
 REWRITES = (
     ('asm volatile("" : "+v"(lane_o_));', "(void)0;"),
