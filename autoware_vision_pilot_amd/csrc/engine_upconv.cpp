@@ -230,8 +230,13 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   const int n_co = coutw / 128;
   int sh = shape;
   if (sh < 0) {
+    // Measured per stage on the MI355X (profiles/r06_upconv_shapes.txt, SceneSeg, us, shape 6 / shape 7): 10x20 -> 20x40 67.2 / 73.1, 20x40 -> 40x80
+    // 87.8 / 77.5, 40x80 -> 80x160 106.4 / 106.2, 80x160 -> 160x320 119.8 / 125.5, 160x320 -> 320x640 (128 channels) 118.4 / 103.9: the 8-row patches
+    // where the map's rows leave a 16-row patch mostly empty (20 and 40 rows), and where the K loop is short (Cin <= 128: two independent workgroups
+    // per CU overlap prologue and epilogue, as for kernels_conv3x3_x3.hip); the 8-wave shape elsewhere
+    const double eff6 = (double)in->H * in->W / (double)(t16 * 256), eff7 = (double)in->H * in->W / (double)(t8 * 128);
     const char* e = dev_option("VP_UPCONV_SHAPE");   // developer knob: 6 / 7 on every stage
-    sh = e ? std::atoi(e) : (cin_pad <= 128 ? 7 : 6);
+    sh = e ? std::atoi(e) : ((eff7 > 1.1 * eff6 || cin_pad <= 128) ? 7 : 6);
   }
   if (sh != 6 && sh != 7) throw std::invalid_argument("composed up-sampling stage: shape 6 (16x16 patches, 8 waves) or 7 (8x16 patches, 4 waves): " + name);
   const long long blocks = (sh == 6 ? t16 : t8) * 4 * n_co;

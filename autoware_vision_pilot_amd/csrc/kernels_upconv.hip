@@ -175,7 +175,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
       VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
     }                                                                                        \
   }
-  // halo pieces of chunk descriptor D -> registers (border / unread pixels: zeros)
+  // halo pieces of chunk descriptor D -> registers.  Pieces outside the map (or never read by this phase) fetch element 0 and are ZEROED AT THE STORE:
+  // a select here, inside the conditional block that issues the loads, is evaluated in that block -- the compiler put s_waitcnt vmcnt(0) right behind
+  // the loads (seen in the ISA: a whole memory round trip exposed at every chunk's last step)
 #define VP_LOAD_H(D)                                                                         \
   {                                                                                          \
     const half_t* sh_ = (D).skip ? p.sk_hi : p.in_hi;                                        \
@@ -183,19 +185,17 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     const int add_ = (D).skip ? ((D).qy * 2 * p.W + (D).qx) * p.Cs + (D).ch0 : (D).ch0;      \
     _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) {                                      \
       const int g_ = (D).skip ? h_gs[pc] : h_gx[pc];                                         \
-      const int o_ = (g_ >= 0 ? g_ : 0) + add_;                                              \
-      const u32x4 v_ = *reinterpret_cast<const u32x4*>(sh_ + o_);                            \
-      const u32x4 l_ = *reinterpret_cast<const u32x4*>(sl_ + o_);                            \
-      rh_hi[pc] = g_ >= 0 ? v_ : zero4;                                                      \
-      rh_lo[pc] = g_ >= 0 ? l_ : zero4;                                                      \
+      const int o_ = (g_ >= 0 ? g_ + add_ : 0);                                              \
+      rh_hi[pc] = *reinterpret_cast<const u32x4*>(sh_ + o_);                                 \
+      rh_lo[pc] = *reinterpret_cast<const u32x4*>(sl_ + o_);                                 \
     }                                                                                        \
   }
 #define VP_STORE_H(BUF)                                                                      \
   _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) {                                        \
     if (tid + NTH * pc < HCHUNKS) {                                                          \
       char* dst_ = halo_base + (BUF) * PL * HSTRIDE + h_lds0 + pc * (NTH / 4) * ROWB;        \
-      *reinterpret_cast<u32x4*>(dst_) = rh_hi[pc];                                           \
-      *reinterpret_cast<u32x4*>(dst_ + HSTRIDE) = rh_lo[pc];                                 \
+      *reinterpret_cast<u32x4*>(dst_) = h_gx[pc] >= 0 ? rh_hi[pc] : zero4;                   \
+      *reinterpret_cast<u32x4*>(dst_ + HSTRIDE) = h_gx[pc] >= 0 ? rh_lo[pc] : zero4;         \
     }                                                                                        \
   }
 #define VP_READ_FRAGS(SET, WPTR, HPTR, TAPOFS)                                               \
@@ -234,86 +234,96 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     dn = upconv_chunk(cA + 1, py, px, p.Cin, p.Cs);
     VP_LOAD_H(dn)
   }
-  int tap_cur = VP_TAP_OFS(d, 0);
-  VP_READ_FRAGS(0, w_base, halo_base, tap_cur)
+  VP_READ_FRAGS(0, w_base, halo_base, VP_TAP_OFS(d, 0))
 
-  int c = cA, t = 0, hb = 0;
+  int c = cA, t = 0, s = 0, hb = 0;
   int w_cur = 0, w_nxt = PL * W_BYTES, w_fre = 2 * PL * W_BYTES;   // byte offsets of the three weight buffers: read now / next step / being filled
-  for (int s = 0; s < S; ++s) {
-    const bool last_tap = t + 1 == d.nt;
-    const bool next_chunk = c + 1 < cB;
-    const bool load_ahead = last_tap && c + 2 < cB;                // this step refills the staging registers with chunk c + 2
-    const char* hbuf = halo_base + (HDB ? hb : 0) * PL * HSTRIDE;
-    const char* hbuf_next = (HDB && last_tap) ? halo_base + (hb ^ 1) * PL * HSTRIDE : hbuf;
-    const int tap_nxt = last_tap ? (next_chunk ? VP_TAP_OFS(dn, 0) : tap_cur) : VP_TAP_OFS(d, t + 1);
-    // HDB: the next chunk's halo (in registers since the previous chunk's last step) goes to the OTHER halo image at the head of this chunk's last
-    // step, BEFORE this step's DMA is issued (the compiler guards the registers with s_waitcnt vmcnt(0): at this point the only other thing in
-    // flight is the weight tile requested one step ago, which this step's barrier needs anyway -- kernels_conv3x3_x3.hip, tap 3)
-    if constexpr (HDB) {
-      if (last_tap && next_chunk) { VP_STORE_H(hb ^ 1) }
-    }
-    // weight tile of step s + 2 -> the buffer step s - 1 read last (its barrier has passed); must land before the NEXT step's barrier
-    if (s + 2 < S) VP_DMA_W(w_fre, s + 2)
-    __builtin_amdgcn_sched_barrier(0);
-    VP_MFMA_RANGE(0, 0, MT * NT / 2)
-    __builtin_amdgcn_sched_barrier(0);
-    VP_READ_FRAGS(1, w_base + w_cur, hbuf, tap_cur)
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise)
-    UpconvChunk dnn = dn;
-    if constexpr (HDB) {
-      if (load_ahead) {
-        dnn = upconv_chunk(c + 2, py, px, p.Cin, p.Cs);
-        VP_LOAD_H(dnn)
-      }
-    }
-    VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)
-    __builtin_amdgcn_sched_barrier(0);
-    // What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s + 1); vmcnt retires in issue order, so it has landed once at most
-    // {the halo loads issued behind it in the previous step, this step's DMA, this step's halo loads} are outstanding.  The previous step refilled the
-    // staging registers iff it was a chunk's last step (t == 0 now) with a chunk to refill them with (c + 1 < cB; the prologue's load counts the same).
-    {
-      const int dma_n = s + 2 < S ? PL * WPIECES : 0;
-      const int ld_prev = (t == 0 && next_chunk) ? PL * HP : 0;
-      const int ld_this = (HDB && load_ahead) ? PL * HP : 0;
-      VP_WAIT_VMCNT_RT(dma_n + ld_prev + ld_this);
-    }
-    // THE BARRIER SITS BETWEEN THE TWO K SUB-STEPS (kernels_conv3x3_x3.hip): the only LDS operations outstanding here are set 1's reads
-    VP_LDS_BARRIER();
-    if constexpr (!HDB) {
-      // single halo image: every wave has issued (and the barrier's lgkmcnt(0) completed) its last read of chunk c -- the next chunk's pieces go over it,
-      // a second barrier opens it, the registers are refilled with chunk c + 2
-      if (last_tap && next_chunk) {
-        VP_STORE_H(0)
-        VP_LDS_BARRIER();
-        if (load_ahead) {
-          dnn = upconv_chunk(c + 2, py, px, p.Cin, p.Cs);
-          VP_LOAD_H(dnn)
-        }
-      }
-    }
-    // ---- K sub-step 1: set 0 of the NEXT step is fetched while set 1 multiplies
-    VP_READ_FRAGS(0, w_base + w_nxt, hbuf_next, tap_nxt)
-    __builtin_amdgcn_sched_barrier(0);
-    VP_MFMA_RANGE(1, 0, MT * NT)
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- advance the step state (wave-uniform scalars)
-    {
-      const int w_old = w_cur;
-      w_cur = w_nxt;
-      w_nxt = w_fre;
-      w_fre = w_old;
-    }
-    tap_cur = tap_nxt;
-    if (last_tap) {
-      ++c;
-      t = 0;
-      d = dn;
-      dn = dnn;
-      hb ^= 1;
-    } else {
-      ++t;
-    }
+  // One K step.  KIND 0: not the chunk's last tap.  KIND 1 / 2 / 3: the chunk's LAST tap, where the halo of chunk c + 1 (in the staging registers since
+  // the previous chunk's last step) goes to LDS and (KIND 1) the registers are refilled with chunk c + 2; 2: no chunk c + 2; 3: no chunk c + 1.
+  // The kinds are separate straight-line instances (the chunk loop below is peeled by them) because the compiler's wait-count model is not path
+  // sensitive: with "store if last tap" and "refill if last tap" as two conditionals of ONE loop body it assumed the refill's destination registers
+  // could still be the targets of the previous refill's loads and put s_waitcnt vmcnt(0) in front of it -- draining the weight tile requested a few
+  // instructions earlier, an L2 round trip with the matrix pipe idle at every chunk's last step (seen in the ISA).
+  // PREVLD: the step in front of this chunk's first step refilled the staging registers (its loads sit BEHIND that step's DMA in the vmcnt order).
+#define VP_STEP(KIND, PREVLD)                                                                \
+  {                                                                                          \
+    const int tap_cur_ = VP_TAP_OFS(d, t);                                                   \
+    const int tap_nxt_ = (KIND) == 0 ? VP_TAP_OFS(d, t + 1) : ((KIND) == 3 ? tap_cur_ : VP_TAP_OFS(dn, 0)); \
+    const char* hbuf = halo_base + (HDB ? hb : 0) * PL * HSTRIDE;                            \
+    const char* hbuf_next = (HDB && (KIND) != 0) ? halo_base + (hb ^ 1) * PL * HSTRIDE : hbuf; \
+    /* HDB: the next chunk's halo goes to the OTHER halo image at the head of this chunk's last step, BEFORE this step's DMA is issued (the compiler */ \
+    /* guards the registers with s_waitcnt vmcnt(0): at this point the only other thing in flight is the weight tile requested one step ago, which */ \
+    /* this step's barrier needs anyway -- kernels_conv3x3_x3.hip, tap 3)                                                                          */ \
+    if constexpr (HDB && ((KIND) == 1 || (KIND) == 2)) { VP_STORE_H(hb ^ 1) }                \
+    /* weight tile of step s + 2 -> the buffer step s - 1 read last (its barrier has passed); must land before the NEXT step's barrier */ \
+    if (s + 2 < S) VP_DMA_W(w_fre, s + 2)                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    VP_MFMA_RANGE(0, 0, MT * NT / 2)                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    VP_READ_FRAGS(1, w_base + w_cur, hbuf, tap_cur_)                                         \
+    __builtin_amdgcn_sched_barrier(0);  /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
+    UpconvChunk dnn = dn;                                                                    \
+    if constexpr (HDB && (KIND) == 1) {                                                      \
+      dnn = upconv_chunk(c + 2, py, px, p.Cin, p.Cs);                                        \
+      VP_LOAD_H(dnn)                                                                         \
+    }                                                                                        \
+    VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    /* What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s + 1); vmcnt retires in issue order, so it has landed once at */ \
+    /* most {the halo loads issued behind it in the previous step, this step's DMA, this step's halo loads} are outstanding                          */ \
+    {                                                                                        \
+      const int dma_n = s + 2 < S ? PL * WPIECES : 0;                                        \
+      const int ld_prev = ((PREVLD) && t == 0) ? PL * HP : 0;                                \
+      const int ld_this = (HDB && (KIND) == 1) ? PL * HP : 0;                                \
+      VP_WAIT_VMCNT_RT(dma_n + ld_prev + ld_this);                                           \
+    }                                                                                        \
+    /* THE BARRIER SITS BETWEEN THE TWO K SUB-STEPS (kernels_conv3x3_x3.hip): the only LDS operations outstanding here are set 1's reads */ \
+    VP_LDS_BARRIER();                                                                        \
+    if constexpr (!HDB && ((KIND) == 1 || (KIND) == 2)) {                                    \
+      /* single halo image: every wave has completed its last read of chunk c (the barrier's lgkmcnt(0)) -- the next chunk's pieces go over it, a */ \
+      /* second barrier opens it, the registers are refilled with chunk c + 2                                                                    */ \
+      VP_STORE_H(0)                                                                          \
+      VP_LDS_BARRIER();                                                                      \
+      if constexpr ((KIND) == 1) {                                                           \
+        dnn = upconv_chunk(c + 2, py, px, p.Cin, p.Cs);                                      \
+        VP_LOAD_H(dnn)                                                                       \
+      }                                                                                      \
+    }                                                                                        \
+    /* ---- K sub-step 1: set 0 of the NEXT step is fetched while set 1 multiplies */       \
+    VP_READ_FRAGS(0, w_base + w_nxt, hbuf_next, tap_nxt_)                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    VP_MFMA_RANGE(1, 0, MT * NT)                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    /* ---- advance the step state (wave-uniform scalars) */                                \
+    {                                                                                        \
+      const int w_old = w_cur;                                                               \
+      w_cur = w_nxt;                                                                         \
+      w_nxt = w_fre;                                                                         \
+      w_fre = w_old;                                                                         \
+    }                                                                                        \
+    ++s;                                                                                     \
+    if constexpr ((KIND) == 0) {                                                             \
+      ++t;                                                                                   \
+    } else {                                                                                 \
+      ++c;                                                                                   \
+      t = 0;                                                                                 \
+      d = dn;                                                                                \
+      dn = dnn;                                                                              \
+      hb ^= 1;                                                                               \
+    }                                                                                        \
   }
+  // chunks with two successors: store + refill at the last tap (the prologue refilled the registers for the first of them)
+  while (c + 2 < cB) {
+    while (t + 1 < d.nt) VP_STEP(0, true)
+    VP_STEP(1, true)
+  }
+  if (c + 1 < cB) {   // the last but one chunk: store, nothing left to refill with
+    while (t + 1 < d.nt) VP_STEP(0, true)
+    VP_STEP(2, true)
+  }
+  while (t + 1 < d.nt) VP_STEP(0, false)   // the last chunk (the step in front of it refilled nothing)
+  VP_STEP(3, false)
+#undef VP_STEP
 #undef VP_TAP_OFS
 #undef VP_MFMA_RANGE
 #undef VP_READ_FRAGS
@@ -343,25 +353,38 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     // ---- register epilogue: bias (by border class) + activation + (hi, lo) split, both planes staged as [pixel][CO_TILE] fp16, 16-byte stores
     constexpr int PITCH = CO_TILE * 2 + 16, STAGE_PLANE = PX * PITCH;
     static_assert(PL * STAGE_PLANE <= NHB * PL * HSTRIDE + 3 * PL * W_BYTES, "stage fits the main buffers");
-    __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
+    // bias (by the pixel's border class) and prescale vectors of this lane's accumulators: ALL requested before the barrier, so their round trips
+    // overlap each other and the barrier instead of one load -> wait -> GELU chain per register group
     const float* const wsc = p.wscale + (size_t)phase * p.CoutW + co0;
+    f32x4_t bb[NT][MT][4], sc[MT][4];
+    int qpix[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int q = (wpx * NT + j) * 32 + (lane & 31);
-      const int m = pix(q);
+      qpix[j] = (wpx * NT + j) * 32 + (lane & 31);
+      const int m = pix(qpix[j]);
       const float* const bsrc = p.bias + (size_t)(m >= 0 ? bias_class(m, 2 * p.H, 2 * p.W) : 4) * p.CoutW + co0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bb[j][i][g] = *reinterpret_cast<const f32x4_t*>(bsrc + (i * WCO + wco) * 32 + 4 * (lane >> 5) + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sc[i][g] = *reinterpret_cast<const f32x4_t*>(wsc + (i * WCO + wco) * 32 + 4 * (lane >> 5) + 8 * g);   // 2^-prescale: exact product
+    __syncthreads();  // every wave has finished its last K sub-step (and the dead prefetch behind the last barrier has landed)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int cl = (i * WCO + wco) * 32 + 4 * (lane >> 5);
-        char* row = smem + q * PITCH + cl * 2;
+        char* row = smem + qpix[j] * PITCH + cl * 2;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4_t b = *reinterpret_cast<const f32x4_t*>(bsrc + cl + 8 * g);
-          const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(wsc + cl + 8 * g);   // 2^-prescale of the phase's weight rows: exact product
           h4_t h, l;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = apply_act(fmaf(acc[i][j][4 * g + r], sc[r], b[r]), ACT);
+            const float x = apply_act(fmaf(acc[i][j][4 * g + r], sc[i][g][r], bb[j][i][g][r]), ACT);
             h[r] = (half_t)x;
             l[r] = (half_t)(x - (float)h[r]);
           }

@@ -495,6 +495,12 @@ int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, d
   if (bytes) *bytes = op.bytes;
   return VP_OK;
 }
+int vp_layer_flops_executed(const vp_engine* e, int i, double* flops) {
+  if (!e || !e->impl || !flops || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
+  const vp::Op& op = e->impl->ops()[i];
+  *flops = op.flops_executed > 0 ? op.flops_executed : op.flops;
+  return VP_OK;
+}
 int vp_layer_kernel(const vp_engine* e, int i, const char** kernel) {
   if (!e || !e->impl || !kernel || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
   *kernel = e->impl->ops()[i].kernel.c_str();

@@ -85,6 +85,7 @@ _SIGS = {
     "vp_layer_kernel": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p)]),
     "vp_copy_outputs_device": (C.c_int, [_P, _P, _P]),
     "vp_profile_layers": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "vp_layer_flops_executed": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "vp_tensor_count": (C.c_int, [_P]),
     "vp_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_tensor_read": (C.c_int, [_P, C.c_int, _P]),
@@ -526,6 +527,15 @@ class Engine:
             name, fl, by = C.c_char_p(), C.c_double(), C.c_double()
             self._ck(self._lib.vp_layer_info(self._h, i, C.byref(name), C.byref(fl), C.byref(by)))
             out.append((name.value.decode(), fl.value, by.value))
+        return out
+
+    def layer_flops_executed(self):
+        """matrix work each launch EXECUTES (differs from layers()' reference-formulation count for the composed up-sampling stages)"""
+        out = []
+        for i in range(self._ck(self._lib.vp_layer_count(self._h))):
+            fl = C.c_double()
+            self._ck(self._lib.vp_layer_flops_executed(self._h, i, C.byref(fl)))
+            out.append(fl.value)
         return out
 
     def layer_kernels(self):

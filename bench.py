@@ -84,9 +84,12 @@ def pmc_traffic(tag):
     (profiles/r0N_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, calibrated in-run on a
     1 GiB streaming kernel: FETCH_SIZE x2, WRITE_SIZE x1 on gfx950; tools/pmc_summarize.py).  The file must carry the hash of
     the CURRENT kernel sources (kernel_source_hash); None if not profiled on them."""
+    mu = re.match(r"upconv_x3w(8|4)<", tag)
     m8 = re.match(r"conv3x3_x3w(8|4)<co(\d+),px(\d+)", tag)
     m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
-    if m8:   # the pipelined shapes: <CO_TILE, TH, WCO, WPX, HDB, ...>
+    if mu:   # composed up-sampling stages: upconv_x3_kernel<CO_TILE, TH, WCO, WPX, HDB, ...>
+        pat = r"upconv_x3_kernel<128, 16, 2, 4, true" if mu.group(1) == "8" else r"upconv_x3_kernel<128, 8, 2, 2, false"
+    elif m8:   # the pipelined shapes: <CO_TILE, TH, WCO, WPX, HDB, ...>
         co8, px8 = int(m8.group(2)), int(m8.group(3))
         if m8.group(1) == "8":
             pat = r"conv3x3_x3_kernel<128, 16, 2, 4, true"
@@ -107,7 +110,7 @@ def pmc_traffic(tag):
         else:
             pat = (rf"conv_gemm_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}, \d, \d, {'true' if m.group(4) == '3' else 'false'}, "
                    rf"\d, (true|false), {m.group(5) or 0}>")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -601,17 +604,20 @@ def main():
         rows = []
         for e in engs:
             ms = e.profile_layers(10)
-            rows += list(zip(e.layers(), e.layer_kernels(), [float(t) for t in ms]))
+            rows += list(zip(e.layers(), e.layer_kernels(), [float(t) for t in ms], e.layer_flops_executed()))
         fam = {}
-        for (name, fl, by), k, t in rows:
-            f = fam.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, worst=("", 0.0)))
+        for (name, fl, by), k, t, fx in rows:
+            f = fam.setdefault(k, dict(ms=0.0, flops=0.0, flops_exec=0.0, bytes=0.0, n=0, worst=("", 0.0)))
             f["ms"] += t
             f["flops"] += fl
+            f["flops_exec"] += fx
             f["bytes"] += by
             f["n"] += 1
             if t > f["worst"][1]:
                 f["worst"] = (name, t)
-        tot_ms = sum(t for _, _, t in rows)
+        tot_ms = sum(t for _, _, t, _ in rows)
+        # what one frame EXECUTES on the matrix pipe (round 6: the composed up-sampling stages run 0.40-0.51x of the reference formulation's count)
+        exec_gflop = sum(fx for _, _, _, fx in rows) / 1e9
         # The path is a dense contraction (bound = MFMA): the roofline kernel is the single instantiation
         # (= one rocprofv3 kernel name) with the largest total time among those carrying >= 5 % of the frame's FLOPs;
         # "+splitk" ops are two launches per timing interval and cannot give a per-kernel duration.
@@ -623,7 +629,7 @@ def main():
 
         def frac_of(k):
             f = fam[k]
-            if k.startswith("conv"):
+            if k.startswith("conv") or k.startswith("upconv"):
                 return "mfma", f["flops"] / (f["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS
             return "hbm", f["bytes"] / (f["ms"] * 1e-3) / 1e9 / 8000.0
 
@@ -634,12 +640,13 @@ def main():
             trk = pmc_traffic(k)
             by_time.append({"kernel": k, "launches": fam[k]["n"], "time_share": round(fam[k]["ms"] / tot_ms, 3),
                             "bound": frac_of(k)[0], "frac": round(frac_of(k)[1], 4),
+                            **({"frac_executed": round(fam[k]["flops_exec"] / (fam[k]["ms"] * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4)} if frac_of(k)[0] == "mfma" else {}),
                             "algorithmic_mb_per_launch": round(fam[k]["bytes"] / fam[k]["n"] / 1e6, 2),
                             "traffic_mb_per_launch": round(trk["bytes"] / 1e6, 2) if trk else None,
                             **({"includes_finish_launch": True} if "+splitk" in k else {})})
         gflop = workload_gflop(kinds)
         frame_tflops = gflop * (main_fig["fps"] / world) / 1e3
-        if dom.startswith("conv"):
+        if dom.startswith("conv") or dom.startswith("upconv"):
             achieved, peak, unit, bound = d["flops"] / (d["ms"] * 1e-3) / 1e12, PEAK_FP16_TFLOPS, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = d["bytes"] / (d["ms"] * 1e-3) / 1e9, 8000.0, "GB/s", "hbm"
@@ -651,19 +658,27 @@ def main():
             "kernel": dom, "launches_per_frame": d["n"], "avg_launch_us": round(1e3 * d["ms"] / d["n"], 2),
             "algorithmic_gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 3),
             "algorithmic_mb_per_launch": round(d["bytes"] / d["n"] / 1e6, 3),
-            "mfma_issue_frac": round(mfma_per_product * achieved / peak, 4) if bound == "mfma" else None,
+            # executed: what the launches of that instantiation put on the matrix pipe (a composed up-sampling stage: 4 taps of the low-resolution tensor +
+            # 9 of the skip tensor per output pixel instead of the reference formulation's ConvTranspose + 1x1 + 3x3); mfma_issue_frac is on EXECUTED work
+            "executed_gflop_per_launch": round(d["flops_exec"] / d["n"] / 1e9, 3),
+            "achieved_executed": round(d["flops_exec"] / (d["ms"] * 1e-3) / 1e12, 2) if bound == "mfma" else None,
+            "mfma_issue_frac": round(mfma_per_product * d["flops_exec"] / (d["ms"] * 1e-3) / 1e12 / peak, 4) if bound == "mfma" else None,
             "slowest_layer": d["worst"][0], "slowest_layer_us": round(1e3 * d["worst"][1], 1),
             "kernel_time_share": round(d["ms"] / tot_ms, 3), "by_time": by_time,
             # every launch of that instantiation: a family average hides that a launch's rate follows its workgroup count (decode_layer_5: 100 workgroups of the
             # 8-wave shape on 100 of 256 CUs -- chosen for its CU-time, DESIGN.md section 3 -- against 200 / 400 for its siblings)
-            "layers": [{"layer": name, "us": round(1e3 * t, 1), "tflops": round(fl / (t * 1e-3) / 1e12, 1), "frac": round(fl / (t * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4)}
-                       for (name, fl, by), k, t in rows if k == dom],
+            "layers": [{"layer": name, "us": round(1e3 * t, 1), "tflops": round(fl / (t * 1e-3) / 1e12, 1), "frac": round(fl / (t * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4),
+                        "tflops_executed": round(fx / (t * 1e-3) / 1e12, 1)}
+                       for (name, fl, by), k, t, fx in rows if k == dom],
             "whole_frame": {"achieved": round(frame_tflops, 2), "frac": round(frame_tflops / PEAK_FP16_TFLOPS, 4),
-                            "mfma_issue_frac": round(mfma_per_product * frame_tflops / PEAK_FP16_TFLOPS, 4),
-                            "gflop_per_frame": round(gflop, 1), "unit": "TFLOP/s"},
+                            # issued MFMA work / peak: on what the frame EXECUTES since round 6 (gflop_per_frame stays SURVEY.md 8d's reference-formulation count,
+                            # so `frac` is comparable across rounds)
+                            "mfma_issue_frac": round(mfma_per_product * exec_gflop * (main_fig["fps"] / world) / 1e3 / PEAK_FP16_TFLOPS, 4),
+                            "gflop_per_frame": round(gflop, 1), "executed_gflop_per_frame": round(exec_gflop, 1), "unit": "TFLOP/s"},
             "note": "per-launch HIP events on the engine stream (eager replay, single stream); `achieved` counts ALGORITHMIC "
-                    "FLOPs (one multiply-add per product); fp16x3 issues 3 fp16 MFMAs per product, `mfma_issue_frac` = "
-                    "issued MFMA FLOPs / peak",
+                    "FLOPs of the reference formulation (SURVEY.md 8d: one multiply-add per product of the reference's operators); a composed up-sampling "
+                    "stage computes its three reference operators with 0.40-0.51x the products (`*_executed`); fp16x3 issues 3 fp16 MFMAs per executed "
+                    "product, `mfma_issue_frac` = issued MFMA FLOPs / peak",
         }
         prec_name = {"fp16": "fp16", "fp16x3": "fp16x3 (hi+lo fp16 pairs on the fp16 MFMA pipe, fp32 accumulate; fp32-class: floats within 1e-3 "
                                                "of the fp32 oracle, 0 class flips outside that float tolerance -- tie flips only, counted "
@@ -681,7 +696,7 @@ def main():
                                    f"shared EfficientNet-B0 encoder (vp_create_shared), {args.precision}",
                        "precision": args.precision, "parity_mode": args.precision == "fp16x3",
                        "frames_in_flight_per_gpu": nstreams, "net_input": "1x3x320x640", "gather": bool(args.gather),
-                       "gflop_per_frame": round(gflop, 1), "timed_region_s": round(main_fig["elapsed"], 3)},
+                       "gflop_per_frame": round(gflop, 1), "executed_gflop_per_frame": round(exec_gflop, 1), "timed_region_s": round(main_fig["elapsed"], 3)},
             "fps_per_gpu": round(main_fig["fps"] / world, 2),
             "single_stream_fps": round(main_fig["single"], 2),
             "p50_ms": round(main_fig["p50"], 4), "p99_ms": round(main_fig["p99"], 4), "latency_iters": main_fig["latency_iters"],

@@ -293,6 +293,10 @@ int vp_comm_fetch(vp_comm* c, vp_engine* e, const void** host, size_t* record_by
 int vp_layer_count(const vp_engine* e);
 int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, double* bytes);
 int vp_layer_kernel(const vp_engine* e, int i, const char** kernel_tag);        /* kernel instantiation of launch i */
+/* vp_layer_info's flops count the REFERENCE formulation of the layer(s) a launch computes (one multiply-add per product of the
+ * reference's operators).  A composed up-sampling stage (round 6: ConvTranspose [+ skip link] -> 3x3 multiplied out at load) executes 0.40-0.51x
+ * of that; this returns what the launch executes (= vp_layer_info's figure for every other launch). */
+int vp_layer_flops_executed(const vp_engine* e, int i, double* flops);
 int vp_profile_layers(vp_engine* e, int iters, float* ms_per_layer, int capacity); /* eager, event per launch */
 int vp_tensor_count(const vp_engine* e);
 int vp_tensor_info(const vp_engine* e, int i, const char** name, int* c, int* h, int* w);
