@@ -23,15 +23,15 @@ public:
   // provider / cache_dir are accepted for signature compatibility (the ONNX/TensorRT engines use them); precision:
   // "fp16" or "fp32" (parity mode).  model_path: the EgoLanes `.onnx` file or a VPW1 blob exported from the checkpoint.
   EgoLanesHipEngine(const std::string & model_path, const std::string & provider = "hip", const std::string & precision = "fp16",
-                    int device_id = 0, const std::string & cache_dir = "")
+                    int device_id = 0, const std::string & cache_dir = "", bool latency_plan = false)
   {
     (void)provider;
     (void)cache_dir;
     char err[512] = {0};
-    const int prec = (precision == "fp32" || precision == "fp16x3") ? VP_FP16X3 : VP_FP16;
-    // one network, one camera, one frame at a time on the lateral thread (main.cpp:505): the latency plan, unless the host already chose
-    // (process-wide option; hip_backend.hpp has the reasoning; EgoLanes alone: p50 1.43 -> 1.32 ms)
-    if (vp_get_option("VP_PLAN_TARGET") == nullptr) vp_set_option("VP_PLAN_TARGET", "latency");
+    // The production app runs this engine on its lateral thread BESIDE the AutoSpeed / AutoSteer engines' threads on the same GPU
+    // (production_release/main.cpp:505-535): the default (throughput) kernel plan leaves them CUs.  latency_plan = true (a creation flag of THIS engine,
+    // no process-wide state) is for a host that runs it alone: EgoLanes p50 1.43 -> 1.32 ms.
+    const int prec = ((precision == "fp32" || precision == "fp16x3") ? VP_FP16X3 : VP_FP16) | (latency_plan ? VP_PLAN_LATENCY : 0);
     if (vp_create(&engine_, VP_EGOLANES, model_path.c_str(), prec, device_id, err, sizeof(err)) != VP_OK)
       throw std::runtime_error(std::string("[hip_engine] ") + err);
     vp_set_input_format(engine_, VP_BGR8, VP_PLANES_RGB);  // resize, BGR->RGB, ImageNet norm: onnxruntime_engine.cpp:72-102
@@ -41,6 +41,8 @@ public:
   ~EgoLanesHipEngine() { vp_destroy(engine_); }
   EgoLanesHipEngine(const EgoLanesHipEngine &) = delete;
   EgoLanesHipEngine & operator=(const EgoLanesHipEngine &) = delete;
+
+  unsigned long long planHash() const { return vp_plan_hash(engine_); }
 
   LaneSegmentation inference(const cv::Mat & input_image, float threshold = 0.0f)
   {

@@ -71,7 +71,7 @@ public:
   // model_type: "segmentation" (SceneSeg), "depth" (Scene3D), "domain" (DomainSeg), "egolanes" -- the node's
   // `model_type` parameter (run_model_node.cpp:35) selects the network the same way it selects the post-process.
   HipBackend(const std::string & model_path, const std::string & precision, int gpu_id,
-             const std::string & model_type = "segmentation")
+             const std::string & model_type = "segmentation", const std::string & plan = "latency")
   {
     int kind;
     if (model_type == "segmentation") kind = VP_SCENESEG;
@@ -84,10 +84,11 @@ public:
     else if (precision == "fp32" || precision == "fp16x3") prec = VP_FP16X3;
     else throw std::invalid_argument("HipBackend: precision must be fp16 or fp32, got '" + precision + "'");
     // One backend instance = one network on one camera, one frame at a time (run_model_node.cpp:79-86): nothing runs beside a layer on the CUs the
-    // default (several-cameras / forked-heads) kernel plan frees, so ask for the latency plan -- unless the host already chose (the option is
-    // process-wide: a process that packs several cameras onto one GPU sets "throughput" before it constructs its backends).  SceneSeg alone:
-    // p50 1.91 -> 1.80 ms (profiles/r05_plan_target_ab.txt).
-    if (vp_get_option("VP_PLAN_TARGET") == nullptr) vp_set_option("VP_PLAN_TARGET", "latency");
+    // default (several-cameras / forked-heads) kernel plan frees, so THIS engine is created with the latency plan (a creation flag since round 6: no
+    // process-wide state is touched; a process that packs several cameras onto one GPU passes plan = "throughput").  SceneSeg alone: p50 1.91 -> 1.80 ms
+    // (profiles/r05_plan_target_ab.txt).
+    if (plan == "latency") prec |= VP_PLAN_LATENCY;
+    else if (plan != "throughput") throw std::invalid_argument("HipBackend: plan must be latency or throughput, got '" + plan + "'");
     char err[512] = {0};
     const int rc = vp_create(&engine_, kind, model_path.c_str(), prec, gpu_id, err, sizeof(err));
     if (rc != VP_OK) {
@@ -114,6 +115,9 @@ public:
   }
   HipBackend(const HipBackend &) = delete;
   HipBackend & operator=(const HipBackend &) = delete;
+
+  // FNV-1a over the engine's kernel plan (vp_plan_hash): tells the latency plan from the throughput plan
+  unsigned long long planHash() const { return vp_plan_hash(engine_); }
 
   bool doInference(const cv::Mat & input_image) override
   {

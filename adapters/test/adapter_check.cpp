@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 
 #include "autospeed_hip_stages.hpp"
 #include "egolanes_hip_engine.hpp"
@@ -89,6 +90,46 @@ int main(int argc, char ** argv)
       return fail("autospeed: a non-BGR8 image must throw");
     } catch (const std::runtime_error &) {
     }
+  } else if (kind == "threads") {
+    // round 6: the plan target is a creation flag of each engine -- a B1 backend (latency plan) and a B2 engine (throughput plan, the production
+    // app's several-engines-per-process case: main.cpp:505-535) constructed CONCURRENTLY from two threads, one frame each; no process-wide option is
+    // touched, and each engine's plan is the one a plain vp_create with / without VP_PLAN_LATENCY builds.  argv: threads <seg blob> <out> <ego blob>
+    if (argc < 5) return fail("threads: <seg blob> <out> <ego blob>");
+    const std::string ego_blob = argv[4];
+    unsigned long long h_b1 = 0, h_b2 = 0;
+    std::string err1, err2;
+    std::thread t1([&] {
+      try {
+        HipBackend b(blob, "fp32", 0, "segmentation");
+        if (!b.doInference(frame)) err1 = "doInference";
+        h_b1 = b.planHash();
+      } catch (const std::exception & ex) { err1 = ex.what(); }
+    });
+    std::thread t2([&] {
+      try {
+        EgoLanesHipEngine e(ego_blob, "hip", "fp32");
+        if (e.inference(frame, 0.0f).ego_left.empty()) err2 = "inference";
+        h_b2 = e.planHash();
+      } catch (const std::exception & ex) { err2 = ex.what(); }
+    });
+    t1.join();
+    t2.join();
+    if (!err1.empty() || !err2.empty()) return fail(("threads: " + err1 + " / " + err2).c_str());
+    if (vp_get_option("VP_PLAN_TARGET") != nullptr) return fail("threads: an adapter set a process-wide option");
+    char err[256] = {0};
+    vp_engine * ref = nullptr;
+    unsigned long long want[4] = {0, 0, 0, 0};
+    const struct { int kind; const char * path; int prec; } mk[4] = {{VP_SCENESEG, blob.c_str(), VP_FP16X3 | VP_PLAN_LATENCY}, {VP_SCENESEG, blob.c_str(), VP_FP16X3},
+                                                                      {VP_EGOLANES, ego_blob.c_str(), VP_FP16X3}, {VP_EGOLANES, ego_blob.c_str(), VP_FP16X3 | VP_PLAN_LATENCY}};
+    for (int i = 0; i < 4; ++i) {
+      if (vp_create(&ref, mk[i].kind, mk[i].path, mk[i].prec, 0, err, sizeof(err)) != VP_OK) return fail(err);
+      want[i] = vp_plan_hash(ref);
+      vp_destroy(ref);
+    }
+    if (h_b1 != want[0] || h_b1 == want[1]) return fail("threads: the B1 backend is not on the latency plan");
+    if (h_b2 != want[2] || h_b2 == want[3]) return fail("threads: the B2 engine is not on the throughput plan");
+    f.write(reinterpret_cast<const char *>(&h_b1), 8);
+    f.write(reinterpret_cast<const char *>(&h_b2), 8);
   } else if (kind == "egolanes") {
     EgoLanesHipEngine e(blob, "hip", "fp32");
     try {

@@ -152,7 +152,7 @@ Engine::Engine(int kind, const WeightBlob* blob, int precision, int gpu_id, Engi
   if (frames > 1 && (base || kind < 0 || kind > 3)) throw std::invalid_argument("a batched encoder is a base engine of a scene network kind");
   if (base && (frame_index < 0 || frame_index >= base->frames_)) throw std::invalid_argument("frame_index out of the base engine's range");
   if (!base && frame_index != 0) throw std::invalid_argument("frame_index needs a batched base engine");
-  if ((precision & 15) > 1 || (precision & ~17) != 0) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3 (optionally | VP_WEIGHTS_FP8)");
+  if ((precision & 15) > 1 || (precision & ~(1 | 16 | 32)) != 0) throw std::invalid_argument("precision must be VP_FP16 or VP_FP16X3 (optionally | VP_WEIGHTS_FP8 | VP_PLAN_LATENCY)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     throw std::runtime_error("libvp_hip: no HIP device visible (this library has no CPU fallback)");
@@ -174,7 +174,7 @@ void Engine::construct(int kind, const WeightBlob* blob, int precision, int gpu_
   if (base) {
     if (kind < 0 || base->kind_ < 0) throw std::invalid_argument("shared engines need model kinds on both sides");
     if (base->base_) throw std::invalid_argument("the base of a shared engine must own its whole network");
-    if (base->precision_ != precision || base->gpu_ != gpu_id)
+    if ((base->precision_ & ~32) != (precision & ~32) || base->gpu_ != gpu_id)   // (the plan target is per engine: a head may differ from its base)
       throw std::invalid_argument("shared engine: precision and gpu_id must equal the base engine's");
     stream_ = base->stream_;  // same stream: this engine's launches are ordered after the base engine's
   } else {
@@ -1246,6 +1246,8 @@ void Engine::build_autodrive(const WeightBlob& blob) {
     ad_place_op_ = ops_.size();        // prime_previous() runs the plan up to and including this launch (minus the shift)
     x = add_conv(cp + ".cv2", t, f2.w, f2.b, f2.cout, 1, o2, acts_.back().get());
     if (ops_.size() != ad_place_op_ + 1) throw std::runtime_error("backbone.p5.3.cv2: expected ONE launch (no split-K finish) in front of the head");
+    // the alias store relies on the kernels' store guard `channel < Ncols` with Ncols = round_up(c5, 32) = c5 (checked above): a tile wider than c5 computes
+    // padding rows but never stores them into the neighbouring "previous frame" half (tests/test_gpu_autodrive.py::test_autodrive_stream_of_four_frames)
   }
   // ---- head: 3 x (conv3x3 + SiLU) -> flatten (C-major) -> MLP
   Act* cat = head_cat;

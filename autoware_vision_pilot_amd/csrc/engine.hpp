@@ -213,6 +213,9 @@ class Engine {
   bool host_logits_current() const { return host_logits_valid_; }  // the pinned host logits belong to the LAST pass
   bool split() const { return (precision_ & 15) == 1; }
   bool fp8_weights() const { return (precision_ & 16) != 0; }
+  // kernel plan target of THIS engine (round 6: a creation flag, VP_PLAN_LATENCY; the process-wide developer option VP_PLAN_TARGET still selects it for
+  // every engine created while it is set): the round-4 choices for the CU-time rules of engine_dispatch.cpp
+  bool plan_latency() const;
   // ... kept as e4m3 BYTES in HBM (round 4): AutoDrive engines (BASELINE configs[4]) and the operator entry; a scene network with the flag keeps
   // de-quantised fp16 planes on its LDS-DMA / register-stationary kernels
   bool fp8_storage() const { return fp8_weights() && (kind_ == 4 || kind_ < 0); }

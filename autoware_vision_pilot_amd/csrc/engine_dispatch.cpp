@@ -8,9 +8,37 @@ namespace vp {
 // Round 5: the dispatch rules trade a layer's OWN latency for CU-time where the rest of the frame can use the freed CUs (decode_layer_5 on 100
 // workgroups, the neck's map layers on half the workgroups, the K = 288 ConvTranspose on 128) -- right for a camera with forked heads and for several
 // cameras per GPU, the configurations bench.py measures; a host that runs ONE network on ONE camera, one frame at a time, has nothing to put on the
-// freed CUs and pays 3-7 % of its frame (SceneSeg alone 1.79 -> 1.91 ms).  vp_set_option("VP_PLAN_TARGET", "latency") selects the round-4 choices
-// for engines created afterwards (it shows in vp_version() and changes vp_plan_hash() like every option); default / "throughput": the rules above.
-static bool plan_for_latency() { return dev_option_is("VP_PLAN_TARGET", 'l'); }
+// freed CUs and pays 3-7 % of its frame (SceneSeg alone 1.79 -> 1.91 ms).  The creation flag VP_PLAN_LATENCY (round 6: per ENGINE, OR-ed into vp_create's
+// precision argument) selects the round-4 choices for that engine; the developer option VP_PLAN_TARGET=latency does it for every engine created while it
+// is set (A/B runs of bench.py).  Either way the choice changes vp_plan_hash().  Default / "throughput": the rules above.
+bool Engine::plan_latency() const { return (precision_ & 32) != 0 || dev_option_is("VP_PLAN_TARGET", 'l'); }
+
+// Developer option VP_PLAN_OVERRIDE = "<layer>=<tile>[:<nsplit>];<layer>=..." (round 6, tools/plan_search.py): ONE layer's kernel choice, by name --
+// <layer> matches a launch whose name ENDS with it ("decode_layer_5" = that layer of every network created while the option is set), <tile> is the
+// halo-tile number of a 3x3 convolution (1 / 3: halo kernel 128 / 64 channels, 6 / 7 / 8: pipelined shapes, 11 / 12: map kernels) or the shape (6 / 7)
+// of a composed up-sampling stage, <nsplit> its K slices (absent / 0: the rule's).  The in-frame tuner flips single layers with it; the rules below
+// are what its table (profiles/r06_plan_search.tsv) says.  Part of the plan hash like every option.
+bool plan_override(const std::string& name, int* tile, int* nsplit) {
+  const char* e = dev_option("VP_PLAN_OVERRIDE");
+  if (!e) return false;
+  const std::string s(e);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(';', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string item = s.substr(pos, end - pos);
+    pos = end + 1;
+    const size_t eq = item.rfind('=');
+    if (eq == std::string::npos || eq == 0) continue;
+    const std::string key = item.substr(0, eq), val = item.substr(eq + 1);
+    if (name.size() < key.size() || name.compare(name.size() - key.size(), key.size(), key) != 0) continue;
+    const size_t colon = val.find(':');
+    *tile = std::atoi(val.substr(0, colon).c_str());
+    *nsplit = colon == std::string::npos ? 0 : std::atoi(val.substr(colon + 1).c_str());
+    return true;
+  }
+  return false;
+}
 
 // ------------------------------------------------------------------------------------------- conv planning
 void Engine::choose_conv_cfg(int M, int ncols, int cin_pad, int ks, const ConvOpts& o, PackedConv* pc) {
@@ -216,7 +244,7 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
     // better (profiles/r05_convt_groups_ab.txt: 403.6 / 402.9 -> 408.4, 414.4 / 413.5 -> 418.7 / 419.9 frames/s; 24 groups +0.7 %, the K = 128 case at
     // 192 / 128 groups +-0).  VP_CONVT_RS_GROUPS_K288 / VP_CONVT_RS_GROUPS (developer knobs, one per shape case) override; both are read HERE, at plan
     // time, and are part of the plan hash.
-    if (p.Cin2 > 0 && !plan_for_latency()) p.rs_groups = 32;
+    if (p.Cin2 > 0 && !plan_latency()) p.rs_groups = 32;
     if (const char* e = dev_option(p.Cin2 > 0 ? "VP_CONVT_RS_GROUPS_K288" : "VP_CONVT_RS_GROUPS")) p.rs_groups = std::max(1, std::atoi(e));
     if (p.rs_groups > 0) op.launch += "groups=" + std::to_string(p.rs_groups);
     op.run = [p](hipStream_t st) { return launch_convt_rs(p, st); };
@@ -241,7 +269,15 @@ void Engine::push_conv_op(const std::string& name, const Act* in, const PackedCo
 
 // w: [cout][cin][ks][ks] fp32 (already BN-folded where applicable), b: [cout]
 Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<float>& w, const std::vector<float>& b, int cout, int ks,
-                      const ConvOpts& o, Act* out_override) {
+                      const ConvOpts& o_in, Act* out_override) {
+  ConvOpts o = o_in;
+  {
+    int ot = -1, on = 0;   // one layer's choice forced by name (VP_PLAN_OVERRIDE: the in-frame tuner)
+    if (ks == 3 && o.tile < 0 && plan_override(name, &ot, &on)) {
+      o.tile = 100 + ot;
+      if (on > 0) o.nsplit = on;
+    }
+  }
   const int cin = in->Creal, cin_pad = in->C;
   if (w.size() != (size_t)cout * cin * ks * ks) throw std::runtime_error("conv weight size mismatch: " + name);
   const int cstride = std::max(1, o.stride);
@@ -288,7 +324,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // the halo kernel's lone-wave schedule left them at 0.29-0.31 of peak.  VP_F16_BIG=0 (developer knob, A/B timing): the halo kernel.
       const char* envf = dev_option("VP_F16_BIG");
       if (!split() && !fp8_storage() && o.tile < 0 && !(envf && envf[0] == '0') && halo >= 0 && halo <= 3 && ncols % 128 == 0 && cin_pad % 64 == 0 && !o.logits_out &&
-          !o.in2 && plain && wgs16 >= (dev_option("VP_F16_MIN_WGS") ? std::atoi(dev_option("VP_F16_MIN_WGS")) : 160)) {
+          !o.in2 && plain && wgs16 >= [] { const char* e = dev_option("VP_F16_MIN_WGS"); return e ? std::atoi(e) : 160; }()) {
         // measured per layer (profiles/r04_layers_sceneseg_fp16_big_ab.tsv): the 8-wave shape wins where ONE round of its workgroups covers the
         // map and the K loop is long (decode_layer_4: 79.6 -> 68.9 us, decode_layer_7: 45.6 -> 40.9); with two rounds (decode_layer_6: 75.6 ->
         // 77.2) or two chunks per workgroup (decode_layer_8: 85.8 -> 95.6 / 83.7 on the 4-wave shape) the halo kernel's two workgroups per CU
@@ -306,7 +342,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
         // the remaining CUs the frame rate gains 1.5-3 % at an unchanged one-camera p50 (profiles/r05_dec5_x3w8_ab.txt).  Below 100 (the 40x80 / 20x40
         // maps: 60 / 36 workgroups) the same move LOSES 2 % / 11 %: their launches get 2-4x longer than the rest of the frame can cover.
         const char* envw = dev_option("VP_X3_MIN_WGS");  // developer knob: fewest 16x16 workgroups for the pipelined shapes
-        if (plain && wgs16 >= (envw ? std::atoi(envw) : (plan_for_latency() ? 160 : 100))) halo = want == 6 ? 6 : 7;
+        if (plain && wgs16 >= (envw ? std::atoi(envw) : (plan_latency() ? 160 : 100))) halo = want == 6 ? 6 : 7;
         (void)wgs8;
       }
     }
@@ -338,7 +374,7 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // without waste: parity mode only.  VP_MAP2=0 (developer knob, A/B timing): tile 11 everywhere.
       int min_regions = 1;
       if (const char* e = dev_option("VP_MAP2_MIN_REGIONS")) min_regions = std::atoi(e);   // developer knob: 4 = the 40x80 maps only
-      if (halo == 11 && o.tile < 0 && split() && geom == 1 && !dev_option_is("VP_MAP2", '0') && !(plan_for_latency() && !dev_option_is("VP_MAP2", '1')) &&
+      if (halo == 11 && o.tile < 0 && split() && geom == 1 && !dev_option_is("VP_MAP2", '0') && !(plan_latency() && !dev_option_is("VP_MAP2", '1')) &&
           round_up(ncols, 64) == round_up(ncols, 32) &&
           (in->H / 20) * (in->W / 40) >= min_regions && conv3x3_map2_shape_ok(in->H, in->W, cin_pad, round_up(ncols, 64)))
         halo = 12;

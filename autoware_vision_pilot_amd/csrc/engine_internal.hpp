@@ -17,6 +17,9 @@ namespace vp {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// VP_PLAN_OVERRIDE (engine_dispatch.cpp): one layer's kernel choice forced by name -- the in-frame tuner's lever (tools/plan_search.py)
+bool plan_override(const std::string& name, int* tile, int* nsplit);
+
 constexpr float kBnEps = 1e-5f;  // torchvision efficientnet_b0 BatchNorm2d default
 
 struct Folded {

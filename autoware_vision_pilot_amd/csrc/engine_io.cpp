@@ -214,11 +214,13 @@ int unregister_frame_range(const void* pool) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   for (size_t i = 0; i < g_pools.size(); ++i)
     if (g_pools[i].first == b) {
-      g_pools.erase(g_pools.begin() + i);
+      // unlock first, forget only on success: a refused unlock (a DMA still in flight) leaves the range page-locked AND tracked, so frames from it keep
+      // the one-DMA path and a later retry finds it (erased first, a failure left it locked but unknown)
       if (hipHostUnregister(const_cast<void*>(pool)) != hipSuccess) {
         (void)hipGetLastError();
         return VP_ERR_HIP;
       }
+      g_pools.erase(g_pools.begin() + i);
       return VP_OK;
     }
   return VP_ERR_ARG;

@@ -159,6 +159,13 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   if (w3.size() != (size_t)cout * cm * 9 || b3.size() != (size_t)cout) throw std::runtime_error("conv weight size mismatch: " + name);
   if (skip_in && (ws.size() != (size_t)cm * cs || bs.size() != (size_t)cm)) throw std::runtime_error("skip conv weight size mismatch: " + name);
   if (skip_in && (skip_in->H != in->H * 2 || skip_in->W != in->W * 2)) throw std::runtime_error("skip tensor size mismatch: " + name);
+  // the load-time range guard of every other layer (engine.cpp split_half): a weight of the checkpoint beyond the fp16 range (or non-finite) is refused --
+  // the composed, prescaled product could carry it, the activations it produces would not survive
+  for (const std::vector<float>* v : {&wt, &w3, skip_in ? &ws : nullptr})
+    if (v)
+      for (float x : *v)
+        if (!(std::fabs(x) <= 65504.0f))
+          throw RangeError("weight " + std::to_string(x) + " is outside the fp16 range the matrix pipe carries (|w| <= 65504): re-scale the checkpoint");
   UpconvComposed cw;
   compose_upconv(wt.data(), bt.data(), skip_in ? ws.data() : nullptr, skip_in ? bs.data() : nullptr, w3.data(), b3.data(), cin, cm, cout, cs, &cw);
 
@@ -229,6 +236,13 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   const long long t16 = (long long)((in->H + 15) / 16) * ((in->W + 15) / 16), t8 = (long long)((in->H + 7) / 8) * ((in->W + 15) / 16);
   const int n_co = coutw / 128;
   int sh = shape;
+  {
+    int ot = -1, on = 0;   // this stage's shape / K slices forced by name (VP_PLAN_OVERRIDE: the in-frame tuner)
+    if (sh < 0 && plan_override(name, &ot, &on)) {
+      sh = ot;
+      if (on > 0 && nsplit <= 0) nsplit = on;
+    }
+  }
   if (sh < 0) {
     // Measured per stage on the MI355X (profiles/r06_upconv_shapes.txt, SceneSeg, us, shape 6 / shape 7): 10x20 -> 20x40 67.2 / 73.1, 20x40 -> 40x80
     // 87.8 / 77.5, 40x80 -> 80x160 106.4 / 106.2, 80x160 -> 160x320 119.8 / 125.5, 160x320 -> 320x640 (128 channels) 118.4 / 103.9: the 8-row patches

@@ -506,6 +506,12 @@ int vp_layer_kernel(const vp_engine* e, int i, const char** kernel) {
   *kernel = e->impl->ops()[i].kernel.c_str();
   return VP_OK;
 }
+// launch geometry beyond the tag ("nsplit=4", "groups=32", "nsplit=2 wgs=128"; "" when the tag says it all): what vp_plan_hash mixes in third
+int vp_layer_launch(const vp_engine* e, int i, const char** launch) {
+  if (!e || !e->impl || !launch || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
+  *launch = e->impl->ops()[i].launch.c_str();
+  return VP_OK;
+}
 // FNV-1a over (launch name, kernel tag, launch geometry) of every launch of the plan: two engines with equal hashes run the same kernels with the same
 // split factors / group counts in the same order
 unsigned long long vp_plan_hash(const vp_engine* e) {

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libvp_hip.so")
 
 VP_SCENESEG, VP_SCENE3D, VP_DOMAINSEG, VP_EGOLANES, VP_AUTODRIVE = 0, 1, 2, 3, 4
 VP_WEIGHTS_FP8 = 16
+VP_PLAN_LATENCY = 32  # creation flag: this engine's kernel plan targets one network on one camera, one frame at a time (vp_hip.h)
 VP_FP16, VP_FP16X3 = 0, 1
 VP_BGR8, VP_RGB8 = 0, 1
 VP_PLANES_BGR, VP_PLANES_RGB = 0, 1
@@ -83,6 +84,7 @@ _SIGS = {
     "vp_layer_count": (C.c_int, [_P]),
     "vp_layer_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vp_layer_kernel": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p)]),
+    "vp_layer_launch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p)]),
     "vp_copy_outputs_device": (C.c_int, [_P, _P, _P]),
     "vp_profile_layers": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "vp_layer_flops_executed": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
@@ -261,7 +263,7 @@ def convert_onnx(onnx_path, vpw_path):
 class Engine:
     """Thin RAII wrapper over a vp_engine handle."""
 
-    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None, weights_fp8=False, frames=1, frame_index=None):
+    def __init__(self, kind, weights, precision="fp16", gpu_id=0, base=None, weights_fp8=False, frames=1, frame_index=None, plan_latency=False):
         """base: another Engine -> shared-prefix engine (vp_create_shared): reuses the base engine's backbone (and
         context + neck when their parameters are identical) on the frame the base last processed.
         frames > 1: batched encoder (vp_create_batched) -- preprocess + backbone of `frames` cameras per pass, no head;
@@ -274,6 +276,8 @@ class Engine:
         pr = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         if weights_fp8:
             pr |= VP_WEIGHTS_FP8
+        if plan_latency:
+            pr |= VP_PLAN_LATENCY
         self._base = base  # keeps the base engine alive as long as this one
         path = None if isinstance(weights, (bytes, bytearray, memoryview, np.ndarray)) else (os.fsencode(weights) if weights else b"")
         if frames != 1 or frame_index is not None:
@@ -543,6 +547,15 @@ class Engine:
         for i in range(self._ck(self._lib.vp_layer_count(self._h))):
             k = C.c_char_p()
             self._ck(self._lib.vp_layer_kernel(self._h, i, C.byref(k)))
+            out.append(k.value.decode())
+        return out
+
+    def layer_launches(self):
+        """launch geometry beyond the kernel tag ("nsplit=4", "groups=32", ""), per launch"""
+        out = []
+        for i in range(self._ck(self._lib.vp_layer_count(self._h))):
+            k = C.c_char_p()
+            self._ck(self._lib.vp_layer_launch(self._h, i, C.byref(k)))
             out.append(k.value.decode())
         return out
 

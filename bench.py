@@ -412,6 +412,35 @@ def main():
                     cm.close()
             comms = None
 
+    # ---- the `value` leg on OTHER DATA: the matrix pipe is power- and data-toggle-limited (profiles/r03_mfma_power.txt: all-zero
+    # operands 2.47 PFLOP/s, random ones 1.74), so the frame rate depends on the bits that go through it.  Same protocol, same kernels; the "trained-like"
+    # weight family of the parity sweep (synthetic.make_trained_like_state_dict: BatchNorm scales spread over 10^3 per layer, small variances, sparse
+    # large weights) and a DIFFERENT synthetic frame in every in-flight slot (the default leg carries one frame in all of them).
+    trained_fig = None
+    if world == 1 and not args.no_secondary and args.leg is None and args.workload == "seg+3d":
+        sds_t = [synthetic.make_trained_like_state_dict(kinds[0], SEEDS[kinds[0]])]
+        for k in kinds[1:]:
+            sds_t.append(synthetic.share_backbone(synthetic.make_trained_like_state_dict(k, SEEDS[k]), k, sds_t[0], kinds[0]))
+        blobs_t = [vw.pack_state_dict(sd) for sd in sds_t]
+        cams_t = [Camera(lib, kinds, blobs_t, args.precision, local_rank, synthetic.synthetic_frame(fh, fw, 40 + 7 * i, smooth=(i != 1))) for i in range(nstreams)]
+        for c in cams_t:
+            c.set_fork(False)
+        kt, elt = throughput(cams_t, args.steps, max(3, args.warmup // 3))
+        for c in cams_t:
+            c.close()
+        # ... and the default weights with three different frames (separates the weights' share from the frames')
+        cams_f = [Camera(lib, kinds, blobs, args.precision, local_rank, synthetic.synthetic_frame(fh, fw, 40 + 7 * i, smooth=(i != 1))) for i in range(nstreams)]
+        for c in cams_f:
+            c.set_fork(False)
+        kf, elf = throughput(cams_f, args.steps, max(3, args.warmup // 3))
+        for c in cams_f:
+            c.close()
+        trained_fig = {"value_trained_like": round(kt / elt, 2), "value_three_frames": round(kf / elf, 2),
+                       "value_data_note": "the `value` leg on other operands (the matrix pipe's sustained clock depends on the bits it multiplies): value_trained_like = "
+                                          "trained-like weight family (BatchNorm scales spread over 10^3 per layer, sparse large weights) + a different frame in each "
+                                          "in-flight slot (one of them unsmoothed noise); value_three_frames = the default seeded weights with those three frames; "
+                                          "`value` = default weights, one frame in all slots"}
+
     # ---- FpsTimer-style split of ONE camera's frame (the reference nodes' benchmark: common/benchmark/fps_timer.cpp:37-63, stamps at
     # run_model_node.cpp:66,77,107/180,115/188): wall-clock stamps at the stage boundaries of a synchronous loop, medians.  The stages here
     # are the device-side ones a frame goes through between the host buffers (the nodes' own "preprocess" stamp brackets a cv_bridge copy):
@@ -720,6 +749,8 @@ def main():
             out.update(three)
         if gather_fig is not None:
             out.update(gather_fig)
+        if trained_fig is not None:
+            out.update(trained_fig)
         if h2h is not None:
             out["host_to_host_fps"] = round(h2h["fps"], 2)
             out["host_to_host_p50_ms"] = round(h2h["p50"], 4)

@@ -29,8 +29,11 @@
  *   vp_mask_resized_u8 / vp_depth_resized_f32
  *       cv::resize(mask, INTER_NEAREST) / cv::resize(depth, INTER_LINEAR)  run_model_node.cpp:104,177
  *
- * Threading: one engine per caller thread; an engine owns its HIP stream and every buffer it uses, there is
- * no process-global state, so several engines may live in one process.
+ * Threading: one engine per caller thread; an engine owns its HIP stream, every buffer it uses and its kernel plan, so several
+ * engines may live in one process and be created / driven from different threads concurrently.  Process-wide
+ * state, all of it optional and each behind its own mutex: (1) the developer options of vp_set_option (read when an engine's plan
+ * is built; no production path sets one); (2) the frame pools of vp_register_frames (a table of page-locked ranges, consulted per
+ * upload); (3) RCCL's dlopen handle (vp_comm_*).  Nothing an engine computes depends on another engine's existence.
  * All functions return 0 on success and a negative vp_status on failure; vp_last_error() gives the text.
  */
 #ifndef VP_HIP_H_
@@ -66,7 +69,14 @@ enum vp_precision { VP_FP16 = 0, VP_FP16X3 = 1,
                      * fp16 matrix pipe with fp16 / (hi, lo) activations (fp8 MFMA would quantise the ACTIVATIONS to 3 mantissa bits:
                      * outside the 1e-3 bar).  Layers on the LDS-DMA / register-stationary kernels of the scene networks keep
                      * de-quantised fp16 planes.  vp_weight_bytes reports the split. */
-                    VP_WEIGHTS_FP8 = 16 };
+                    VP_WEIGHTS_FP8 = 16,
+                    /* OR-able flag (round 6): the LATENCY kernel plan for THIS engine.  The default plan spends a layer's own latency where the rest
+                     * of the frame can use the CUs it frees (forked heads on one camera, several cameras per GPU); a host that runs ONE network on
+                     * ONE camera, one frame at a time, has nothing to put there and gets 3-7 % of its frame back with this flag.  Per engine: a
+                     * process that holds several engines (VisionPilot/production_release/main.cpp:505-535: EgoLanes beside AutoSpeed / AutoSteer)
+                     * chooses for each; results differ from the default plan's only in fp32 summation order; vp_plan_hash() tells the plans apart.
+                     * A shared-prefix engine may choose differently from its base. */
+                    VP_PLAN_LATENCY = 32 };
 
 enum vp_pixel_format { VP_BGR8 = 0, VP_RGB8 = 1 };
 /* Plane order of the network input: BGR planes = middleware "common" backends (onnx_runtime_backend.cpp:47-57),
@@ -293,6 +303,7 @@ int vp_comm_fetch(vp_comm* c, vp_engine* e, const void** host, size_t* record_by
 int vp_layer_count(const vp_engine* e);
 int vp_layer_info(const vp_engine* e, int i, const char** name, double* flops, double* bytes);
 int vp_layer_kernel(const vp_engine* e, int i, const char** kernel_tag);        /* kernel instantiation of launch i */
+int vp_layer_launch(const vp_engine* e, int i, const char** launch);            /* its geometry beyond the tag: "nsplit=4", "groups=32", "" */
 /* vp_layer_info's flops count the REFERENCE formulation of the layer(s) a launch computes (one multiply-add per product of the
  * reference's operators).  A composed up-sampling stage (round 6: ConvTranspose [+ skip link] -> 3x3 multiplied out at load) executes 0.40-0.51x
  * of that; this returns what the launch executes (= vp_layer_info's figure for every other launch). */
@@ -371,9 +382,8 @@ int vp_op_upconv(int gpu_id, const float* in, int cin, int h, int w, const float
  * created AFTERWARDS; value NULL removes a key; an unknown key is VP_ERR_ARG.  No option is needed in production and none changes a
  * result beyond fp32 summation order.  vp_version() lists every option in force; vp_plan_hash() = FNV-1a over (launch name, kernel
  * tag, launch geometry) of an engine's plan, so a host (bench.py does) can record exactly which kernels ran.
- * ONE key is meant for hosts (round 5): "VP_PLAN_TARGET" = "latency" | "throughput" (default).  The default plan spends a layer's own latency where
- * the rest of the frame can use the CUs it frees (forked heads on one camera, several cameras per GPU: +3.6 % frames/s); a host that runs ONE
- * network on ONE camera, one frame at a time, has nothing to put there and gets its 3-7 % back with "latency" (SceneSeg alone: p50 1.91 -> 1.8 ms). */
+ * "VP_PLAN_TARGET" = "latency" | "throughput" (anything else: VP_ERR_ARG) selects the kernel plan target for EVERY engine created while it is set --
+ * a developer knob for A/B runs since round 6; hosts choose per engine with the creation flag VP_PLAN_LATENCY (vp_precision). */
 int vp_set_option(const char* key, const char* value);
 const char* vp_get_option(const char* key);       /* NULL when unset */
 void vp_clear_options(void);

@@ -38,10 +38,10 @@ def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, vp_opts, mtype, kind
     raw = np.fromfile(out, dtype=np.uint8)
     frame = raw[:720 * 1280 * 3].reshape(720, 1280, 3)
     rest = raw[720 * 1280 * 3:]
-    # the adapters ask for the latency plan (one backend = one network on one camera: hip_backend.hpp, round 5); the same plan here, so the
-    # comparison stays bit for bit (the default plan differs from it in fp32 summation order only)
-    vp_opts.setenv("VP_PLAN_TARGET", "latency")
-    eng = lib.Engine(kind, blob.read_bytes(), precision="fp16x3")
+    # the B1 adapter creates its engine with the latency plan (one backend = one network on one camera: hip_backend.hpp; a creation flag since round 6),
+    # the B2 adapter with the default plan (the production app runs it beside other engines); the same plan here, so the comparison stays bit for bit
+    # (the plans differ in fp32 summation order only)
+    eng = lib.Engine(kind, blob.read_bytes(), precision="fp16x3", plan_latency=(kind != "egolanes"))
     eng.set_input_format(lib.VP_BGR8, lib.VP_PLANES_RGB if kind == "egolanes" else lib.VP_PLANES_BGR)
     eng.set_norm_form(lib.VP_NORM_OPENCV)   # the adapters compute the C++ front-ends' q * fl(1/255) (hip_backend.hpp, egolanes_hip_engine.hpp)
     eng.infer(frame)
@@ -59,6 +59,22 @@ def test_adapter_frame_matches_c_abi(tmp_path, state_dicts, vp_opts, mtype, kind
     else:
         assert np.array_equal(tail.view(np.float32).reshape(80, 160), pre_post.egolanes_planes(lg)[0])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_adapters_constructed_concurrently_keep_their_own_plan(tmp_path, state_dicts):
+    """a B1 backend and a B2 engine constructed concurrently from two threads of one process -- each on its own kernel plan
+    (creation flag VP_PLAN_LATENCY / default), no process-wide option touched (adapter_check 'threads' checks the plan hashes against plain vp_create)."""
+    from autoware_vision_pilot_amd import weights as vw
+
+    _build()
+    seg, ego, out = tmp_path / "seg.vpw", tmp_path / "ego.vpw", tmp_path / "out.bin"
+    seg.write_bytes(vw.pack_state_dict(state_dicts("sceneseg")))
+    ego.write_bytes(vw.pack_state_dict(state_dicts("egolanes")))
+    r = subprocess.run([BIN, "threads", str(seg), str(out), str(ego)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    h = np.fromfile(out, dtype=np.uint64)
+    assert len(h) >= 2 and h[-1] != h[-2] and h[-1] != 0
 
 
 @pytest.mark.gpu

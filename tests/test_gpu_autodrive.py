@@ -93,6 +93,27 @@ def test_autodrive_parity_fp16x3(setup, fp8):
         eng.close()
 
 
+def test_autodrive_stream_of_four_frames(setup):
+    """the shift -> cv2 (alias store into the 512-channel head input) -> head ordering over a stream LONGER than infer_pair's: four
+    different frames through plain infer(); every frame's outputs against the oracle on (frame n-1, frame n) -- frame 0 pairs with itself."""
+    from autoware_vision_pilot_amd import lib
+
+    g, frames, sd, blob = setup
+    stream = frames + [pre_post.synthetic_frame(1080, 1920, 77), pre_post.synthetic_frame(1080, 1920, 78)]
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xs = [torch.from_numpy(pre_post.preprocess(f, input_is_bgr=True, planes_rgb=True, out_h=512, out_w=1024, resize="pil_bilinear")) for f in stream]
+    eng = lib.Engine("autodrive", blob, precision="fp16x3")
+    try:
+        for n, f in enumerate(stream):
+            eng.infer(f)
+            got = eng.logits().reshape(3).copy()
+            with torch.no_grad():
+                ref = np.array([float(v) for v in autodrive.forward(sdt, xs[max(n - 1, 0)], xs[n])], dtype=np.float32)
+            assert np.abs(got - ref).max() <= 1e-3, f"frame {n}: got {got}, oracle {ref}"
+    finally:
+        eng.close()
+
+
 def test_autodrive_fp16_close(setup):
     from autoware_vision_pilot_amd import lib
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -48,6 +49,39 @@ __global__ __launch_bounds__(512, 2) void mfma16_loop(const h8* src, float* out,
   float s = 0;
   for (int k = 0; k < 8; ++k)
     for (int e = 0; e < 4; ++e) s += c[k][e];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
+}
+
+
+// Round 6: the parity mode's product as the pipelined kernels issue it -- per accumulator tile lo*hi, hi*lo, hi*hi, three
+// dependent MFMAs back to back -- with (hi, lo) planes of random fp32 values, the `lo` planes' mantissas truncated to KEEP explicit bits (10 = as
+// split today).  If the sustained rate on 256 CUs rises as the low planes carry fewer toggling bits, truncating them at load / in the epilogues buys
+// clock on a power-limited pipe (product error 2^-(11 + KEEP + 1) relative instead of 2^-22).  src: [a_hi | a_lo | b_hi | b_lo] x 512 lanes.
+__global__ __launch_bounds__(512, 2) void mfma_x3_loop(const h8* src, float* out, long long* clk, int iters) {
+  const h8 ah = src[threadIdx.x], al = src[512 + threadIdx.x], bh = src[1024 + threadIdx.x], bl = src[1536 + threadIdx.x];
+  f16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  const long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c2, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, c3, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, c3, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, c3, 0, 0, 0);
+  }
+  const long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  float s = 0;
+  for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
   out[blockIdx.x * 512 + threadIdx.x] = s;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     clk[0] = t1 - t0;
@@ -171,6 +205,46 @@ int main() {
       lds_row<3>(src, out, clk, e0, e1, n);
       lds_row<4>(src, out, clk, e0, e1, n);
     }
+  }
+  {
+    // round 6: (hi, lo) planes, low planes truncated to KEEP explicit mantissa bits; -1 = low planes all zero (control: two of three MFMAs multiply by 0)
+    h8* src4;
+    hipMalloc(&src4, 2048 * sizeof(h8));
+    std::vector<_Float16> q(2048 * 8);
+    std::printf("# parity-mode product (lo*hi, hi*lo, hi*hi per accumulator), random fp32 values split into (hi, lo) fp16 planes, low planes truncated\n"
+                "# keep_bits\tactive_CUs\tms\tTFLOP/s_issued\tTFLOP/s_per_CU\tshader_clock_MHz\n");
+    for (int keep : {10, 8, 6, 5, 4, 2, 0, -1}) {
+      unsigned s = 777;
+      for (int plane = 0; plane < 2; ++plane)        // a, b
+        for (int i = 0; i < 512 * 8; ++i) {
+          s = s * 1664525u + 1013904223u;
+          const float x = ((int)(s >> 8) % 2000001 - 1000000) * 1e-6f;
+          const _Float16 hi = (_Float16)x;
+          _Float16 lo = (_Float16)(x - (float)hi);
+          unsigned short bits;
+          std::memcpy(&bits, &lo, 2);
+          if (keep < 0) bits = 0;
+          else bits &= (unsigned short)~((1u << (10 - keep)) - 1u);
+          std::memcpy(&lo, &bits, 2);
+          q[(size_t)(plane * 2 + 0) * 512 * 8 + i] = hi;
+          q[(size_t)(plane * 2 + 1) * 512 * 8 + i] = lo;
+        }
+      hipMemcpy(src4, q.data(), q.size() * 2, hipMemcpyHostToDevice);
+      for (int n : {64, 256}) {
+        const int iters = 14000;
+        hipLaunchKernelGGL(mfma_x3_loop, dim3(n), dim3(512), 0, 0, src4, out, clk, 1400);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(mfma_x3_loop, dim3(n), dim3(512), 0, 0, src4, out, clk, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flop = (double)n * 8 * iters * 12 * 32 * 32 * 16 * 2;
+        std::printf("%d\t%d\t%.3f\t%.1f\t%.2f\t%.0f\n", keep, n, ms, flop / ms * 1e-9, flop / ms * 1e-9 / n, (double)clk[0] / clk[1] * 100.0);
+      }
+    }
+    hipFree(src4);
   }
   return 0;
 }
