@@ -90,6 +90,19 @@ Folded fold_conv_bn(const WeightBlob& blob, const std::string& p) { return fold_
 // common_layers.py:5-14 Conv: `conv` (no bias) + `norm` (BatchNorm2d eps 1e-3)
 Folded fold_conv_norm(const WeightBlob& blob, const std::string& p) { return fold_conv(blob, p + ".conv", p + ".norm", 1e-3f); }
 
+// Experiment knob VP_WLO_KEEP_BITS (round 6; read once per engine in Engine::construct): explicit mantissa bits the LOW planes of
+// the weights keep (10 = all; fewer toggling bits through a power-limited matrix pipe: profiles/r06_mfma_power_lo_trunc.txt).  Default: untouched.
+std::atomic<int> g_wlo_keep{10};
+half_t truncate_lo(half_t lo) {
+  const int keep = g_wlo_keep.load(std::memory_order_relaxed);
+  if (keep >= 10) return lo;
+  unsigned short bits;
+  std::memcpy(&bits, &lo, 2);
+  bits &= (unsigned short)~((1u << (10 - std::max(0, keep))) - 1u);
+  std::memcpy(&lo, &bits, 2);
+  return lo;
+}
+
 void split_half(float v, float pre, half_t* hi, half_t* lo) {
   // Both precision modes carry weights on fp16 planes: a folded weight beyond the fp16 range (or non-finite) is refused at load (the
   // prescale could carry it, the activations it produces would not survive).  Small weights: see prescale_exp (engine_internal.hpp).
@@ -97,7 +110,7 @@ void split_half(float v, float pre, half_t* hi, half_t* lo) {
   const float x = v * pre;
   const half_t h = (half_t)x;
   *hi = h;
-  *lo = (half_t)(x - (float)h);
+  *lo = truncate_lo((half_t)(x - (float)h));
 }
 
 uint8_t e4m3_encode(float q) {
@@ -170,6 +183,10 @@ void Engine::construct(int kind, const WeightBlob* blob, int precision, int gpu_
   {  // process-unique plan epochs: a combined graph keyed on (engine address, epoch) can never match a later engine at the same address
     static std::atomic<unsigned long long> next_epoch{1};
     plan_epoch_ = next_epoch.fetch_add(1ull << 32);
+  }
+  {
+    const char* e = dev_option("VP_WLO_KEEP_BITS");
+    g_wlo_keep.store(e ? std::atoi(e) : 10, std::memory_order_relaxed);
   }
   if (base) {
     if (kind < 0 || base->kind_ < 0) throw std::invalid_argument("shared engines need model kinds on both sides");

@@ -32,6 +32,7 @@ Folded fold_conv_norm(const WeightBlob& blob, const std::string& p);  // common_
 // (hi, lo) fp16 planes of v * pre, pre = the weight row's power-of-two prescale (an exact product); throws RangeError when v itself is
 // beyond the fp16 range or not finite
 void split_half(float v, float pre, half_t* hi, half_t* lo);
+half_t truncate_lo(half_t lo);   // experiment knob VP_WLO_KEEP_BITS (engine.cpp); identity by default
 // Per-output-row power-of-two PRESCALE of a weight matrix (round 4).  Unscaled, lo = fp16(w - fp16(w)) of a typical decoder weight is an fp16
 // SUBNORMAL (kaiming std 0.013 at K = 11520: |lo| <= 4e-6, spacing 6e-8) and the pair carries ~17 bits instead of 22.  With s such that the
 // row maximum lands in [2^13, 2^14) every weight within 2^-10 of the row maximum keeps both planes normal, and any smaller one is still exact

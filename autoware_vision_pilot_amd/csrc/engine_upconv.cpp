@@ -28,7 +28,7 @@ inline void split_half_d(double v, double pre, half_t* hi, half_t* lo) {
   if (!(std::fabs(x) <= 65504.0)) throw RangeError("composed up-sampling weight " + std::to_string(v) + " is outside the fp16 range the matrix pipe carries: re-scale the checkpoint");
   const half_t h = (half_t)x;
   *hi = h;
-  *lo = (half_t)(x - (double)h);
+  *lo = truncate_lo((half_t)(x - (double)h));
 }
 
 }  // namespace
@@ -147,13 +147,15 @@ void Engine::compose_upconv(const float* wt, const float* bt, const float* ws, c
       }
 }
 
-bool Engine::upconv_wanted() const { return split() && !fp8_storage() && !dev_option_is("VP_UPCONV", '0'); }
+// both precision modes since the fp16 form of the kernel exists (X1, kernels_upconv.hip); VP_UPCONV=0 (developer knob): the three-operator plan
+bool Engine::upconv_wanted() const { return !fp8_storage() && !dev_option_is("VP_UPCONV", '0') && (split() || !dev_option_is("VP_UPCONV_F16", '0')); }
 
 // One composed stage as ONE op of the plan.  in: low-resolution tensor (H x W x cin), skip_in: 2H x 2W x cs or null.
 Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_in, const std::vector<float>& wt, const std::vector<float>& bt,
                         const std::vector<float>& ws, const std::vector<float>& bs, const std::vector<float>& w3, const std::vector<float>& b3, int cm,
                         int cout, int act, int shape, int nsplit, const std::string& out_name) {
-  if (!split()) throw std::invalid_argument("composed up-sampling stages exist in the parity mode (VP_FP16X3) only: " + name);
+  const bool x1 = !split();   // VP_FP16 engines: 64-channel chunks, the halves in the two weight planes (kernels_upconv.hip X1)
+  if (x1 && in->C % 64 != 0) throw std::invalid_argument("composed up-sampling stage in an fp16 engine: input channels a multiple of 64: " + name);
   const int cin = in->Creal, cin_pad = in->C, cs = skip_in ? skip_in->Creal : 0, cs_pad = skip_in ? skip_in->C : 0;
   if (wt.size() != (size_t)cin * cm * 4 || bt.size() != (size_t)cm) throw std::runtime_error("convT weight size mismatch: " + name);
   if (w3.size() != (size_t)cout * cm * 9 || b3.size() != (size_t)cout) throw std::runtime_error("conv weight size mismatch: " + name);
@@ -170,7 +172,9 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   compose_upconv(wt.data(), bt.data(), skip_in ? ws.data() : nullptr, skip_in ? bs.data() : nullptr, w3.data(), b3.data(), cin, cm, cout, cs, &cw);
 
   const int ncols = round_up(cout, 32), coutw = round_up(ncols, 128);
-  const int S = upconv_steps(cin_pad, cs_pad), n_chunks = upconv_chunks(cin_pad, cs_pad);
+  // the chunk list's channel counts: fp16 engines walk 64-channel chunks = descriptors over halved counts (the skip tensor rounded up to 64 first)
+  const int cin_v = x1 ? cin_pad / 2 : cin_pad, cs_v = x1 ? round_up(cs_pad, 64) / 2 : cs_pad, chm = x1 ? 2 : 1, chunk_w = x1 ? 64 : 32;
+  const int S = upconv_steps(cin_v, cs_v), n_chunks = upconv_chunks(cin_v, cs_v);
   std::vector<half_t> hi((size_t)4 * S * coutw * 32, (half_t)0.0f), lo(hi.size(), (half_t)0.0f);
   std::vector<float> post((size_t)4 * coutw, 1.0f), bias((size_t)9 * coutw, 0.0f);
   for (int k = 0; k < 9; ++k)
@@ -192,7 +196,7 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
       const double pre = std::ldexp(1.0, sexp);
       post[(size_t)phase * coutw + co] = std::ldexp(1.0f, -sexp);
       for (int c = 0; c < n_chunks; ++c) {
-        const UpconvChunk d = upconv_chunk(c, py, px, cin_pad, cs_pad);
+        const UpconvChunk d = upconv_chunk(c, py, px, cin_v, cs_v);
         const int creal = d.skip ? cs : cin;
         for (int k = 0; k < d.nt; ++k) {
           const int a = d.a0 + (d.nb == 2 ? (k >> 1) : k), b = d.b0 + (d.nb == 2 ? (k & 1) : 0);
@@ -203,9 +207,15 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
           } else {
             row = cw.wx.data() + ((size_t)(phase * 4 + a * 2 + b) * cout + co) * cin;
           }
-          for (int i = 0; i < 32 && d.ch0 + i < creal; ++i) {
-            const size_t dst = upconv_pack_index(phase, d.step0 + k, co, i, S, coutw);
-            split_half_d(row[d.ch0 + i], pre, &hi[dst], &lo[dst]);
+          for (int i = 0; i < chunk_w && chm * d.ch0 + i < creal; ++i) {
+            const size_t dst = upconv_pack_index(phase, d.step0 + k, co, i & 31, S, coutw);
+            if (x1) {   // one fp16 value per weight; plane = which half of the 64-channel chunk
+              half_t h, l;
+              split_half_d(row[chm * d.ch0 + i], pre, &h, &l);
+              (i >> 5 ? lo : hi)[dst] = h;
+            } else {
+              split_half_d(row[d.ch0 + i], pre, &hi[dst], &lo[dst]);
+            }
           }
         }
       }
@@ -214,9 +224,9 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   Act* out = new_act(out_name.empty() ? name : out_name, cout, in->H * 2, in->W * 2);
   UpconvParams p{};
   p.in_hi = in->hi;
-  p.in_lo = in->lo;
+  p.in_lo = x1 ? nullptr : in->lo;
   p.sk_hi = skip_in ? skip_in->hi : nullptr;
-  p.sk_lo = skip_in ? skip_in->lo : nullptr;
+  p.sk_lo = (skip_in && !x1) ? skip_in->lo : nullptr;
   p.H = in->H;
   p.W = in->W;
   p.Cin = cin_pad;
@@ -230,8 +240,8 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   p.Ncols = ncols;
   p.Cstore = out->C;
   p.out_hi = out->hi;
-  p.out_lo = out->lo;
-  p.act = act;
+  p.out_lo = x1 ? nullptr : out->lo;
+  p.act = (x1 && act == ACT_GELU) ? ACT_GELU_F16 : act;   // VP_FP16: reduced-instruction activation (common.hpp), as push_conv_op
   // shape and K slices: the dispatch rule (measured, profiles/r06_*), or the caller's choice
   const long long t16 = (long long)((in->H + 15) / 16) * ((in->W + 15) / 16), t8 = (long long)((in->H + 7) / 8) * ((in->W + 15) / 16);
   const int n_co = coutw / 128;
@@ -270,14 +280,14 @@ Act* Engine::add_upconv(const std::string& name, const Act* in, const Act* skip_
   if (!upconv_supported(p, sh)) throw std::invalid_argument("composed up-sampling stage: shape not covered: " + name);
   Op op;
   op.name = name;
-  op.kernel = std::string("upconv_x3") + (sh == 6 ? "w8<co128,px256>" : "w4<co128,px128>") + (ns > 1 ? "+splitk" : "");
+  op.kernel = std::string(x1 ? "upconv_x1" : "upconv_x3") + (sh == 6 ? "w8<co128,px256" : "w4<co128,px128") + (x1 ? ",k64>" : ">") + (ns > 1 ? "+splitk" : "");
   if (ns > 1) op.launch = "nsplit=" + std::to_string(ns);
   const double M2 = 4.0 * in->H * in->W;
   // algorithmic work of the REFERENCE formulation (ConvTranspose on input pixels x 4 taps, 1x1 skip and 3x3 on output pixels) ...
   op.flops = 2.0 * (M2 * cin * cm + M2 * cs * cm + M2 * 9.0 * cm * cout);
   // ... and what this launch executes (real channels): 4 taps of x and 9 of the skip tensor per output pixel
   op.flops_executed = 2.0 * M2 * cout * (4.0 * cin + 9.0 * cs);
-  op.bytes = 4.0 * (M2 / 4 * cin + M2 * cs + M2 * cout) + 4.0 * cout * (16.0 * cin + 9.0 * cs);
+  op.bytes = (x1 ? 2.0 : 4.0) * ((M2 / 4 * cin + M2 * cs + M2 * cout) + cout * (16.0 * cin + 9.0 * cs));
   op.run = [p, sh](hipStream_t st) { return launch_upconv(p, sh, st); };
   ops_.push_back(std::move(op));
   return out;

@@ -65,7 +65,12 @@ __device__ __forceinline__ int bias_class(int m, int H2, int W2) {
     else { VP_WAIT_VMCNT(0); }                    \
   } while (0)
 
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, bool SPLITK>
+// X1 (round 6): the VP_FP16 engines' form, as kernels_conv3x3_x3.hip's: a chunk covers SIXTY-FOUR channels and the two "planes" of every LDS image are its
+// 32-channel halves (plane 0 = channels [64c, 64c + 32), plane 1 = [64c + 32, 64c + 64) of the ONE fp16 tensor; w_hi / w_lo carry the halves of the composed
+// weights likewise), two MFMAs per fragment pair, one output plane.  The chunk list is upconv_chunk's over HALVED channel counts (Cin / 2, Cs rounded up to
+// 64 and halved; ch0 doubled); the last chunk of a skip tensor of 32 or 96 channels (the 20x40, 160x320 and 320x640 stages) fills plane 0 only -- plane 1
+// of that chunk is zeroed at the halo store and its weights are zero (half of those steps' MFMAs multiply zeros: up to 18 % of a stage's steps, accepted).
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, bool SPLITK, bool X1 = false>
 __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const UpconvParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
@@ -109,7 +114,15 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
   const int tyi = tile_px / tiles_x, txi = tile_px - tyi * tiles_x;
   const int y0 = tyi * TH, x0 = txi * TW;
   const int co0 = tile_co * CO_TILE;
-  const int n_chunks = upconv_chunks(p.Cin, p.Cs);
+  // channel counts the chunk list is built on: X1 chunks are 64 channels wide = two 32-channel halves
+  const int CinV = X1 ? p.Cin >> 1 : p.Cin, CsV = X1 ? ((p.Cs + 63) >> 6) << 5 : p.Cs;
+  constexpr int CHM = X1 ? 2 : 1;   // real channel offset of a chunk = CHM * its descriptor's ch0
+  const half_t* const in_p1 = X1 ? p.in_hi + 32 : p.in_lo;   // second plane of the halo image
+  const half_t* const sk_p1 = X1 ? p.sk_hi + 32 : p.sk_lo;
+  // X1: the LAST 64-channel chunk of a skip tensor whose (padded) channel count is an odd multiple of 32 has no second half: plane 1 of that chunk is
+  // fetched from the first half's address (never past the tensor) and zeroed at the halo store
+#define VP_SK_DEAD1(D) (X1 && (D).skip && CHM * (D).ch0 + 32 >= p.Cs)
+  const int n_chunks = upconv_chunks(CinV, CsV);
   int cA = 0, cB = n_chunks;
   if constexpr (SPLITK) {
     cA = (int)(((long long)n_chunks * zsplit) / p.nsplit);
@@ -147,9 +160,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
   }
   // weight tiles by LDS-DMA: a step's tile plane is CO_TILE x 64 B = W_BYTES contiguous bytes in global memory, already in LDS image order; wave v
   // copies the 1 KiB pieces v, v + NW, ... of both planes.  Steps of one phase are consecutive tiles.
-  const UpconvChunk dA = upconv_chunk(cA, py, px, p.Cin, p.Cs);
-  const int S = (cB < n_chunks ? upconv_chunk(cB, py, px, p.Cin, p.Cs).step0 : upconv_steps(p.Cin, p.Cs)) - dA.step0;   // steps of THIS slice
-  const size_t w_goff0 = ((size_t)phase * upconv_steps(p.Cin, p.Cs) + dA.step0) * w_step + co0 * 32 + wave * 512 + lane * 8;
+  const UpconvChunk dA = upconv_chunk(cA, py, px, CinV, CsV);
+  const int S = (cB < n_chunks ? upconv_chunk(cB, py, px, CinV, CsV).step0 : upconv_steps(CinV, CsV)) - dA.step0;   // steps of THIS slice
+  const size_t w_goff0 = ((size_t)phase * upconv_steps(CinV, CsV) + dA.step0) * w_step + co0 * 32 + wave * 512 + lane * 8;
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -181,8 +194,8 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 #define VP_LOAD_H(D)                                                                         \
   {                                                                                          \
     const half_t* sh_ = (D).skip ? p.sk_hi : p.in_hi;                                        \
-    const half_t* sl_ = (D).skip ? p.sk_lo : p.in_lo;                                        \
-    const int add_ = (D).skip ? ((D).qy * 2 * p.W + (D).qx) * p.Cs + (D).ch0 : (D).ch0;      \
+    const half_t* sl_ = (D).skip ? (VP_SK_DEAD1(D) ? p.sk_hi : sk_p1) : in_p1;               \
+    const int add_ = (D).skip ? ((D).qy * 2 * p.W + (D).qx) * p.Cs + CHM * (D).ch0 : CHM * (D).ch0; \
     _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) {                                      \
       const int g_ = (D).skip ? h_gs[pc] : h_gx[pc];                                         \
       const int o_ = (g_ >= 0 ? g_ + add_ : 0);                                              \
@@ -190,12 +203,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
       rh_lo[pc] = *reinterpret_cast<const u32x4*>(sl_ + o_);                                 \
     }                                                                                        \
   }
-#define VP_STORE_H(BUF)                                                                      \
+  // DEAD1: plane 1 of the chunk in the registers does not exist (X1: a chunk of a 32-channel skip tensor): zeros
+#define VP_STORE_H(BUF, DEAD1)                                                               \
   _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) {                                        \
     if (tid + NTH * pc < HCHUNKS) {                                                          \
       char* dst_ = halo_base + (BUF) * PL * HSTRIDE + h_lds0 + pc * (NTH / 4) * ROWB;        \
       *reinterpret_cast<u32x4*>(dst_) = h_gx[pc] >= 0 ? rh_hi[pc] : zero4;                   \
-      *reinterpret_cast<u32x4*>(dst_ + HSTRIDE) = h_gx[pc] >= 0 ? rh_lo[pc] : zero4;         \
+      *reinterpret_cast<u32x4*>(dst_ + HSTRIDE) = (h_gx[pc] >= 0 && !(DEAD1)) ? rh_lo[pc] : zero4; \
     }                                                                                        \
   }
 #define VP_READ_FRAGS(SET, WPTR, HPTR, TAPOFS)                                               \
@@ -215,6 +229,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 #define VP_MFMA_RANGE(SET, Q0, Q1)                                                           \
   _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
     const int i = q_ / NT, j = q_ % NT;                                                      \
+    if constexpr (X1) { /* the planes are K halves: a0 . b0 + a1 . b1 */                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
+      continue;                                                                              \
+    }                                                                                        \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);  \
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 
   // ---- prologue: halo(chunk cA) and weight tiles 0, 1 -> LDS; halo(chunk cA + 1) -> registers
   VP_LOAD_H(dA)
-  VP_STORE_H(0)
+  VP_STORE_H(0, VP_SK_DEAD1(dA))
   VP_DMA_W(0, 0)
   if (S > 1) VP_DMA_W(PL * W_BYTES, 1)
   VP_WAIT_VMCNT(0);
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
   UpconvChunk d = dA;                                            // current chunk
   UpconvChunk dn = dA;                                           // next chunk (valid while c + 1 < cB)
   if (cA + 1 < cB) {
-    dn = upconv_chunk(cA + 1, py, px, p.Cin, p.Cs);
+    dn = upconv_chunk(cA + 1, py, px, CinV, CsV);
     VP_LOAD_H(dn)
   }
   VP_READ_FRAGS(0, w_base, halo_base, VP_TAP_OFS(d, 0))
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     /* HDB: the next chunk's halo goes to the OTHER halo image at the head of this chunk's last step, BEFORE this step's DMA is issued (the compiler */ \
     /* guards the registers with s_waitcnt vmcnt(0): at this point the only other thing in flight is the weight tile requested one step ago, which */ \
     /* this step's barrier needs anyway -- kernels_conv3x3_x3.hip, tap 3)                                                                          */ \
-    if constexpr (HDB && ((KIND) == 1 || (KIND) == 2)) { VP_STORE_H(hb ^ 1) }                \
+    if constexpr (HDB && ((KIND) == 1 || (KIND) == 2)) { VP_STORE_H(hb ^ 1, VP_SK_DEAD1(dn)) }   \
     /* weight tile of step s + 2 -> the buffer step s - 1 read last (its barrier has passed); must land before the NEXT step's barrier */ \
     if (s + 2 < S) VP_DMA_W(w_fre, s + 2)                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     __builtin_amdgcn_sched_barrier(0);  /* keep the prefetch AHEAD of the MFMAs (the scheduler sinks it otherwise) */ \
     UpconvChunk dnn = dn;                                                                    \
     if constexpr (HDB && (KIND) == 1) {                                                      \
-      dnn = upconv_chunk(c + 2, py, px, p.Cin, p.Cs);                                        \
+      dnn = upconv_chunk(c + 2, py, px, CinV, CsV);                                        \
       VP_LOAD_H(dnn)                                                                         \
     }                                                                                        \
     VP_MFMA_RANGE(0, MT * NT / 2, MT * NT)                                                   \
@@ -282,10 +301,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     if constexpr (!HDB && ((KIND) == 1 || (KIND) == 2)) {                                    \
       /* single halo image: every wave has completed its last read of chunk c (the barrier's lgkmcnt(0)) -- the next chunk's pieces go over it, a */ \
       /* second barrier opens it, the registers are refilled with chunk c + 2                                                                    */ \
-      VP_STORE_H(0)                                                                          \
+      VP_STORE_H(0, VP_SK_DEAD1(dn))                                                         \
       VP_LDS_BARRIER();                                                                      \
       if constexpr ((KIND) == 1) {                                                           \
-        dnn = upconv_chunk(c + 2, py, px, p.Cin, p.Cs);                                      \
+        dnn = upconv_chunk(c + 2, py, px, CinV, CsV);                                      \
         VP_LOAD_H(dnn)                                                                       \
       }                                                                                      \
     }                                                                                        \
@@ -324,6 +343,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
   while (t + 1 < d.nt) VP_STEP(0, false)   // the last chunk (the step in front of it refilled nothing)
   VP_STEP(3, false)
 #undef VP_STEP
+#undef VP_SK_DEAD1
 #undef VP_TAP_OFS
 #undef VP_MFMA_RANGE
 #undef VP_READ_FRAGS
@@ -353,6 +373,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     // ---- register epilogue: bias (by border class) + activation + (hi, lo) split, both planes staged as [pixel][CO_TILE] fp16, 16-byte stores
     constexpr int PITCH = CO_TILE * 2 + 16, STAGE_PLANE = PX * PITCH;
     static_assert(PL * STAGE_PLANE <= NHB * PL * HSTRIDE + 3 * PL * W_BYTES, "stage fits the main buffers");
+    // (X1: one output plane -- the lo half of the stage and out_lo stay untouched)
     // bias (by the pixel's border class) and prescale vectors of this lane's accumulators: ALL requested before the barrier, so their round trips
     // overlap each other and the barrier instead of one load -> wait -> GELU chain per register group
     const float* const wsc = p.wscale + (size_t)phase * p.CoutW + co0;
@@ -386,10 +407,10 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
           for (int r = 0; r < 4; ++r) {
             const float x = apply_act(fmaf(acc[i][j][4 * g + r], sc[i][g][r], bb[j][i][g][r]), ACT);
             h[r] = (half_t)x;
-            l[r] = (half_t)(x - (float)h[r]);
+            if constexpr (!X1) l[r] = (half_t)(x - (float)h[r]);
           }
           *reinterpret_cast<h4_t*>(row + g * 16) = h;
-          *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
+          if constexpr (!X1) *reinterpret_cast<h4_t*>(row + STAGE_PLANE + g * 16) = l;
         }
       }
     }
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
       if (m < 0) continue;
       const size_t o = (size_t)m * p.Cstore + co;
       *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
-      *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
+      if constexpr (!X1) *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
     }
   }
 }
@@ -441,31 +462,33 @@ __global__ __launch_bounds__(256) void upconv_finish_kernel(const UpconvParams p
   }
   const size_t o = (size_t)m * p.Cstore + co;
   *reinterpret_cast<h8_t*>(p.out_hi + o) = hi;
-  *reinterpret_cast<h8_t*>(p.out_lo + o) = lo;
+  if (p.out_lo) *reinterpret_cast<h8_t*>(p.out_lo + o) = lo;   // (VP_FP16 engines: one plane)
 }
 
 bool upconv_supported(const UpconvParams& p, int shape) {
   if (shape != 6 && shape != 7) return false;
-  if (!(p.in_hi && p.in_lo && p.w_hi && p.w_lo && p.bias && p.wscale && p.out_hi && p.out_lo)) return false;
-  if (p.H < 1 || p.W < 1 || p.Cin < 32 || p.Cin % 32 != 0 || p.Cs % 32 != 0 || p.Cs < 0) return false;
-  if (p.Cs > 0 && !(p.sk_hi && p.sk_lo)) return false;
+  const bool x1 = p.in_lo == nullptr;   // VP_FP16 engines: one plane per tensor, 64-channel chunks (template parameter X1)
+  if (!(p.in_hi && p.w_hi && p.w_lo && p.bias && p.wscale && p.out_hi && (x1 ? p.out_lo == nullptr : p.out_lo != nullptr))) return false;
+  if (p.H < 1 || p.W < 1 || p.Cin < (x1 ? 64 : 32) || p.Cin % (x1 ? 64 : 32) != 0 || p.Cs % 32 != 0 || p.Cs < 0) return false;
+  if (p.Cs > 0 && !(p.sk_hi && (x1 ? p.sk_lo == nullptr : p.sk_lo != nullptr))) return false;
   if (p.CoutW % 128 != 0 || p.Ncols % 8 != 0 || p.Ncols > p.CoutW || p.Cstore < p.Ncols) return false;
-  if (!(p.act == ACT_GELU || p.act == ACT_NONE)) return false;
-  if (p.nsplit < 1 || p.nsplit > upconv_chunks(p.Cin, p.Cs)) return false;
+  if (!(p.act == (x1 ? ACT_GELU_F16 : ACT_GELU) || p.act == ACT_NONE)) return false;
+  if (p.nsplit < 1 || p.nsplit > (x1 ? upconv_chunks(p.Cin >> 1, ((p.Cs + 63) >> 6) << 5) : upconv_chunks(p.Cin, p.Cs))) return false;
   if (p.nsplit > 1 && !p.partial) return false;
   // element offsets are 32-bit in the kernel
   if ((long long)p.H * p.W * p.Cin >= (1ll << 31) || 4ll * p.H * p.W * std::max(p.Cs, 1) >= (1ll << 31) || 4ll * p.H * p.W * p.Cstore >= (1ll << 31)) return false;
   return true;
 }
 
-template <int TH, int WPX, bool HDB>
+template <int TH, int WPX, bool HDB, bool X1>
 static hipError_t launch_upconv_cfg(const UpconvParams& p, hipStream_t st) {
   constexpr int CO = 128;
   constexpr int lds = (HDB ? 2 : 1) * 2 * ((TH + 2) * 18 * 80) + 6 * (CO * 64);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  const bool gelu = p.act == ACT_GELU, sk = p.nsplit > 1;
-  auto k = sk ? upconv_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, true>
-              : (gelu ? upconv_x3_kernel<CO, TH, 2, WPX, HDB, ACT_GELU, false> : upconv_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, false>);
+  constexpr int GELU = X1 ? ACT_GELU_F16 : ACT_GELU;
+  const bool gelu = p.act == GELU, sk = p.nsplit > 1;
+  auto k = sk ? upconv_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, true, X1>
+              : (gelu ? upconv_x3_kernel<CO, TH, 2, WPX, HDB, GELU, false, X1> : upconv_x3_kernel<CO, TH, 2, WPX, HDB, ACT_NONE, false, X1>);
   static LdsAttrOnce attr_once[3];
   if (hipError_t e = set_max_dynamic_lds(attr_once[sk ? 2 : gelu], reinterpret_cast<const void*>(k), lds); e != hipSuccess) return e;
   dim3 grid(((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * 4 * (p.CoutW / CO) * p.nsplit);
@@ -479,8 +502,12 @@ static hipError_t launch_upconv_cfg(const UpconvParams& p, hipStream_t st) {
 
 hipError_t launch_upconv(const UpconvParams& p, int shape, hipStream_t st) {
   if (!upconv_supported(p, shape)) return hipErrorInvalidValue;
-  if (shape == 6) return launch_upconv_cfg<16, 4, true>(p, st);
-  return launch_upconv_cfg<8, 2, false>(p, st);
+  if (p.in_lo == nullptr) {   // VP_FP16 engines
+    if (shape == 6) return launch_upconv_cfg<16, 4, true, true>(p, st);
+    return launch_upconv_cfg<8, 2, false, true>(p, st);
+  }
+  if (shape == 6) return launch_upconv_cfg<16, 4, true, false>(p, st);
+  return launch_upconv_cfg<8, 2, false, false>(p, st);
 }
 
 // ------------------------------------------------------------------------------------------------ weight composition (load time)

@@ -25,7 +25,7 @@ std::deque<std::string> g_versions; // retired texts stay alive: a pointer vp_ve
 const char* const kKeys[] = {"VP_MBCONV_FUSE", "VP_MBCONV_BACK", "VP_PROJ_SPLIT", "VP_FUSE_DECODE", "VP_AUTOTUNE", "VP_HEAD_CONV", "VP_CONVT_RS",
                              "VP_CONV3X3", "VP_HEAD_TILE5", "VP_X3_TILE", "VP_X3_MIN_WGS", "VP_MAP3X3", "VP_NSPLIT_PCT", "VP_NSPLIT_FORCE", "VP_X3_C64",
                              "VP_GEMM_DMA", "VP_GEMM_DMA_NSPLIT", "VP_CONVT_TILE", "VP_CONVT_BK", "VP_FUSE_SKIP", "VP_CONVT_RS_GROUPS", "VP_F16_BIG",
-                             "VP_CTX3", "VP_MAP_TAPSPLIT", "VP_ATTN_BLOCK", "VP_F16_MAP", "VP_MAP_NSPLIT_PCT", "VP_MAP2", "VP_MAP2_SLOTS", "VP_X3_T16", "VP_MAP2_CAP_MB", "VP_MAP2_MIN_REGIONS", "VP_CTX_FUSE", "VP_MAP_MAX_M", "VP_F16_MIN_WGS", "VP_CONVT_RS_GROUPS_K288", "VP_PLAN_TARGET", "VP_UPCONV", "VP_UPCONV_SHAPE", "VP_UPCONV_NSPLIT", "VP_PLAN_OVERRIDE"};
+                             "VP_CTX3", "VP_MAP_TAPSPLIT", "VP_ATTN_BLOCK", "VP_F16_MAP", "VP_MAP_NSPLIT_PCT", "VP_MAP2", "VP_MAP2_SLOTS", "VP_X3_T16", "VP_MAP2_CAP_MB", "VP_MAP2_MIN_REGIONS", "VP_CTX_FUSE", "VP_MAP_MAX_M", "VP_F16_MIN_WGS", "VP_CONVT_RS_GROUPS_K288", "VP_PLAN_TARGET", "VP_UPCONV", "VP_UPCONV_SHAPE", "VP_UPCONV_NSPLIT", "VP_PLAN_OVERRIDE", "VP_WLO_KEEP_BITS", "VP_UPCONV_F16"};
 }  // namespace
 
 const char* dev_option(const char* key) {

@@ -689,14 +689,18 @@ int vp_compose_upconv(int gpu_id, const float* wt, const float* bt, const float*
 }
 
 int vp_op_upconv(int gpu_id, const float* in, int cin, int h, int w, const float* skip, int cs, const float* wt, const float* bt, const float* ws,
-                 const float* bs, const float* w3, const float* b3, int cm, int cout, int act, int shape, int nsplit, float* out, char* err,
+                 const float* bs, const float* w3, const float* b3, int cm, int cout, int act, int shape, int nsplit, int precision, float* out, char* err,
                  size_t err_len) {
+  if (precision != VP_FP16 && precision != VP_FP16X3) {
+    set_err(err, err_len, "precision must be VP_FP16 or VP_FP16X3");
+    return VP_ERR_ARG;
+  }
   if (!in || !wt || !bt || !w3 || !b3 || !out || cin < 1 || cm < 1 || cout < 1 || h < 1 || w < 1 || cs < 0 || (cs > 0 && (!skip || !ws || !bs))) {
     set_err(err, err_len, "bad argument");
     return VP_ERR_ARG;
   }
   try {
-    vp::Engine g(-1, nullptr, VP_FP16X3, gpu_id);
+    vp::Engine g(-1, nullptr, precision, gpu_id);
     vp::Act* a = g.new_act("in", cin, h, w);
     g.upload_act(a, in);
     vp::Act* sk = nullptr;

@@ -94,7 +94,7 @@ _SIGS = {
     "vp_op_conv2d": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_int, C.c_int, C.c_int, _P, C.c_char_p, C.c_size_t]),
     "vp_compose_upconv": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_char_p, C.c_size_t]),
-    "vp_op_upconv": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P,
+    "vp_op_upconv": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                C.c_char_p, C.c_size_t]),
     "vp_detect_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "vp_detect_destroy": (None, [_P]),
@@ -703,8 +703,9 @@ def compose_upconv(wt, bt, w3, b3, ws=None, bs=None, gpu_id=0):
     return wx, wsk, bias
 
 
-def op_upconv(x, wt, bt, w3, b3, skip=None, ws=None, bs=None, act=1, shape=-1, nsplit=0, gpu_id=0):
-    """vp_op_upconv: one composed up-sampling stage through the engine's kernel (parity mode): x [cin][h][w], skip [cs][2h][2w] -> [cout][2h][2w]."""
+def op_upconv(x, wt, bt, w3, b3, skip=None, ws=None, bs=None, act=1, shape=-1, nsplit=0, gpu_id=0, precision="fp16x3"):
+    """vp_op_upconv: one composed up-sampling stage through the engine's kernel (parity mode, or the fp16 engines' form of it): x [cin][h][w],
+    skip [cs][2h][2w] -> [cout][2h][2w]."""
     lib = load()
     x, wt, bt, w3, b3, skip, ws, bs = (_f32(v) for v in (x, wt, bt, w3, b3, skip, ws, bs))
     cin, h, w = x.shape
@@ -714,7 +715,7 @@ def op_upconv(x, wt, bt, w3, b3, skip=None, ws=None, bs=None, act=1, shape=-1, n
     out = np.empty((cout, 2 * h, 2 * w), dtype=np.float32)
     err = C.create_string_buffer(512)
     rc = lib.vp_op_upconv(gpu_id, _ptr(x), cin, h, w, _ptr(skip) if cs else None, cs, _ptr(wt), _ptr(bt), _ptr(ws) if cs else None,
-                          _ptr(bs) if cs else None, _ptr(w3), _ptr(b3), cm, cout, act, shape, nsplit, _ptr(out), err, len(err))
+                          _ptr(bs) if cs else None, _ptr(w3), _ptr(b3), cm, cout, act, shape, nsplit, PRECISIONS[precision], _ptr(out), err, len(err))
     if rc != 0:
         raise VpError(f"vp_op_upconv failed ({rc}): {err.value.decode(errors='replace')}")
     return out

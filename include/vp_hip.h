@@ -368,13 +368,14 @@ int vp_op_conv2d(int gpu_id, int precision, int mode, const float* in, int cin, 
  *   wx [4 phases py*2+px][4 taps a*2+b][cout][cin]: out(2y+py, 2x+px) += wx . x(y+py-1+a, x+px-1+b) (zero outside the low-resolution map);
  *   wsk [9 taps ty*3+tx][cout][cs]: plain 3x3 / pad 1 convolution of the skip tensor;
  *   bias [9 classes rc*3+cc][cout]: rc / cc = 0 first, 1 inner, 2 last row / column of the OUTPUT map.
- * vp_op_upconv: the whole stage through the engine's kernel (VP_FP16X3): in [cin][h][w], skip [cs][2h][2w] -> out [cout][2h][2w], fp32 CHW host
- *   buffers; act 0 none, 1 GELU; shape 6 / 7 or -1 (dispatch rule); nsplit K slices or 0 (dispatch rule). */
+ * vp_op_upconv: the whole stage through the engine's kernel: in [cin][h][w], skip [cs][2h][2w] -> out [cout][2h][2w], fp32 CHW host
+ *   buffers; act 0 none, 1 GELU; shape 6 / 7 or -1 (dispatch rule); nsplit K slices or 0 (dispatch rule); precision VP_FP16X3 (parity mode) or
+ *   VP_FP16 (the fp16 engines' form: 64-channel chunks, one MFMA per product; input channels a multiple of 64 after padding). */
 int vp_compose_upconv(int gpu_id, const float* wt, const float* bt, const float* ws, const float* bs, const float* w3, const float* b3, int cin, int cm,
                       int cout, int cs, double* wx, double* wsk, double* bias, char* err, size_t err_len);
 int vp_op_upconv(int gpu_id, const float* in, int cin, int h, int w, const float* skip, int cs, const float* wt, const float* bt, const float* ws,
-                 const float* bs, const float* w3, const float* b3, int cm, int cout, int act, int shape, int nsplit, float* out, char* err,
-                 size_t err_len);
+                 const float* bs, const float* w3, const float* b3, int cm, int cout, int act, int shape, int nsplit, int precision, float* out,
+                 char* err, size_t err_len);
 
 /* ---- developer options ------------------------------------------------------------------------------------
  * The library NEVER reads the environment.  The dispatch rules' developer knobs (A/B timing of a kernel against the one it replaced,

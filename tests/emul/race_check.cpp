@@ -66,6 +66,18 @@ static int conv_logits(int precision, int cin, int cout, int h, int w) {  // vp_
   return rc;
 }
 
+// composed up-sampling stage (kernels_upconv.hip) through vp_op_upconv: halo images handed over at a chunk's last step (double-buffered on the 8-wave
+// shape, rewritten between two barriers on the 4-wave shape), three weight buffers by LDS-DMA, K slices + finish kernel; precision 0 = the fp16 engines' form
+static int upconv(int precision, int cin, int cm, int cout, int cs, int h, int w, int shape, int nsplit) {
+  std::vector<float> x = rnd((size_t)cin * h * w), wt = rnd((size_t)cin * cm * 4, 0.1f), bt = rnd(cm, 0.1f), w3 = rnd((size_t)cout * cm * 9, 0.1f), b3 = rnd(cout, 0.1f);
+  std::vector<float> sk = rnd((size_t)std::max(cs, 1) * 4 * h * w), ws = rnd((size_t)cm * std::max(cs, 1), 0.1f), bs = rnd(cm, 0.1f), out((size_t)cout * 4 * h * w);
+  char err[256] = {0};
+  const int rc = vp_op_upconv(0, x.data(), cin, h, w, cs ? sk.data() : nullptr, cs, wt.data(), bt.data(), cs ? ws.data() : nullptr, cs ? bs.data() : nullptr, w3.data(),
+                              b3.data(), cm, cout, 1, shape, nsplit, precision, out.data(), err, sizeof err);
+  if (rc) std::fprintf(stderr, "vp_op_upconv failed: %s\n", err);
+  return rc;
+}
+
 __global__ void canary_kernel(float* out) {
   __shared__ float lds[64];
   lds[threadIdx.x] = (float)threadIdx.x;
@@ -128,6 +140,13 @@ int main(int argc, char** argv) {
     // LDS-DMA GEMM (kernels_gemm_dma.hip): three-stage ring, one barrier per K step, patches over the ring; 256 pixels = two tiles, 8 K steps
     if (precision == 1 || quick) bad |= conv(1, 1, 256, 256, 8, quick ? 16 : 32, 2, 0, 6, -1, quick ? 2 : 1);
     // a head's logits convolution (kernels_head.hip) is reached through mode 3 only: see conv_logits below
+  }
+  if (!skip_conv) {  // composed up-sampling stages, both precisions: x chunks + the four skip classes (4 / 2 / 2 / 1 taps), both shapes, K slices
+    bad |= upconv(1, 64, 16, 128, 24, 9, 17, 6, 1);
+    bad |= upconv(1, 64, 16, 128, 24, 5, 17, 7, quick ? 2 : 1);
+    bad |= upconv(0, 128, 16, 128, 24, 9, 17, 6, 1);        // fp16 form: 64-channel chunks, the skip chunk's second half dead
+    bad |= upconv(0, 128, 16, 128, 72, 5, 17, 7, 2);        // ... 96 skip channels: one full + one half-dead chunk per class, K slices
+    if (!quick) bad |= upconv(1, 96, 16, 128, 0, 17, 19, 6, 1);
   }
   if (!skip_conv) {  // heads' logits convolution: DMA halo + zero page, slab reduction through LDS (128 channels)
     bad |= conv_logits(1, 128, 3, quick ? 5 : 9, quick ? 17 : 33);

@@ -213,8 +213,8 @@ def test_scene_network_end_to_end_on_cpu(emu_lib, kind, seed):
 
 
 def test_sceneseg_fp16_benchmark_mode_on_cpu(emu_lib):
-    """The precision bench.py reports (VP_FP16: single fp16 plane, fp16 activation variants, register epilogues, the
-    register-stationary ConvTranspose) through the whole SceneSeg network on the CPU; the GPU test's bar: max |error| within
+    """The precision bench.py reports (VP_FP16: single fp16 plane, fp16 activation variants, register epilogues, the composed
+    up-sampling stages on 64-channel chunks) through the whole SceneSeg network on the CPU; the GPU test's bar: max |error| within
     3e-2 of the largest logit, >= 99.5 % class agreement."""
     import torch
 
@@ -232,7 +232,9 @@ def test_sceneseg_fp16_benchmark_mode_on_cpu(emu_lib):
         assert float(np.abs(got - ref).max() / np.abs(ref).max()) <= 3e-2
         assert float((got.argmax(0) == ref.argmax(0)).mean()) >= 0.995
         kernels = {eng_k for eng_k in _layer_kernels(eng)}
-        assert any(k.startswith("convt_rs") for k in kernels) and any("regepi" in k for k in kernels) and any(k.startswith("head_conv3x3") for k in kernels)   # the fp16-only paths ran
+        # the fp16-only paths ran (round 6: the composed up-sampling stages' fp16 form took the ConvTranspose launches' place)
+        assert any(k.startswith("upconv_x1") for k in kernels) and any("regepi" in k for k in kernels) and any(k.startswith("head_conv3x3") for k in kernels)
+        assert not any(k.startswith("convt_rs") or k.startswith("gemm_dma") for k in kernels)
     finally:
         eng.close()
 
@@ -277,6 +279,12 @@ def test_range_guard_is_loud_on_cpu(emu_lib):
         eng.close()
 
 
+def vw_blob(kind, seed):
+    from autoware_vision_pilot_amd import synthetic, weights as vw
+
+    return vw.pack_state_dict(synthetic.make_state_dict(kind, seed))
+
+
 def test_kernel_plan_is_the_committed_one(emu_lib, monkeypatch):
     """WHICH kernel every layer of every network gets (vp_layer_kernel), both precisions, against tests/golden/kernel_plan.json: the
     dispatch rules of engine.cpp (tile shapes, split-K, the pipelined / register-stationary / LDS-DMA kernels, fused decode) are host
@@ -309,9 +317,18 @@ def test_kernel_plan_is_the_committed_one(emu_lib, monkeypatch):
     assert seg["SceneSegHead.upsample_layer_4+decode_layer_8"] == "upconv_x3w4<co128,px128>"
     assert seg["SceneNeck.decode_layer_5"] == "conv3x3_x3w8<co128,px256>" and seg["SceneSegHead.decode_layer_9"] == "conv3x3_x3w4<co64,px128>"
     assert seg["SceneSegHead.decode_layer_10"].startswith("head_conv3x3<c64,x3>+decode")
-    # the fp16 engines (and VP_UPCONV=0) keep the three-op form of rounds 1-5
+    # the fp16 engines take the same composed stages on 64-channel chunks (X1 form of the kernel); VP_UPCONV=0 / VP_UPCONV_F16=0 keep the three-op form
     seg16 = dict(tuple(r) for r in got["sceneseg/fp16"])
-    assert seg16["SceneSegHead.upsample_layer_4"] == "convt_rs<k128,x1>" and "SceneNeck.upsample_layer_2+skip_link_layer_2" in seg16
+    assert seg16["SceneSegHead.upsample_layer_4+decode_layer_8"].startswith("upconv_x1w") and "SceneSegHead.upsample_layer_4" not in seg16
+    assert seg16["SceneNeck.upsample_layer_2+skip_link_layer_2+decode_layer_4"].startswith("upconv_x1w")
+    emu_lib.set_option("VP_UPCONV_F16", "0")
+    try:
+        e16 = emu_lib.Engine("sceneseg", vw_blob("sceneseg", 0), precision="fp16")
+        k16 = dict(zip([n for n, _, _ in e16.layers()], e16.layer_kernels()))
+        e16.close()
+    finally:
+        emu_lib.clear_options()
+    assert k16["SceneSegHead.upsample_layer_4"] == "convt_rs<k128,x1>" and "SceneNeck.upsample_layer_2+skip_link_layer_2" in k16
     # the same knobs through vp_set_option DO change the plan -- and its hash, which bench.py records
     from autoware_vision_pilot_amd import synthetic, weights as vw
 

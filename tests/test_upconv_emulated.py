@@ -90,11 +90,12 @@ def test_compose_upconv_equals_the_three_op_form_in_fp64(emu_lib, cin, cm, cout,
     assert np.abs(got - ref).max() <= 1e-12 * max(1.0, float(np.abs(ref).max()))
 
 
-def _op_case(lib, seed, cin, cm, cout, cs, h, w, act, cfgs, tol=2e-5):
+def _op_case(lib, seed, cin, cm, cout, cs, h, w, act, cfgs, tol=2e-5, precision="fp16x3"):
     t = make_stage(np.random.default_rng(seed), cin, cm, cout, cs, h, w)
     ref = three_op_fp64(t, act)
     for shape, nsplit in cfgs:
-        got = lib.op_upconv(t["x"], t["wt"], t["bt"], t["w3"], t["b3"], skip=t["skip"], ws=t["ws"], bs=t["bs"], act=act, shape=shape, nsplit=nsplit)
+        got = lib.op_upconv(t["x"], t["wt"], t["bt"], t["w3"], t["b3"], skip=t["skip"], ws=t["ws"], bs=t["bs"], act=act, shape=shape, nsplit=nsplit,
+                            precision=precision)
         assert got.shape == ref.shape
         err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
         assert err <= tol, f"shape {shape} nsplit {nsplit}: err {err:.3e}"
@@ -112,3 +113,20 @@ def test_upconv_kernel_with_skip(emu_lib):
     _op_case(emu_lib, 3, 32, 48, 128, 24, 8, 16, 1, [(6, 1), (7, 1)])
     _op_case(emu_lib, 4, 64, 64, 200, 40, 10, 20, 1, [(6, 1), (7, 1), (6, 3), (7, 5)])
     _op_case(emu_lib, 5, 40, 24, 128, 33, 17, 18, 0, [(6, 1), (7, 1), (7, 10)])
+
+
+def test_upconv_kernel_fp16_form(emu_lib):
+    """the VP_FP16 engines' form of the kernel (X1: 64-channel chunks, the chunk's halves in the two planes, two MFMAs per fragment pair, one output
+    plane): no skip tensor; skip tensors of 32 channels (plane 1 of their chunks is dead), 64 and 128 channels (one and two full chunks per class), 96 channels (one full + one half-dead chunk);
+    K slices; both shapes.  Tolerance: fp16 operands (2^-11 each) -- the regression class of the fp16 engines, not the parity bar."""
+    _op_case(emu_lib, 11, 64, 32, 128, 0, 9, 17, 1, [(6, 1), (7, 1)], tol=6e-3, precision="fp16")
+    _op_case(emu_lib, 12, 128, 48, 128, 24, 8, 16, 1, [(6, 1), (7, 1), (7, 2)], tol=6e-3, precision="fp16")
+    _op_case(emu_lib, 13, 64, 64, 200, 40, 10, 20, 0, [(6, 1), (7, 3)], tol=6e-3, precision="fp16")
+    _op_case(emu_lib, 14, 120, 40, 128, 112, 5, 9, 1, [(7, 1), (6, 4)], tol=6e-3, precision="fp16")
+    _op_case(emu_lib, 16, 64, 40, 128, 80, 7, 11, 1, [(6, 1), (7, 3)], tol=6e-3, precision="fp16")   # 80 -> 96 channels: one full chunk + one half-dead chunk
+
+
+def test_upconv_fp16_form_refuses_what_it_cannot_tile(emu_lib):
+    t = make_stage(np.random.default_rng(15), 32, 32, 128, 0, 8, 16)   # 32 input channels pad to 32: not a multiple of the fp16 form's 64-channel chunk
+    with pytest.raises(emu_lib.VpError, match="multiple of 64"):
+        emu_lib.op_upconv(t["x"], t["wt"], t["bt"], t["w3"], t["b3"], precision="fp16")
