@@ -324,13 +324,21 @@ Act* Engine::add_conv(const std::string& name, const Act* in, const std::vector<
       // the halo kernel's lone-wave schedule left them at 0.29-0.31 of peak.  VP_F16_BIG=0 (developer knob, A/B timing): the halo kernel.
       const char* envf = dev_option("VP_F16_BIG");
       if (!split() && !fp8_storage() && o.tile < 0 && !(envf && envf[0] == '0') && halo >= 0 && halo <= 3 && ncols % 128 == 0 && cin_pad % 64 == 0 && !o.logits_out &&
-          !o.in2 && plain && wgs16 >= [] { const char* e = dev_option("VP_F16_MIN_WGS"); return e ? std::atoi(e) : 160; }()) {
+          !o.in2 && plain && wgs16 >= [this] { const char* e = dev_option("VP_F16_MIN_WGS"); return e ? std::atoi(e) : (plan_latency() ? 160 : 36); }()) {
         // measured per layer (profiles/r04_layers_sceneseg_fp16_big_ab.tsv): the 8-wave shape wins where ONE round of its workgroups covers the
         // map and the K loop is long (decode_layer_4: 79.6 -> 68.9 us, decode_layer_7: 45.6 -> 40.9); with two rounds (decode_layer_6: 75.6 ->
         // 77.2) or two chunks per workgroup (decode_layer_8: 85.8 -> 95.6 / 83.7 on the 4-wave shape) the halo kernel's two workgroups per CU
         // do as well or better.  VP_F16_BIG=6 / 7 forces a shape on every eligible layer.
+        // Round 6, throughput plan: the in-frame search (tools/plan_search.py --precision fp16, profiles/r06_plan_search_fp16.tsv) moves the smaller layers
+        // onto the pipelined shapes as well, as round 5 did for the parity mode -- fewer, fatter workgroups leave CUs to the other cameras: decode_layer_5
+        // (100 tiles of 16x16 x 128 channels) and decode_layer_3 (60) on the 8-wave shape (+0.5 % / +1.1 % frames/s on the metric pair), decode_layer_1
+        // (20x40 map, 36 tiles) on the 4-wave shape in four K slices (+0.6 %); together 1040 -> 1067 frames/s.  The latency plan keeps the 160-tile floor.
         if (envf) halo = std::atoi(envf) == 6 ? 6 : 7;
-        else if (wgs16 <= 256 && cin_pad >= 256) halo = 6;
+        else if (wgs16 <= 256 && cin_pad >= 256 && wgs16 >= 60) halo = 6;
+        else if (wgs16 < 60 && cin_pad >= 256 && in->H * in->W <= 800 && o.nsplit <= 0) {
+          halo = 7;
+          o.nsplit = 4;
+        }
       }
       if (split() && o.tile < 0 && want != 0 && (halo == 1 || halo == 3) && ncols % 128 == 0 && !o.logits_out && !o.in2) {
         // Smaller layers stay on the halo kernel's 64-channel tiles (two workgroups per CU, twice the workgroup count): measured

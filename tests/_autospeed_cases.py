@@ -40,8 +40,8 @@ def raw_tensor(num_boxes, num_classes, seed, net=640, clusters=40, p_obj=0.12):
 
 
 def untie(raw, seed):
-    """Every positive class score made distinct, NaNs removed: the reference's std::sort is not stable, so tensors pinned against the
-    reference's own binary (oracle/pin_autospeed_ref.py, tests/golden/autospeed_ref.npz) must not contain equal confidences."""
+    """Every positive class score made distinct, NaNs removed: the reference's std::sort is not stable (onnxruntime_engine.cpp:252), so on such
+    tensors the order of the detections is fully specified by the reference's code -- the TIE_FREE_CASES below."""
     rng = np.random.default_rng(seed)
     r = raw.copy()
     pos = r[4:] > 0.1
@@ -50,6 +50,16 @@ def untie(raw, seed):
     best = r[4:].max(axis=0)
     assert len(np.unique(best[best > 0.1])) == int((best > 0.1).sum())
     return r
+
+
+# tie-free decode + NMS cases: (boxes, classes, tensor seed, untie seed), (conf threshold, IoU threshold, scale, pad_x, pad_y, orig_w, orig_h) -- 80 % of
+# a YOLO head at three letterbox geometries, one class, a threshold above every score (nothing kept), an IoU threshold of 0, a tiny tensor
+TIE_FREE_CASES = [((2100, 4, 300, 0), (0.25, 0.45, 0.5, 0, 140, 1280, 720)), ((2100, 8, 301, 1), (0.5, 0.3, 0.3333333432674408, 0, 140, 1920, 1080)),
+                  ((700, 1, 302, 2), (0.05, 0.45, 1.0, 0, 0, 640, 640)), ((2100, 4, 303, 3), (1.5, 0.45, 0.5, 0, 140, 1280, 720)),
+                  ((37, 3, 304, 4), (0.1, 0.0, 1.3141683340072632, 122, 0, 301, 487)), ((2100, 4, 305, 5), (0.2, 0.6, 0.3333333432674408, 0, 140, 1920, 1080))]
+# letterbox geometry the reference's expressions give (scale = min(W/w, H/h) in fp32, truncated new size, integer-division pads): (h, w) -> (scale, pad_x, pad_y)
+LETTERBOX_GEOMETRY = [((720, 1280), (0.5, 0, 140)), ((1080, 1920), (0.3333333432674408, 0, 140)), ((487, 301), (1.3141683340072632, 122, 0)),
+                      ((640, 640), (1.0, 0, 0)), ((33, 900), (0.7111111283302307, 0, 308)), ((641, 1283), (0.4988308548927307, 0, 160))]
 
 
 def check(det_got, n_got, raw, conf, iou, geom, orig_w, orig_h, cap=None):

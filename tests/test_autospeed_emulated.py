@@ -124,18 +124,14 @@ def test_postprocess_needs_geometry(emu_lib):
         det.close()
 
 
-def test_decode_nms_equals_the_reference_binarys_outputs_emulated(emu_lib):
-    """As tests/test_gpu_autospeed.py::test_decode_nms_equals_the_reference_binarys_outputs, through the CPU emulation."""
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "autospeed_ref.npz"))
+def test_decode_nms_tie_free_cases_emulated(emu_lib):
+    """As tests/test_gpu_autospeed.py::test_decode_nms_tie_free_cases, through the CPU emulation."""
     det = emu_lib.Detector(max_boxes=2100, max_attrs=12)
     try:
-        for i in range(sum(1 for k in g.files if k.endswith("_det"))):
-            nb, nc, seed, useed = (int(v) for v in g[f"post{i}_spec"])
+        for (nb, nc, seed, useed), (conf, iou, scale, px, py, ow, oh) in cases.TIE_FREE_CASES:
             raw = cases.untie(cases.raw_tensor(nb, nc, seed), useed)
-            conf, iou, scale, px, py, ow, oh = g[f"post{i}_args"]
             det.set_letterbox(np.float32(scale), int(px), int(py), int(ow), int(oh))
             got, n = det.postprocess(raw, conf, iou)
-            want = g[f"post{i}_det"]
-            assert n == len(want) and np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
+            cases.check(got, n, raw, np.float32(conf), np.float32(iou), (np.float32(scale), int(px), int(py)), int(ow), int(oh))
     finally:
         det.close()

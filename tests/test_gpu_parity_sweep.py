@@ -32,7 +32,13 @@ FRAMES = [((720, 1280), 101, True), ((720, 1280), 102, False), ((360, 640), 103,
           ((1080, 1920), 105, True), ((1080, 1920), 106, False), ((720, 1280), 107, True), ((487, 651), 108, False)]
 ROWS = []
 JUDGED = []
-K64 = 3.0   # below the ratio of the unit round-offs (fp16x3 2^-22 : fp32 2^-24 = 4); measured worst 1.86, most passes < 1 (module docstring)
+# Round 6: 3.0 -> 2.5.  Measured worst 1.87 (DomainSeg weight seed 23), most passes < 1.  Where those rows lose their bits is known by layer
+# (profiles/r06_where_the_bits_go.tsv: engine / reference stays 0.7-1.2 through encoder stage 5 and grows to ~2 across the MBConv blocks of stages
+# 6-7 -- K = 672 / 1152 projections on 10x20 maps -- and does not grow further in the decoder) and by cause (profiles/r06_pair_storage_study.tsv: the
+# (hi, lo) storage format ALONE, in exact arithmetic, is 3-4x an fp32 storage's distance; r06_mfma_accum.txt: the matrix pipe's accumulation is as
+# good as a scalar fp32 loop's; r06_deep_encoder_bits_ab.txt: the fast SiLU and the depthwise tensor's subnormal low plane are 10-25 % each).
+# The ratio of the unit round-offs (2^-23 : 2^-25) is 4.
+K64 = 2.5
 
 
 def _decode(kind, logits):

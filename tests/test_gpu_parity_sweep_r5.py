@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 FRAMES = [((720, 1280), 101, True), ((720, 1280), 102, False), ((360, 640), 103, True), ((360, 640), 104, False),
           ((1080, 1920), 105, True), ((1080, 1920), 106, False), ((720, 1280), 107, True), ((487, 651), 108, False)]
 ROWS = []
-K64 = 3.0
+K64 = 2.5   # round 6: 3.0 -> 2.5 (tests/test_gpu_parity_sweep.py has the reasoning and the by-layer record)
 
 
 def _decode(kind, logits):

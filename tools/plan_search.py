@@ -173,13 +173,15 @@ def main():
         for tok in members[0][2].split():
             if tok.startswith("nsplit="):
                 ns_now = int(tok[7:])
-        if k.startswith("upconv"):
+        if "splitk" in members[0][1] and not k.startswith("upconv") and "map" not in k:   # a split halo-kernel layer (the fp16 engines' neck): K slices and the map kernel
+            cands = [f"{t}:{ns}" for t in (3, 1) for ns in sorted({max(1, ns_now // 2), ns_now, ns_now * 2})] + ["11", "7:2", "7:4", "6"]
+        elif k.startswith("upconv"):
             small = fl < 6e10 and ns_now > 1      # K slices only where the rule splits today (the 20x40 / 40x80 stages): elsewhere the fp32 slabs are 100+ MB
             cands = [f"{sh}:{ns}" for sh in (6, 7) for ns in (sorted({1, 2, 3, 4, 6, ns_now}) if small else [1])]
         elif "map" in k:
-            cands = [f"{t}:{ns}" for t in (11, 12) for ns in sorted({max(1, ns_now // 2), ns_now, ns_now * 2, max(1, ns_now * 3 // 2)})] + ["3", "7:2", "7:4"]
+            cands = [f"{t}:{ns}" for t in ((11, 12) if args.precision == "fp16x3" else (11,)) for ns in sorted({max(1, ns_now // 2), ns_now, ns_now * 2, max(1, ns_now * 3 // 2)})] + ["3", "7:2", "7:4"]
         else:
-            cands = ["1", "3", "6", "7", "8"] + ([f"7:{n}" for n in (2,)] if fl < 4e10 else [])
+            cands = (["1", "3", "6", "7", "8"] if args.precision == "fp16x3" else ["0", "1", "2", "3", "6", "7", "8"]) + ([f"7:{n}" for n in (2,)] if fl < 4e10 else [])
         decisions.append(dict(names=names, suffix=suf, kernel=members[0][1], launch=members[0][2], cands=cands, gflop=fl / 1e9))
     log("# decisions", len(decisions))
     for d in decisions:
