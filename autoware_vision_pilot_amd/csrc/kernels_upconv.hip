@@ -70,7 +70,9 @@ __device__ __forceinline__ int bias_class(int m, int H2, int W2) {
 // weights likewise), two MFMAs per fragment pair, one output plane.  The chunk list is upconv_chunk's over HALVED channel counts (Cin / 2, Cs rounded up to
 // 64 and halved; ch0 doubled); the last chunk of a skip tensor of 32 or 96 channels (the 20x40, 160x320 and 320x640 stages) fills plane 0 only -- plane 1
 // of that chunk is zeroed at the halo store and its weights are zero (half of those steps' MFMAs multiply zeros: up to 18 % of a stage's steps, accepted).
-template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, bool SPLITK, bool X1 = false>
+// ABL (tools/upconv_ablate.hip only; 0 in the library): 1 = no halo loads / stores after the prologue, 2 = no MFMA, 16 = no epilogue (the accumulators stay
+// alive through a store no launch takes), 32 = epilogue arithmetic without the global stores, 128 = no weight DMA after the prologue
+template <int CO_TILE, int TH, int WCO, int WPX, bool HDB, int ACT, bool SPLITK, bool X1 = false, int ABL = 0>
 __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const UpconvParams p) {
   constexpr int NTH = 64 * WCO * WPX;
   constexpr int TW = 16, ROWB = 80, HWD = TW + 2, HPX = (TH + 2) * HWD, PX = TH * TW;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 
   // weight tile of slice step SIDX -> LDS buffer at byte offset WOFS (from w_base), asynchronously
 #define VP_DMA_W(WOFS, SIDX)                                                                 \
-  {                                                                                          \
+  if (!(ABL & 128) || (SIDX) < 2) {                                                          \
     const size_t base_ = (size_t)(SIDX) * w_step + w_goff0;                                  \
     char* dst_ = w_base + (WOFS) + wave * 1024;                                              \
     _Pragma("unroll") for (int pc = 0; pc < WPIECES; ++pc) {                                 \
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
   // a select here, inside the conditional block that issues the loads, is evaluated in that block -- the compiler put s_waitcnt vmcnt(0) right behind
   // the loads (seen in the ISA: a whole memory round trip exposed at every chunk's last step)
 #define VP_LOAD_H(D)                                                                         \
-  {                                                                                          \
+  if (!(ABL & 1) || abl_prologue) {                                                          \
     const half_t* sh_ = (D).skip ? p.sk_hi : p.in_hi;                                        \
     const half_t* sl_ = (D).skip ? (VP_SK_DEAD1(D) ? p.sk_hi : sk_p1) : in_p1;               \
     const int add_ = (D).skip ? ((D).qy * 2 * p.W + (D).qx) * p.Cs + CHM * (D).ch0 : CHM * (D).ch0; \
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
   }
   // DEAD1: plane 1 of the chunk in the registers does not exist (X1: a chunk of a 32-channel skip tensor): zeros
 #define VP_STORE_H(BUF, DEAD1)                                                               \
+  if (!(ABL & 1) || abl_prologue)                                                            \
   _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) {                                        \
     if (tid + NTH * pc < HCHUNKS) {                                                          \
       char* dst_ = halo_base + (BUF) * PL * HSTRIDE + h_lds0 + pc * (NTH / 4) * ROWB;        \
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 #define VP_MFMA_RANGE(SET, Q0, Q1)                                                           \
   _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
     const int i = q_ / NT, j = q_ % NT;                                                      \
+    if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[SET][i][1] + (float)fb[SET][j][2] + (float)fbl[SET][j][3]; continue; } \
     if constexpr (X1) { /* the planes are K halves: a0 . b0 + a1 . b1 */                     \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);   \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 #define VP_TAP_OFS(D, K) ((((py + (D).a0 + ((D).nb == 2 ? ((K) >> 1) : (K))) * HWD) + px + (D).b0 + ((D).nb == 2 ? ((K) & 1) : 0)) * ROWB)
 
   // ---- prologue: halo(chunk cA) and weight tiles 0, 1 -> LDS; halo(chunk cA + 1) -> registers
+  bool abl_prologue = true;   // (ablation hooks: the prologue always stages)
   VP_LOAD_H(dA)
   VP_STORE_H(0, VP_SK_DEAD1(dA))
   VP_DMA_W(0, 0)
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     VP_LOAD_H(dn)
   }
   VP_READ_FRAGS(0, w_base, halo_base, VP_TAP_OFS(d, 0))
+  abl_prologue = false;
 
   int c = cA, t = 0, s = 0, hb = 0;
   int w_cur = 0, w_nxt = PL * W_BYTES, w_fre = 2 * PL * W_BYTES;   // byte offsets of the three weight buffers: read now / next step / being filled
@@ -352,6 +358,17 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
 #undef VP_DMA_W
 
   const PixPhase pix{y0, x0, p.H, p.W, py, px};
+  if constexpr ((ABL & 16) != 0) {   // ablation: keep the accumulators alive, skip the epilogue
+    if (p.H == -12345) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p.partial[(i * NT + j) * 16 + r + tid * 64] = acc[i][j][r];
+    }
+    return;
+  }
   if constexpr (SPLITK) {
     // fp32 partial sums straight from the accumulators: lanes l and l + 32 hold channels 8g + 0..3 / 8g + 4..7 of pixel l & 31
     const int M2 = 4 * p.H * p.W;
@@ -424,6 +441,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, 2) void upconv_x3_kernel(const Upco
     for (int r = r0; r < PX; r += RPI) {
       const int m = pix(r);
       if (m < 0) continue;
+      if constexpr ((ABL & 32) != 0) { if (p.H != -12345) continue; }   // ablation: epilogue arithmetic and staging, no global stores
       const size_t o = (size_t)m * p.Cstore + co;
       *reinterpret_cast<h8_t*>(p.out_hi + o) = *reinterpret_cast<const h8_t*>(smem + r * PITCH + c8 * 16);
       if constexpr (!X1) *reinterpret_cast<h8_t*>(p.out_lo + o) = *reinterpret_cast<const h8_t*>(smem + STAGE_PLANE + r * PITCH + c8 * 16);
