@@ -69,6 +69,24 @@ class _ModelEngine(_lib.Engine):
         self._give_back()
         super().upload_frame(frame_u8, index)
 
+    # every other frame-consuming entry of the Engine gives the mode back as well: a caller that mixes them with
+    # inference_resized() always runs on its OWN resize mode
+    def infer_pair(self, prev_u8, cur_u8):
+        self._give_back()
+        return super().infer_pair(prev_u8, cur_u8)
+
+    def enqueue(self):
+        self._give_back()
+        super().enqueue()
+
+    def enqueue_multi(self, heads):
+        self._give_back()
+        super().enqueue_multi(heads)
+
+    def profile_layers(self, iters=10):
+        self._give_back()
+        return super().profile_layers(iters)
+
 
 class _NetworkInfer:
     _kind = None

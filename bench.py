@@ -12,7 +12,7 @@ frame: data = "synthetic".
 
 ``value`` is measured in the PARITY mode (fp16x3: every tensor a (hi, lo) fp16 pair, three fp16 MFMAs per product, fp32
 accumulate -- floats within 1e-3 of the fp32 oracle, class maps equal to the oracle's except tie flips inside that float tolerance
-(counted per pass in profiles/r05_parity_sweep.tsv; tests/test_gpu_networks.py, tests/test_gpu_parity_sweep.py), with the frame
+(counted per pass in profiles/r06_parity_sweep.tsv; tests/test_gpu_networks.py, tests/test_gpu_parity_sweep.py), with the frame
 resident in HBM and ``--streams`` frames in flight per GPU.  The same JSON line also carries
   single_stream_fps / p50_ms : one frame at a time (back-to-back / synchronised per frame), parity mode
   fp16_value ...             : the same three figures in plain fp16 (the reference's "fp16" configuration; NOT parity-grade)
@@ -88,7 +88,8 @@ def pmc_traffic(tag):
     m8 = re.match(r"conv3x3_x3w(8|4)<co(\d+),px(\d+)", tag)
     m = re.match(r"conv3x3_halo<co(\d+),px(\d+),x(\d)(,regepi)?>", tag)
     if mu:   # composed up-sampling stages: upconv_x3_kernel<CO_TILE, TH, WCO, WPX, HDB, ...>
-        pat = r"upconv_x3_kernel<128, 16, 2, 4, true" if mu.group(1) == "8" else r"upconv_x3_kernel<128, 8, 2, 2, false"
+        sk = "true" if "+splitk" in tag else "false"      # <..., HDB, ACT, SPLITK, X1, ABL>: the split launches are their own instantiation
+        pat = (r"upconv_x3_kernel<128, 16, 2, 4, true, \d, " if mu.group(1) == "8" else r"upconv_x3_kernel<128, 8, 2, 2, false, \d, ") + sk
     elif m8:   # the pipelined shapes: <CO_TILE, TH, WCO, WPX, HDB, ...>
         co8, px8 = int(m8.group(2)), int(m8.group(3))
         if m8.group(1) == "8":
@@ -711,7 +712,7 @@ def main():
         }
         prec_name = {"fp16": "fp16", "fp16x3": "fp16x3 (hi+lo fp16 pairs on the fp16 MFMA pipe, fp32 accumulate; fp32-class: floats within 1e-3 "
                                                "of the fp32 oracle, 0 class flips outside that float tolerance -- tie flips only, counted "
-                                               "per pass in profiles/r05_parity_sweep.tsv)"}[args.precision]
+                                               "per pass in profiles/r06_parity_sweep.tsv)"}[args.precision]
         names = {"sceneseg": "SceneSeg", "scene3d": "Scene3D", "egolanes": "EgoLanes", "domainseg": "DomainSeg"}
         wl = "+".join(names[k] for k in kinds)
         out = {

@@ -189,7 +189,9 @@ int vp_set_pinned_staging(vp_engine* e, int enable);
  * does not.  The synchronous vp_infer* calls return after the copy, as before.  Frames outside every registered range take the staged path.
  * What TensorRTBackend does with its own pinned input buffer (tensorrt_backend.cpp:184-186), offered to the caller's buffers instead.
  * vp_unregister_frames(pool) releases a range registered with exactly that pointer (after the last pass that read it was synchronised).
- * Returns VP_ERR_ARG (null / zero / overlapping an existing range / unknown pointer) or VP_ERR_HIP (the runtime refused to lock the pages). */
+ * Returns VP_ERR_ARG (null / zero / overlapping an existing range / unknown pointer) or VP_ERR_HIP (the runtime refused to lock the pages).
+ * Device context: the range is registered PORTABLE (usable from every device); the call itself runs on the calling thread's current HIP device
+ * (device 0 for a thread that never called hipSetDevice) -- a host may call it before or after vp_create, from any thread. */
 int vp_register_frames(const void* pool, size_t bytes);
 int vp_unregister_frames(const void* pool);
 /* {1, C, H, W} of the output tensor WITHOUT touching the device: vp_logits also returns the shape but fetches a de-selected tensor

@@ -5,6 +5,7 @@
 #   <tag>_bench_default.json                  python bench.py   (the driver's N = 1 command)
 #   <tag>_rocprofv3_kernel_stats_bench.csv    rocprofv3 --kernel-trace --stats of bench.py --no-secondary --no-cpu-baseline --no-fork --steps 100
 #   <tag>_pmc_traffic.json                    separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_conv.py, calibrated in-run (tools/pmc_summarize.py)
+#   <tag>_pmc_sq_conv.tsv                     SQ counters per dispatch of the matrix kernels (tools/pmc_sq_summarize.py)
 #   <tag>_layers_<net>_<precision>.tsv        per-launch HIP-event tables (tools/layer_profile.py)
 #   <tag>_trace_sceneseg_fp16x3.tsv           one SceneSeg frame inside the replayed graph (tools/trace_single_stream.py under --kernel-trace)
 TAG=${1:-r06}
@@ -38,6 +39,11 @@ rm -rf /tmp/pmc_f /tmp/pmc_w
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python $ROOT/tools/pmc_conv.py fp16x3 > /dev/null 2> /tmp/pmc_f.err)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $ROOT/tools/pmc_conv.py fp16x3 > /dev/null 2> /tmp/pmc_w.err)
 python tools/pmc_summarize.py /tmp/pmc_f /tmp/pmc_w $O/${TAG}_pmc_traffic.json 2>&1 | tail -5
+# ---- SQ counters of the matrix kernels (matrix-pipe busy share, clock, wait shares): one more counter pass of its own
+rm -rf /tmp/pmc_sq
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+  --output-format csv -d /tmp/pmc_sq -- python $ROOT/tools/pmc_conv.py fp16x3 > /dev/null 2> /tmp/pmc_sq.err)
+python tools/pmc_sq_summarize.py /tmp/pmc_sq > $O/${TAG}_pmc_sq_conv.tsv 2>/dev/null; head -20 $O/${TAG}_pmc_sq_conv.tsv | cut -c1-160
 # ---- per-launch tables and the in-graph trace
 for np in "sceneseg fp16x3" "scene3d fp16x3" "egolanes fp16x3" "domainseg fp16x3" "sceneseg fp16" "autodrive fp16"; do
   set -- $np

@@ -31,7 +31,7 @@ for f in cc:
             dur[k] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 last = OrderedDict()
 for k, d in disp.items():
-    if "conv3x3" not in d["name"] and "gemm_dma" not in d["name"] and "convt_rs" not in d["name"]:
+    if "conv3x3" not in d["name"] and "gemm_dma" not in d["name"] and "convt_rs" not in d["name"] and "upconv_x3" not in d["name"]:
         continue
     last[(d["name"], d["grid"])] = (k, d)
 print("# kernel\tgrid_threads\tdur_us\tclock_GHz\tmfma_busy\twait_any\twait_inst_any\tactive_inst_any\tinsts_valu")
