@@ -27,7 +27,9 @@ resident in HBM and ``--streams`` frames in flight per GPU.  The same JSON line 
   gather_fps                 : the metric configuration with the per-frame RCCL all-gather enqueued (world 1): the N = 1 anchor of --gather
 p50 / p99 are taken over --latency-iters (default 1000) synchronised iterations after 50 warm-up ones: the reference's protocol
 (Models/data_utils/benchmark.py:17-47).
-The timed region is floored at >= 1 s: if K steps would take less, K is raised (reported in ``steps``).
+Timing: with ``--steps K`` given (the driver's form) a timed region is EXACTLY K steps, fenced on both sides; the region is repeated until
+``--min-seconds`` (1 s) have been measured and the MEDIAN region is reported (``timed_regions`` in the line; a 20-step region is 37 ms, and one such
+sample moves by +-2 %).  Without ``--steps``: 300, raised until one region lasts ``--min-seconds``.
 
 Multi-GPU: the path shards by camera: rank r owns camera r, weights replicated, no data-path collective (the
 reference has none) -> "scaling": "weak".  ``--gather`` adds the per-frame RCCL all-gather of the per-camera masks through
@@ -207,7 +209,9 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps K.  Given: EXACTLY K steps per timed region (the contract), repeated over several such "
+                    "regions until --min-seconds have been measured, `value` from the MEDIAN region (`timed_regions` in the line).  Absent: 300, raised so "
+                    "that one region lasts --min-seconds")
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="seg+3d", choices=sorted(WORKLOADS))
     ap.add_argument("--kind", default=None, help="deprecated alias: --workload <kind>")
@@ -232,6 +236,9 @@ def main():
                     help="developer knob of the dispatch rules (vp_set_option; repeatable) -- the library does not read the environment; "
                          "whatever is set shows in the line's `library` and `plan_hash` fields")
     args = ap.parse_args()
+    exact_steps = args.steps is not None     # the driver's form (--steps K): K is honoured exactly
+    if args.steps is None:
+        args.steps = 300
     if args.kind:
         args.workload = args.kind
     Camera.fork = not args.no_fork
@@ -310,14 +317,23 @@ def main():
         return el
 
     def throughput(cams, steps, warmup, gather=False):
+        """(K, seconds of one K-step region).  --steps given: K = steps exactly, the region repeated (each one fenced on both sides, max over ranks) until
+        --min-seconds are covered, at most 40 times, and the MEDIAN region reported; otherwise K is raised until one region lasts --min-seconds."""
         timed(cams, max(1, warmup), gather)
         probe = timed(cams, min(max(steps, 1), 20), gather) / min(max(steps, 1), 20)
-        k = max(steps, int(math.ceil(1.15 * args.min_seconds / max(probe, 1e-6))))
-        if dist is not None:  # every rank must run the same number of steps
-            t = torch.tensor([k], dtype=torch.int64, device="cuda")
+        if exact_steps:
+            k = max(1, steps)
+            regions = max(1, min(40, int(math.ceil(args.min_seconds / max(probe * k, 1e-6)))))
+        else:
+            k, regions = max(steps, int(math.ceil(1.15 * args.min_seconds / max(probe, 1e-6)))), 1
+        if dist is not None:  # every rank must run the same number of steps and regions
+            t = torch.tensor([k, regions], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            k = int(t.item())
-        return k, timed(cams, k, gather)
+            k, regions = int(t[0].item()), int(t[1].item())
+        els = sorted(timed(cams, k, gather) for _ in range(regions))
+        throughput.regions = regions
+        return k, els[len(els) // 2]
+    throughput.regions = 1
 
     def latency(cam, iters):
         lat = []
@@ -335,11 +351,12 @@ def main():
         for c in cams:
             c.set_fork(False)
         k, el = throughput(cams, steps, warmup, gather)
+        main_regions = throughput.regions
         cams[0].set_fork(True)
         k1, el1 = throughput(cams[:1], max(steps // 3, 1), 3)
         lat = latency(cams[0], args.latency_iters)
         cams[0].set_fork(False)
-        return dict(steps=k, elapsed=el, fps=world * k / el, single=k1 / el1, latency_iters=len(lat),
+        return dict(steps=k, elapsed=el, regions=main_regions, fps=world * k / el, single=k1 / el1, latency_iters=len(lat),
                     p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)))
 
     def ego_engine():
@@ -719,7 +736,7 @@ def main():
             "metric": f"frames/sec ({wl} {fw}x{fh}, one camera per GPU: preprocess + shared encoder + "
                       f"{len(kinds)} decoder(s) + decode per frame); p50 per-frame latency beside it",
             "value": round(main_fig["fps"], 2), "unit": "frames/s", "n_gpus": world, "steps": main_fig["steps"],
-            "steps_requested": args.steps, "warmup": args.warmup,
+            "steps_requested": args.steps, "timed_regions": main_fig["regions"], "warmup": args.warmup,
             "ms_per_step": round(1e3 * main_fig["elapsed"] / main_fig["steps"], 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": prec_name, "data": "synthetic",
             "config": {"workload": f"BASELINE.json metric configuration: {wl} on one {fw}x{fh} camera per GPU, batch 1, "
