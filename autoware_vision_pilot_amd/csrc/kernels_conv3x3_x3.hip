@@ -160,6 +160,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
 
   // fragment sets [K sub-step parity]: set 0 = channels 0..15 of the tap's 32, set 1 = channels 16..31
   h8_t fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
+  // ABL 4096 (prototype, tools/x3_ablate.hip): the WEIGHT fragments travel global -> registers directly, three steps deep, instead of through LDS
+  // (no weight DMA, no weight ds_reads; the host packing is the LDS image, so a lane's fragment is 16 contiguous bytes at the same offset)
+  constexpr bool DIRECT_A = (ABL & 4096) != 0;
+  h8_t ra[DIRECT_A ? 3 : 1][2][MT], ral[DIRECT_A ? 3 : 1][2][MT];
+  const size_t w_a0 = (size_t)c_first * 9 * w_step + co0 * 32;
   // halo staging ring (compile-time slots): piece pc in slot pc
   u32x4 rh_hi[RING], rh_lo[RING];
 #pragma unroll
@@ -175,6 +180,17 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
     _Pragma("unroll") for (int pc = 0; pc < WPIECES; ++pc) {                                 \
       VP_GLOBAL_LOAD_LDS16(p.w_hi + base_ + pc * NW * 512, dst_ + pc * NW * 1024);           \
       VP_GLOBAL_LOAD_LDS16(p.w_lo + base_ + pc * NW * 512, dst_ + W_BYTES + pc * NW * 1024); \
+    }                                                                                        \
+  }
+#define VP_LOAD_A(RSLOT, SIDX)                                                               \
+  {                                                                                          \
+    const int si_ = (SIDX) < s_last ? (SIDX) : s_last;                                       \
+    const size_t base_ = (size_t)si_ * w_step + w_a0;                                        \
+    _Pragma("unroll") for (int ss_ = 0; ss_ < 2; ++ss_)                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
+      const size_t o_ = base_ + (size_t)(((a_ofs0 ^ (ss_ * 32)) + i * WCO * 32 * WROW) >> 1); \
+      ra[RSLOT][ss_][i] = *reinterpret_cast<const h8_t*>(p.w_hi + o_);                       \
+      ral[RSLOT][ss_][i] = *reinterpret_cast<const h8_t*>(p.w_lo + o_);                      \
     }                                                                                        \
   }
 #define VP_LOAD_H(SLOT, PC, C)                                                               \
@@ -195,9 +211,11 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
 #define VP_READ_FRAGS(SET, WBUF, HBUF, TAPOFS)                                               \
   {                                                                                          \
     const char* wsrc_ = (WBUF) + (a_ofs0 ^ ((SET) * 32));                                    \
+    if constexpr (!DIRECT_A) {                                                               \
     _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                         \
       fa[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + i * WCO * 32 * WROW);              \
       fal[SET][i] = *reinterpret_cast<const h8_t*>(wsrc_ + W_BYTES + i * WCO * 32 * WROW);   \
+    }                                                                                        \
     }                                                                                        \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                         \
       fb[SET][j] = *reinterpret_cast<const h8_t*>((HBUF) + b_ofs0 + j * 2 * HWD * ROWB + (TAPOFS) + (SET) * 32); \
@@ -210,6 +228,12 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
   _Pragma("unroll") for (int q_ = (Q0); q_ < (Q1); ++q_) {                                   \
     const int i = q_ / NT, j = q_ % NT;                                                      \
     if constexpr ((ABL & 2) != 0) { acc[i][j][0] += (float)fa[SET][i][0] + (float)fal[SET][i][1] + (float)fb[SET][j][2] + (float)fbl[SET][j][3]; continue; } \
+    if constexpr (DIRECT_A) {                                                                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ral[aslot_][SET][i], fb[SET][j], acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[aslot_][SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ra[aslot_][SET][i], fb[SET][j], acc[i][j], 0, 0, 0);  \
+      continue;                                                                              \
+    }                                                                                        \
     if constexpr (X1) { /* the planes are K halves: a0 . b0 + a1 . b1 */                     \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);   \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[SET][i], fbl[SET][j], acc[i][j], 0, 0, 0); \
@@ -226,6 +250,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
 #define VP_TAP(T)                                                                            \
   {                                                                                          \
     constexpr int tap_ofs_ = (((T) / 3) * HWD + ((T) % 3)) * ROWB;                           \
+    constexpr int aslot_ = DIRECT_A ? (T) % 3 : 0;   /* 9 taps per chunk: the step's ring slot is the tap's */ \
     constexpr int tn_ = ((T) + 1) % 9;                                                       \
     constexpr int tap_next_ = ((tn_ / 3) * HWD + (tn_ % 3)) * ROWB;                          \
     const char* wcur_ = w_base + ((T) % 3) * PL * W_BYTES;                                   \
@@ -244,7 +269,9 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
     if constexpr (HDB && (T) == 3 && !(ABL & 1) && !(ABL & 64)) {                            \
       if (next_chunk) { _Pragma("unroll") for (int pc = 0; pc < HP; ++pc) VP_STORE_H(pc, pc, hb ^ 1) } \
     }                                                                                        \
-    if constexpr (!(ABL & 1) && !(ABL & 128)) {                                              \
+    if constexpr (DIRECT_A) {                                                                \
+      if (next_chunk || (T) < 7) VP_LOAD_A(((T) + 2) % 3, c * 9 + (T) + 2)                   \
+    } else if constexpr (!(ABL & 1) && !(ABL & 128)) {                                       \
       if (next_chunk || (T) < 7) VP_DMA_W(((T) + 2) % 3, c * 9 + (T) + 2)                     \
     }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
     /* round 4 (ISA): keep these MFMAs IN FRONT of the barrier's lgkmcnt(0) -- the scheduler moved five of the six behind it, so set 1's */ \
     /* reads were drained one MFMA after their issue                                                                                   */ \
     __builtin_amdgcn_sched_barrier(0);                                                       \
-    if constexpr (!(ABL & 1)) {                                                              \
+    if constexpr (!(ABL & 1) && !DIRECT_A) {                                                 \
       /* What THIS barrier must publish is the weight tile requested ONE STEP AGO (tile s+1: its first read follows this      */ \
       /* barrier); the tile requested in this step (s+2) is first read behind the NEXT barrier and stays in flight -- two taps */ \
       /* of lead for the L2 / Infinity-Cache round trip instead of one.  vmcnt counts in issue order, so "the previous step's  */ \
@@ -311,8 +338,13 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
     VP_LOAD_H(0, pc, 0)
     VP_STORE_H(0, pc, 0)
   }
-  VP_DMA_W(0, 0)
-  VP_DMA_W(1, 1)
+  if constexpr (DIRECT_A) {
+    VP_LOAD_A(0, 0)
+    VP_LOAD_A(1, 1)
+  } else {
+    VP_DMA_W(0, 0)
+    VP_DMA_W(1, 1)
+  }
   VP_WAIT_VMCNT(0);
   __syncthreads();
   VP_READ_FRAGS(0, w_base, halo_base, 0)
@@ -344,6 +376,7 @@ __global__ __launch_bounds__(64 * WCO * WPX, (CO_TILE == 64 && TH == 8) ? 3 : 2)
 #undef VP_READ_FRAGS
 #undef VP_STORE_H
 #undef VP_LOAD_H
+#undef VP_LOAD_A
 #undef VP_DMA_W
 
   // ---- register epilogue: bias + activation + (hi, lo) split, both planes staged as [pixel][CO_TILE] fp16, 16-byte stores.

@@ -60,10 +60,12 @@ static int run_shape(const char* name, int H, int W, int Cin, int Cout) {
   const float t0 = time_variant<TH, WPX, HDB, 0>(p, it), t16 = time_variant<TH, WPX, HDB, 16>(p, it), t1 = time_variant<TH, WPX, HDB, 1>(p, it),
               t4 = time_variant<TH, WPX, HDB, 4>(p, it), t8 = time_variant<TH, WPX, HDB, 8>(p, it), t2 = time_variant<TH, WPX, HDB, 2>(p, it),
               t29 = time_variant<TH, WPX, HDB, 1 | 4 | 8 | 16>(p, it), t21 = time_variant<TH, WPX, HDB, 1 | 4 | 16>(p, it),
-              t17 = time_variant<TH, WPX, HDB, 1 | 16>(p, it), t20 = time_variant<TH, WPX, HDB, 4 | 16>(p, it);
+              t17 = time_variant<TH, WPX, HDB, 1 | 16>(p, it), t20 = time_variant<TH, WPX, HDB, 4 | 16>(p, it),
+              tA = time_variant<TH, WPX, HDB, 4096>(p, it), tA8 = time_variant<TH, WPX, HDB, 4096 | 8>(p, it);
   std::printf("%-30s %5.1f GF | full %6.1f us (%5.1f TF alg) | noEpi %6.1f | noGlobal %6.1f | noLdsRead %6.1f | noBarrier %6.1f | noMFMA %6.1f | "
-              "noEpi+noGlobal %6.1f | noEpi+noLdsRead %6.1f | noEpi+noGlobal+noLdsRead %6.1f | MFMA+loop only %6.1f\n",
-              name, gflop, t0, gflop / t0 * 1e3, t16, t1, t4, t8, t2, t17, t20, t21, t29);
+              "noEpi+noGlobal %6.1f | noEpi+noLdsRead %6.1f | noEpi+noGlobal+noLdsRead %6.1f | MFMA+loop only %6.1f | weights global->registers (prototype) %6.1f, "
+              "without the per-step barrier %6.1f\n",
+              name, gflop, t0, gflop / t0 * 1e3, t16, t1, t4, t8, t2, t17, t20, t21, t29, tA, tA8);
   hipFree(in); hipFree(inl); hipFree(out); hipFree(outl); hipFree(w); hipFree(wl); hipFree(bias);
   return 0;
 }
