@@ -142,11 +142,13 @@ int main(int argc, char** argv) {
     // a head's logits convolution (kernels_head.hip) is reached through mode 3 only: see conv_logits below
   }
   if (!skip_conv) {  // composed up-sampling stages, both precisions: x chunks + the four skip classes (4 / 2 / 2 / 1 taps), both shapes, K slices
-    bad |= upconv(1, 64, 16, 128, 24, 9, 17, 6, 1);
-    bad |= upconv(1, 64, 16, 128, 24, 5, 17, 7, quick ? 2 : 1);
-    bad |= upconv(0, 128, 16, 128, 24, 9, 17, 6, 1);        // fp16 form: 64-channel chunks, the skip chunk's second half dead
-    bad |= upconv(0, 128, 16, 128, 72, 5, 17, 7, 2);        // ... 96 skip channels: one full + one half-dead chunk per class, K slices
-    if (!quick) bad |= upconv(1, 96, 16, 128, 0, 17, 19, 6, 1);
+    bad |= upconv(1, 64, 16, 128, 24, 5, 17, 7, 2);           // 4-wave shape: single halo image rewritten between two barriers; K slices + finish kernel
+    bad |= upconv(0, 128, 16, 128, 24, 5, 17, 6, 1);          // fp16 form on the 8-wave shape: double-buffered halo, 64-channel chunks, half-dead skip chunk
+    if (!quick) {
+      bad |= upconv(1, 64, 16, 128, 24, 9, 17, 6, 1);
+      bad |= upconv(0, 128, 16, 128, 72, 5, 17, 7, 2);        // 96 skip channels: one full + one half-dead chunk per class, K slices
+      bad |= upconv(1, 96, 16, 128, 0, 17, 19, 6, 1);
+    }
   }
   if (!skip_conv) {  // heads' logits convolution: DMA halo + zero page, slab reduction through LDS (128 channels)
     bad |= conv_logits(1, 128, 3, quick ? 5 : 9, quick ? 17 : 33);
