@@ -507,6 +507,18 @@ int vp_layer_kernel(const vp_engine* e, int i, const char** kernel) {
   return VP_OK;
 }
 // launch geometry beyond the tag ("nsplit=4", "groups=32", "nsplit=2 wgs=128"; "" when the tag says it all): what vp_plan_hash mixes in third
+// AutoSteerOnnxEngine::postProcess (production_release/src/inference/autosteer_engine.cpp:160-185): first maximum wins, angle = class - 30
+float vp_autosteer_angle(const float* logits, int classes) {
+  if (!logits || classes < 1) return 0.0f;
+  int best = 0;
+  float best_v = logits[0];
+  for (int i = 1; i < classes; ++i)
+    if (logits[i] > best_v) {
+      best_v = logits[i];
+      best = i;
+    }
+  return static_cast<float>(best - 30);
+}
 int vp_layer_launch(const vp_engine* e, int i, const char** launch) {
   if (!e || !e->impl || !launch || i < 0 || i >= (int)e->impl->ops().size()) return VP_ERR_ARG;
   *launch = e->impl->ops()[i].launch.c_str();

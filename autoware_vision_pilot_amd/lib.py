@@ -85,6 +85,7 @@ _SIGS = {
     "vp_layer_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vp_layer_kernel": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p)]),
     "vp_layer_launch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p)]),
+    "vp_autosteer_angle": (C.c_float, [_P, C.c_int]),
     "vp_copy_outputs_device": (C.c_int, [_P, _P, _P]),
     "vp_profile_layers": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "vp_layer_flops_executed": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
@@ -719,6 +720,12 @@ def op_upconv(x, wt, bt, w3, b3, skip=None, ws=None, bs=None, act=1, shape=-1, n
     if rc != 0:
         raise VpError(f"vp_op_upconv failed ({rc}): {err.value.decode(errors='replace')}")
     return out
+
+
+def autosteer_angle(logits):
+    """vp_autosteer_angle: AutoSteerOnnxEngine::postProcess -- first arg-max over the head's logits (61 classes) minus 30 degrees (host only)."""
+    a = np.ascontiguousarray(logits, dtype=np.float32).reshape(-1)
+    return float(load().vp_autosteer_angle(_ptr(a), int(a.size)))
 
 
 def resample_coeffs(in_size, out_size, mode):

@@ -262,6 +262,11 @@ int vp_input_tensor(vp_engine* e, float* dst_1x3x320x640);                     /
 int vp_set_lane_ring(vp_engine* e, int enable);
 int vp_lane_ring_device(const vp_engine* e, void** dev_f32_6x80x160, int* frames_valid);
 int vp_lane_ring_fetch(vp_engine* e, float* dst_host_6x80x160, int* frames_valid);
+/* The other end of that head, AutoSteerOnnxEngine::postProcess (autosteer_engine.cpp:160-185): arg-max over the `classes` (61) logits of the head's
+ * SECOND output, strict '>' from class 0 (the first maximum wins, a NaN never wins), steering angle = class - 30 degrees.  Host arithmetic on 61 floats
+ * (no device work): offered so that a host replacing the engine class keeps the decode bit for bit.  Returns 0 (the reference's failure value) for
+ * logits == NULL or classes < 1. */
+float vp_autosteer_angle(const float* logits, int classes);
 
 /* ---- asynchronous / device-resident path (bench, multi-GPU) ---------------------------------------------- */
 int vp_upload_frame(vp_engine* e, const uint8_t* frame, int h, int w, int stride_bytes); /* H2D, frame stays in HBM */

@@ -383,3 +383,29 @@ def test_fp8_codes_reproduce_the_quantised_weights():
     rec = decode(codes) * scale.astype(np.float64)[:, None]
     assert np.abs(rec - wf).max() <= 4e-7 * np.abs(wf).max()
     assert (np.abs(decode(codes)).max(axis=1) == 448.0).all()                 # every row's maximum is the largest code, as the quantiser made it
+
+
+def test_autosteer_angle_is_the_reference_postprocess():
+    """vp_autosteer_angle (host arithmetic, no device): AutoSteerOnnxEngine::postProcess, autosteer_engine.cpp:160-185 -- strict '>' arg-max from class 0
+    over the 61 logits of the head's second output (the FIRST maximum wins; a NaN never wins), angle = class - 30.  Against a line-by-line Python
+    restatement on random logits, ties, a NaN, a maximum at either end; NULL / empty input gives the reference's failure value 0."""
+    from autoware_vision_pilot_amd import lib
+
+    def ref(v):
+        best, best_v = 0, v[0]
+        for i in range(1, len(v)):
+            if v[i] > best_v:
+                best, best_v = i, v[i]
+        return float(best - 30)
+
+    rng = np.random.default_rng(61)
+    cases = [rng.standard_normal(61).astype(np.float32) for _ in range(20)]
+    t = np.zeros(61, np.float32); t[[7, 40]] = 3.0; cases.append(t)                      # tie: class 7 wins
+    t = rng.standard_normal(61).astype(np.float32); t[12] = np.nan; t[50] = 9.0; cases.append(t)
+    t = np.full(61, -1.0, np.float32); t[60] = 0.0; cases.append(t)                       # +30 degrees
+    t = np.full(61, -1.0, np.float32); t[0] = 0.0; cases.append(t)                        # -30 degrees
+    cases.append(np.array([np.nan] + [0.0] * 60, np.float32))                             # NaN first: nothing is '>' NaN -> class 0
+    for v in cases:
+        assert lib.autosteer_angle(v) == ref(v)
+    assert lib.load().vp_autosteer_angle(None, 61) == 0.0
+    assert lib.autosteer_angle(np.array([5.0], np.float32)) == -30.0
